@@ -1,0 +1,138 @@
+"""Deterministic synthetic triangle meshes used by tests and bench.py.
+
+The reference's own fixtures (unit cube, three planes; test/main.cpp:14-61 with the quad->triangle rule of
+test/testutil.hpp:84-106) are regenerated here as data; the sphere family stands in for the assets
+BASELINE.json names (Spot / Dragon / Sponza are not in the reference tree and there is no network).
+All generators return float32 arrays shaped [T, 9] (three xyz vertices per triangle).
+"""
+import numpy as np
+
+# test/main.cpp:20-38 (vertex and quad-element tables, data only)
+_UNIT_CUBE_VERTS = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1],
+                             [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]], dtype=np.float32)
+_UNIT_CUBE_QUADS = np.array([[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1],
+                             [2, 3, 7, 6], [0, 2, 6, 4], [1, 5, 7, 3]])
+# test/main.cpp:40-61
+_THREE_PLANES_VERTS = np.array([[x, 0, 0] for x in (0.0, 0.5, 1.0)], dtype=np.float32)
+
+
+def _quads_to_tris(verts, quads):
+    """Quad (0,1,2,3) -> triangles (0,1,2), (2,3,0): test/testutil.hpp:84-106."""
+    tris = []
+    for q in quads:
+        tris.append([verts[q[0]], verts[q[1]], verts[q[2]]])
+        tris.append([verts[q[2]], verts[q[3]], verts[q[0]]])
+    return np.asarray(tris, dtype=np.float32).reshape(-1, 9)
+
+
+def unit_cube():
+    return _quads_to_tris(_UNIT_CUBE_VERTS, _UNIT_CUBE_QUADS)
+
+
+def three_planes():
+    verts = []
+    for x in (0.0, 0.5, 1.0):
+        verts += [[x, 0, 0], [x, 0, 1], [x, 1, 1], [x, 1, 0]]
+    verts = np.asarray(verts, dtype=np.float32)
+    quads = np.arange(12).reshape(3, 4)
+    return _quads_to_tris(verts, quads)
+
+
+def single_triangle():
+    """test/main.cpp:14-18."""
+    return np.array([[0, 0, 0, 0, 0, 1, 1, 0, 0]], dtype=np.float32)
+
+
+def uv_sphere(nv, nu=None, radius=1.0, center=(0.0, 0.0, 0.0), with_uv=False):
+    """UV sphere with nv latitude bands and nu (=2*nv) longitude segments, poles on the y axis.
+
+    T = 2*nu*(nv-1) triangles (pole bands contribute one triangle per segment).
+    Vertices are computed in float64 and rounded once to float32, so the mesh is reproducible bit-for-bit.
+    """
+    nu = 2 * nv if nu is None else nu
+    theta = np.pi * np.arange(nv + 1, dtype=np.float64) / nv          # 0..pi
+    phi = 2.0 * np.pi * np.arange(nu + 1, dtype=np.float64) / nu      # 0..2pi
+    st, ct = np.sin(theta), np.cos(theta)
+    sp, cp = np.sin(phi), np.cos(phi)
+    sp[-1], cp[-1] = sp[0], cp[0]  # close the seam exactly
+    st[0] = st[-1] = 0.0
+    P = np.empty((nv + 1, nu + 1, 3), dtype=np.float64)
+    P[..., 0] = radius * st[:, None] * cp[None, :] + center[0]
+    P[..., 1] = radius * ct[:, None] * np.ones_like(cp)[None, :] + center[1]
+    P[..., 2] = radius * st[:, None] * sp[None, :] + center[2]
+    UV = np.empty((nv + 1, nu + 1, 2), dtype=np.float64)
+    UV[..., 0] = (np.arange(nu + 1) / nu)[None, :]
+    UV[..., 1] = (np.arange(nv + 1) / nv)[:, None]
+    i, j = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    a, b, c, d = (i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)
+    tri1 = (a, b, c)   # valid unless i == nv-1 (b == c at the south pole)
+    tri2 = (a, c, d)   # valid unless i == 0 (a == d at the north pole)
+    m1 = i != nv - 1
+    m2 = i != 0
+    tris, uvs = [], []
+    for (p, q, r), m in ((tri1, m1), (tri2, m2)):
+        tris.append(np.stack([P[p[0][m], p[1][m]], P[q[0][m], q[1][m]], P[r[0][m], r[1][m]]], axis=1))
+        uvs.append(np.stack([UV[p[0][m], p[1][m]], UV[q[0][m], q[1][m]], UV[r[0][m], r[1][m]]], axis=1))
+    # interleave so that triangle order follows the (i, j) sweep rather than all-tri1-then-all-tri2
+    order = np.argsort(np.concatenate([2 * np.flatnonzero(m1), 2 * np.flatnonzero(m2) + 1]), kind="stable")
+    verts = np.concatenate(tris, axis=0)[order].astype(np.float32).reshape(-1, 9)
+    if with_uv:
+        return verts, np.concatenate(uvs, axis=0)[order].astype(np.float32).reshape(-1, 6)
+    return verts
+
+
+def triangle_colors(T):
+    """Per-triangle colours ((37i)%256, (91i)%256, (13i)%256)/255."""
+    i = np.arange(T, dtype=np.int64)
+    return (np.stack([(37 * i) % 256, (91 * i) % 256, (13 * i) % 256], axis=1) / 255.0).astype(np.float32)
+
+
+def checker_texture(size=256, tiles=16):
+    """Procedural RGB texture: checkerboard modulated by a gradient; uint8 [size, size, 3]."""
+    y, x = np.mgrid[0:size, 0:size]
+    chk = (((x * tiles) // size + (y * tiles) // size) & 1).astype(np.uint8)
+    img = np.empty((size, size, 3), dtype=np.uint8)
+    img[..., 0] = (x * 255) // (size - 1)
+    img[..., 1] = (y * 255) // (size - 1)
+    img[..., 2] = 40 + 200 * chk
+    return img
+
+
+def box_room(n=8):
+    """Axis-aligned box interior made of n x n quads per wall (large aligned triangles: exercises the
+    aligned fast path of voxelization.cpp:335-347,503 and large leaves)."""
+    tris = []
+    g = np.linspace(0.0, 1.0, n + 1)
+    for axis in range(3):
+        for side in (0.0, 1.0):
+            for a in range(n):
+                for b in range(n):
+                    def pt(u, v):
+                        p = [0.0, 0.0, 0.0]
+                        p[axis] = side
+                        p[(axis + 1) % 3] = u
+                        p[(axis + 2) % 3] = v
+                        return p
+                    q = [pt(g[a], g[b]), pt(g[a + 1], g[b]), pt(g[a + 1], g[b + 1]), pt(g[a], g[b + 1])]
+                    tris.append([q[0], q[1], q[2]])
+                    tris.append([q[2], q[3], q[0]])
+    return np.asarray(tris, dtype=np.float32).reshape(-1, 9)
+
+
+def random_soup(T, seed=0, scale=0.2):
+    """Random small triangles in the unit cube plus a few large diagonal ones (subdivision-heavy)."""
+    rng = np.random.default_rng(seed)
+    c = rng.random((T, 1, 3), dtype=np.float64)
+    v = c + scale * (rng.random((T, 3, 3), dtype=np.float64) - 0.5)
+    return np.clip(v, 0.0, 1.0).astype(np.float32).reshape(-1, 9)
+
+
+def sorted_voxels(vox):
+    """Canonical order for comparing unordered (x,y,z,argb) outputs: sort by z, y, x."""
+    vox = np.asarray(vox, dtype=np.uint32).reshape(-1, 4)
+    if vox.shape[0] == 0:
+        return vox
+    key = (vox[:, 2].astype(np.uint64) << np.uint64(42)) | (vox[:, 1].astype(np.uint64) << np.uint64(21)) \
+        | vox[:, 0].astype(np.uint64)
+    return vox[np.argsort(key, kind="stable")]

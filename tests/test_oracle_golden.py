@@ -1,0 +1,59 @@
+"""Pins the CPU oracle on every result the reference's own tests hold for the hot path.
+
+Reference: test/main.cpp:120-126 (expected unit cube count), :128-156 (cube @64), :194-208 (cube @128 = two
+chunks per axis), :225-237 (three planes @32), :239-252 (three planes @128).
+"""
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+
+def expected_unit_cube_voxels(r):
+    # test/main.cpp:120-126
+    return 8 + 12 * (r - 2) + 6 * (r - 2) * (r - 2)
+
+
+@pytest.mark.parametrize("res", [64, 128])
+def test_unit_cube_known_answer(oracle, res):
+    vox = oracle.voxelize(meshes.unit_cube(), res)
+    assert len(vox) == expected_unit_cube_voxels(res)
+    assert {64: 23816, 128: 96776}[res] == len(vox)
+    # every voxel lies on the cube surface and is white/opaque (MATERIALLESS, triangle.hpp:186)
+    xyz = vox[:, :3]
+    on_surface = ((xyz == 0) | (xyz == res - 1)).any(axis=1)
+    assert on_surface.all()
+    assert (vox[:, 3] == 0xFFFFFFFF).all()
+    assert len(np.unique(xyz, axis=0)) == len(vox)
+
+
+@pytest.mark.parametrize("res", [32, 128])
+def test_three_planes_known_answer(oracle, res):
+    vox = oracle.voxelize(meshes.three_planes(), res)
+    assert len(vox) == 3 * res * res
+    # x = 0.5 maps to exactly res/2 (0.25 + 0.5*(res-0.5)), whose voxel AABB is the single slice res/2
+    assert np.unique(vox[:, 0]).tolist() == [0, res // 2, res - 1]
+
+
+def test_empty_mesh(oracle):
+    assert len(oracle.voxelize(np.zeros((0, 9), np.float32), 32)) == 0
+
+
+def test_slab_filter_is_subset(oracle):
+    s = meshes.uv_sphere(10)
+    full = meshes.sorted_voxels(oracle.voxelize(s, 96))
+    parts = [oracle.voxelize(s, 96, zslab=(z, z + 32)) for z in (0, 32, 64)]
+    got = meshes.sorted_voxels(np.concatenate(parts))
+    assert np.array_equal(full, got)
+
+
+def test_oracle_regression_vectors(oracle):
+    """Drift detector: vectors in tests/golden/oracle_regression.npz were produced by THIS oracle
+    (tests/golden/make_golden.py); they are not reference outputs."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "oracle_regression.npz")
+    data = np.load(path)
+    from tests.golden.make_golden import CASES, run_case
+    for name in CASES:
+        vox = meshes.sorted_voxels(run_case(oracle, name))
+        assert np.array_equal(vox, data[name]), name

@@ -1,0 +1,621 @@
+// o2v_api.cpp -- host side of the drop-in C API (include/obj2voxel.h).
+//
+// Mirrors the reference's instance / setter / voxelize layer (src/obj2voxel.cpp:142-173, :578-637, :645-1003)
+// and replaces its chunk loop with one call sequence into the HIP pipeline through the C-ABI of o2v_hip.h.
+// There is no CPU voxelization path in this library: without a usable GPU obj2voxel_voxelize() logs an error
+// and returns OBJ2VOXEL_ERR_DEVICE.
+#include "o2v_io.hpp"
+
+#include "../../include/o2v_hip.h"
+#include "../../include/obj2voxel.h"
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// Extension to the reference's error codes: the GPU pipeline could not run (no device, HIP failure, device OOM).
+static const obj2voxel_error_t OBJ2VOXEL_ERR_DEVICE = 8;
+
+using namespace o2v;
+
+// ---- opaque API types ------------------------------------------------------------------------------------
+
+// reference src/triangle.hpp:148-167 (wrapper around voxelio::Image)
+struct obj2voxel_texture {
+    std::vector<uint8_t> pixels;
+    size_t width = 0, height = 0, channels = 0;
+    uint32_t wrap = 1;  // REPEAT is the default (include/obj2voxel.h:346-347)
+    bool loaded() const { return !pixels.empty(); }
+};
+
+// reference src/triangle.hpp:170-195; filled only through obj2voxel_set_triangle_*
+struct obj2voxel_triangle {
+    float v[9];
+    float t[6];
+    uint32_t type;
+    float color[3];
+    const obj2voxel_texture *texture;
+};
+
+namespace {
+
+// ---- logging (reference obj2voxel.cpp:639-682; process-global like the reference) ------------------------
+
+obj2voxel_enum_t g_log_level = OBJ2VOXEL_LOG_LEVEL_INFO;  // constants.hpp:21 (release default)
+obj2voxel_log_callback *g_log_callback = nullptr;
+void *g_log_callback_data = nullptr;
+std::mutex g_log_mutex;
+
+}  // namespace
+
+namespace o2v {
+
+void log_message(int level, const std::string &msg)
+{
+    if (level > g_log_level) return;
+    std::lock_guard<std::mutex> lock{g_log_mutex};
+    if (g_log_callback && g_log_callback(g_log_callback_data, msg.c_str(), (obj2voxel_enum_t) level)) return;
+    static const char *names[] = {"", "ERROR", "WARNING", "INFO", "DEBUG"};
+    std::fprintf(level <= OBJ2VOXEL_LOG_LEVEL_WARNING ? stderr : stdout, "[obj2voxel] [%s] %s\n",
+                 names[level < 0 || level > 4 ? 0 : level], msg.c_str());
+}
+
+}  // namespace o2v
+
+namespace {
+
+#define O2V_ASSERT(cond, msg)                                                              \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            std::fprintf(stderr, "[obj2voxel] assertion failed: %s (%s)\n", #cond, msg);   \
+            std::abort();                                                                  \
+        }                                                                                  \
+    } while (0)
+
+enum class IoKind { MISSING, FILE, MEMORY, CALLBACK };
+
+}  // namespace
+
+// reference src/obj2voxel.cpp:142-173
+struct obj2voxel_instance {
+    IoKind input_kind = IoKind::MISSING;
+    const char *input_path = nullptr;  // borrowed, read at voxelize time like the reference (:714-720)
+    FileFormat input_format = FileFormat::UNKNOWN;
+    obj2voxel_triangle_callback *input_callback = nullptr;
+    void *input_callback_data = nullptr;
+
+    IoKind output_kind = IoKind::MISSING;
+    const char *output_path = nullptr;
+    FileFormat output_format = FileFormat::UNKNOWN;
+    obj2voxel_voxel_callback *output_callback = nullptr;
+    void *output_callback_data = nullptr;
+
+    obj2voxel_texture *default_texture = nullptr;
+    float mesh_bounds[6] = {0, 0, 0, 0, 0, 0};
+    bool bounds_known = false;
+    obj2voxel_enum_t strategy = OBJ2VOXEL_MAX_STRATEGY;
+    uint32_t output_resolution = 0;
+    uint32_t supersampling = 1;
+    bool parallel = false;
+    int unit_transform[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+
+    std::unique_ptr<VoxelSink> sink;
+
+    // worker compatibility (reference :957-1003): workers only register and wait
+    std::mutex worker_mutex;
+    std::condition_variable worker_cv;
+    uint32_t worker_count = 0;
+    uint32_t exit_tokens = 0;
+    bool workers_stopped = false;
+    bool done = false;
+};
+
+namespace {
+
+struct CallbackTriangleSource final : TriangleSource {
+    obj2voxel_triangle_callback *callback;
+    void *data;
+    CallbackTriangleSource(obj2voxel_triangle_callback *cb, void *d) : callback{cb}, data{d} {}
+    bool next(HostTriangle &out) override
+    {
+        // like `CachedTriangle triangle{}` (obj2voxel.cpp:585) the staging object is zeroed once and reused,
+        // so fields a setter does not write keep their previous value
+        if (!callback(data, &staging)) return false;
+        std::memcpy(out.v, staging.v, sizeof(out.v));
+        std::memcpy(out.t, staging.t, sizeof(out.t));
+        out.type = staging.type;
+        std::memcpy(out.color, staging.color, sizeof(out.color));
+        out.texture = staging.texture;
+        return true;
+    }
+    obj2voxel_triangle staging{};
+};
+
+struct CallbackVoxelSink final : VoxelSink {
+    obj2voxel_voxel_callback *callback;
+    void *data;
+    bool good = true;
+    CallbackVoxelSink(obj2voxel_voxel_callback *cb, void *d) : callback{cb}, data{d} {}
+    bool can_write() const override { return good; }
+    void write(uint32_t *voxels, size_t count) override
+    {
+        written += count;
+        good &= callback(data, voxels, count);  // reference io.cpp:638-653
+    }
+    void finalize() override {}
+};
+
+std::unique_ptr<TriangleSource> open_input(obj2voxel_instance &inst)
+{
+    switch (inst.input_kind) {
+    case IoKind::CALLBACK:
+        return std::unique_ptr<TriangleSource>{new CallbackTriangleSource{inst.input_callback, inst.input_callback_data}};
+    case IoKind::FILE:
+        switch (inst.input_format) {
+        case FileFormat::OBJ: return open_obj_file(inst.input_path, inst.default_texture);
+        case FileFormat::STL: return open_stl_file(inst.input_path);
+        default: return nullptr;
+        }
+    default: return nullptr;
+    }
+}
+
+std::unique_ptr<VoxelSink> open_output(obj2voxel_instance &inst)
+{
+    switch (inst.output_kind) {
+    case IoKind::CALLBACK:
+        return std::unique_ptr<VoxelSink>{new CallbackVoxelSink{inst.output_callback, inst.output_callback_data}};
+    case IoKind::FILE: return open_file_sink(inst.output_path, inst.output_format, inst.output_resolution);
+    case IoKind::MEMORY: return open_memory_sink(inst.output_format, inst.output_resolution);
+    default: return nullptr;
+    }
+}
+
+// The GPU leg of voxelize_specialized (reference obj2voxel.cpp:467-520): bounds, transform, per-triangle
+// voxelization, colour combine and packing all happen on the device; the host only moves data.
+obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, std::vector<HostTriangle> &tris)
+{
+    const uint64_t T = tris.size();
+    std::vector<float> verts(T * 9), uvs(T * 6), colors(T * 3);
+    std::vector<uint32_t> types(T);
+    std::vector<int32_t> texids(T);
+    std::map<const obj2voxel_texture *, int32_t> tex_index;
+    std::vector<const obj2voxel_texture *> tex_list;
+    bool any_uv = false;
+    for (uint64_t i = 0; i < T; ++i) {
+        const HostTriangle &t = tris[i];
+        std::memcpy(&verts[i * 9], t.v, sizeof(t.v));
+        std::memcpy(&uvs[i * 6], t.t, sizeof(t.t));
+        std::memcpy(&colors[i * 3], t.color, sizeof(t.color));
+        types[i] = t.type;
+        texids[i] = 0;
+        if (t.type == O2V_HIP_TRI_TEXTURED) {
+            O2V_ASSERT(t.texture != nullptr && t.texture->loaded(), "textured triangle without a loaded texture");
+            auto it = tex_index.find(t.texture);
+            if (it == tex_index.end()) {
+                it = tex_index.emplace(t.texture, (int32_t) tex_list.size()).first;
+                tex_list.push_back(t.texture);
+            }
+            texids[i] = it->second;
+            any_uv = true;
+        }
+    }
+    tris.clear();
+    tris.shrink_to_fit();
+
+    int device = 0;
+    if (const char *env = std::getenv("O2V_DEVICE")) device = std::atoi(env);
+    o2v_hip_ctx *ctx = nullptr;
+    int rc = o2v_hip_create(device, &ctx);
+    if (rc != O2V_HIP_OK) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device: the GPU voxelization path cannot run "
+                                               "and this library has no CPU fallback");
+        return OBJ2VOXEL_ERR_DEVICE;
+    }
+    struct Guard {
+        o2v_hip_ctx *c;
+        ~Guard() { o2v_hip_destroy(c); }
+    } guard{ctx};
+
+    auto device_error = [&](const char *what) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, std::string(what) + ": " + o2v_hip_last_error(ctx));
+        return OBJ2VOXEL_ERR_DEVICE;
+    };
+
+    std::vector<o2v_hip_texture> tex_desc;
+    for (const obj2voxel_texture *t : tex_list)
+        tex_desc.push_back(o2v_hip_texture{t->pixels.data(), (uint32_t) t->width, (uint32_t) t->height,
+                                           (uint32_t) t->channels, t->wrap});
+    if (!tex_desc.empty() && o2v_hip_set_textures(ctx, tex_desc.data(), (uint32_t) tex_desc.size()) != O2V_HIP_OK)
+        return device_error("uploading textures failed");
+    if (o2v_hip_set_triangles(ctx, verts.data(), any_uv ? uvs.data() : nullptr, types.data(), colors.data(),
+                              texids.data(), T) != O2V_HIP_OK)
+        return device_error("uploading triangles failed");
+
+    o2v_hip_params params{};
+    params.resolution = inst.output_resolution;
+    params.supersampling = inst.supersampling;
+    params.strategy = inst.strategy;
+    for (int i = 0; i < 9; ++i) params.unit_transform[i] = inst.unit_transform[i];
+    params.bounds_known = inst.bounds_known ? 1u : 0u;
+    for (int i = 0; i < 6; ++i) params.bounds[i] = inst.mesh_bounds[i];
+    params.z_begin = params.z_end = 0;
+
+    uint64_t count = 0;
+    if (o2v_hip_voxelize(ctx, &params, &count) != O2V_HIP_OK) return device_error("device voxelization failed");
+
+    o2v_hip_timings tm{};
+    o2v_hip_get_timings(ctx, &tm);
+    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "device pipeline: " + std::to_string(tm.total_ms) + " ms, " +
+                                               std::to_string(count) + " voxels, " + std::to_string(tm.passes) + " pass(es)");
+
+    // hand the (x, y, z, argb) records to the sink in batches (reference obj2voxel.cpp:298-303; the callback
+    // may be invoked any number of times, in any order)
+    constexpr uint64_t kBatch = 1u << 20;
+    std::vector<uint32_t> buffer(std::min<uint64_t>(count, kBatch) * 4);
+    for (uint64_t first = 0; first < count; first += kBatch) {
+        const uint64_t n = std::min<uint64_t>(kBatch, count - first);
+        if (!inst.sink->can_write()) break;
+        if (o2v_hip_read_voxels(ctx, buffer.data(), first, n) != O2V_HIP_OK) return device_error("reading voxels failed");
+        inst.sink->write(buffer.data(), n);
+    }
+    if (!inst.sink->can_write()) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "Voxelization failed because of IO error");
+        return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
+    }
+    log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Voxelized " + std::to_string(T) + " triangles, writing any buffered voxels ...");
+    inst.sink->finalize();
+    if (!inst.sink->can_write()) return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
+    log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "All " + std::to_string(inst.sink->written) + " voxels written");
+    return OBJ2VOXEL_ERR_OK;
+}
+
+// reference obj2voxel.cpp:602-637 (precondition order: done, input, output, resolution) and :578-600
+obj2voxel_error_t voxelize(obj2voxel_instance &inst)
+{
+    if (inst.done) return OBJ2VOXEL_ERR_DOUBLE_VOXELIZATION;
+    if (inst.input_kind == IoKind::MISSING) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No input was specified");
+        return OBJ2VOXEL_ERR_NO_INPUT;
+    }
+    if (inst.output_kind == IoKind::MISSING) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No output was specified");
+        return OBJ2VOXEL_ERR_NO_OUTPUT;
+    }
+    if (inst.output_resolution == 0) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No resolution was specified");
+        return OBJ2VOXEL_ERR_NO_RESOLUTION;
+    }
+    std::unique_ptr<TriangleSource> input = open_input(inst);
+    if (!input) return OBJ2VOXEL_ERR_IO_ERROR_ON_OPEN_INPUT_FILE;
+    inst.sink = open_output(inst);
+    if (!inst.sink) return OBJ2VOXEL_ERR_IO_ERROR_ON_OPEN_OUTPUT_FILE;
+
+    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "Caching triangles ...");
+    std::vector<HostTriangle> tris;
+    HostTriangle tri{};
+    while (input->next(tri)) tris.push_back(tri);
+
+    obj2voxel_error_t result;
+    if (tris.empty()) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_WARNING, "Model has no triangles, aborting and writing empty voxel model");
+        inst.sink->finalize();
+        result = inst.sink->can_write() ? OBJ2VOXEL_ERR_OK : OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
+    }
+    else {
+        log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Cached model with " + std::to_string(tris.size()) + " triangles");
+        result = voxelize_on_device(inst, tris);
+    }
+    if (inst.output_kind != IoKind::MEMORY) inst.sink.reset();
+    inst.done = true;
+    return result;
+}
+
+}  // namespace
+
+// ---- exported API ---------------------------------------------------------------------------------------
+
+extern "C" {
+
+obj2voxel_instance *obj2voxel_alloc(void) { return new obj2voxel_instance; }
+
+void obj2voxel_free(obj2voxel_instance *instance)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    delete instance;
+}
+
+void obj2voxel_set_log_level(obj2voxel_enum_t level)
+{
+    O2V_ASSERT(level <= OBJ2VOXEL_LOG_LEVEL_DEBUG, "invalid log level");
+    g_log_level = level;
+}
+
+obj2voxel_enum_t obj2voxel_get_log_level(void) { return g_log_level; }
+
+void obj2voxel_set_log_callback(obj2voxel_log_callback *callback, void *callback_data)
+{
+    std::lock_guard<std::mutex> lock{g_log_mutex};
+    g_log_callback = callback;
+    g_log_callback_data = callback_data;
+}
+
+void obj2voxel_set_resolution(obj2voxel_instance *instance, uint32_t resolution)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(resolution != 0, "resolution must not be zero");
+    instance->output_resolution = resolution;
+}
+
+void obj2voxel_set_supersampling(obj2voxel_instance *instance, uint32_t level)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(level == 1 || level == 2, "supersampling level must be 1 or 2");
+    instance->supersampling = level;
+}
+
+void obj2voxel_set_color_strategy(obj2voxel_instance *instance, obj2voxel_enum_t strategy)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(strategy < 2, "invalid colour strategy");
+    instance->strategy = strategy;
+}
+
+void obj2voxel_set_texture(obj2voxel_instance *instance, obj2voxel_texture *texture)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(texture != nullptr, "null texture");
+    instance->default_texture = texture;
+}
+
+void obj2voxel_set_input_file(obj2voxel_instance *instance, const char *file, const char *type)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(file != nullptr, "null file");
+    FileFormat f = detect_format(file, type);
+    O2V_ASSERT(f != FileFormat::UNKNOWN, "unrecognised input file type");
+    instance->input_kind = IoKind::FILE;
+    instance->input_path = file;
+    instance->input_format = f;
+}
+
+void obj2voxel_set_input_callback(obj2voxel_instance *instance, obj2voxel_triangle_callback *callback, void *callback_data)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(callback != nullptr, "null callback");
+    instance->input_kind = IoKind::CALLBACK;
+    instance->input_callback = callback;
+    instance->input_callback_data = callback_data;
+}
+
+void obj2voxel_set_output_file(obj2voxel_instance *instance, const char *file, const char *type)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(file != nullptr, "null file");
+    FileFormat f = detect_format(file, type);
+    O2V_ASSERT(f != FileFormat::UNKNOWN, "unrecognised output file type");
+    instance->output_kind = IoKind::FILE;
+    instance->output_path = file;
+    instance->output_format = f;
+}
+
+void obj2voxel_set_output_memory(obj2voxel_instance *instance, const char *type)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(type != nullptr, "null type");
+    FileFormat f = detect_format(nullptr, type);
+    O2V_ASSERT(f != FileFormat::UNKNOWN, "unrecognised output type");
+    instance->output_kind = IoKind::MEMORY;
+    instance->output_path = nullptr;
+    instance->output_format = f;
+}
+
+void obj2voxel_set_output_callback(obj2voxel_instance *instance, obj2voxel_voxel_callback *callback, void *callback_data)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(callback != nullptr, "null callback");
+    instance->output_kind = IoKind::CALLBACK;
+    instance->output_callback = callback;
+    instance->output_callback_data = callback_data;
+}
+
+void obj2voxel_set_parallel(obj2voxel_instance *instance, bool enabled)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    instance->parallel = enabled;
+}
+
+void obj2voxel_set_unit_transform(obj2voxel_instance *instance, const int transform[9])
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(transform != nullptr, "null transform");
+    std::memcpy(instance->unit_transform, transform, sizeof(instance->unit_transform));
+}
+
+void obj2voxel_set_mesh_boundaries(obj2voxel_instance *instance, const float bounds[6])
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(bounds != nullptr, "null bounds");
+    for (int i = 0; i < 6; ++i) O2V_ASSERT(bounds[i] - bounds[i] == 0.f, "mesh boundaries must be finite");
+    for (int i = 0; i < 3; ++i) O2V_ASSERT(bounds[i] <= bounds[i + 3], "lower mesh bound must be <= upper bound");
+    std::memcpy(instance->mesh_bounds, bounds, sizeof(instance->mesh_bounds));
+    instance->bounds_known = true;
+}
+
+uint32_t obj2voxel_get_resolution(obj2voxel_instance *instance)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    return instance->output_resolution;
+}
+
+uint32_t obj2voxel_get_chunk_size(obj2voxel_instance *instance)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    return 64;  // reference constants.hpp:10
+}
+
+const obj2voxel_byte_t *obj2voxel_get_output_memory(obj2voxel_instance *instance, size_t *out_size)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    O2V_ASSERT(instance->sink != nullptr || instance->output_kind != IoKind::MEMORY,
+               "accessing output memory before voxelization");
+    if (instance->output_kind != IoKind::MEMORY) return nullptr;
+    const std::vector<uint8_t> *bytes = instance->sink->memory();
+    O2V_ASSERT(bytes != nullptr, "memory sink without buffer");
+    *out_size = bytes->size();
+    return bytes->data();
+}
+
+void obj2voxel_set_triangle_basic(obj2voxel_triangle *triangle, const float vertices[9])
+{
+    triangle->type = O2V_HIP_TRI_MATERIALLESS;
+    std::memcpy(triangle->v, vertices, sizeof(triangle->v));
+}
+
+void obj2voxel_set_triangle_colored(obj2voxel_triangle *triangle, const float vertices[9], const float color[3])
+{
+    // the reference stores the colour but marks the triangle MATERIALLESS (obj2voxel.cpp:828-837): white
+    triangle->type = O2V_HIP_TRI_MATERIALLESS;
+    std::memcpy(triangle->v, vertices, sizeof(triangle->v));
+    std::memcpy(triangle->color, color, sizeof(triangle->color));
+}
+
+void obj2voxel_set_triangle_textured(obj2voxel_triangle *triangle, const float vertices[9], const float textures[6],
+                                     obj2voxel_texture *texture)
+{
+    triangle->type = O2V_HIP_TRI_TEXTURED;
+    std::memcpy(triangle->v, vertices, sizeof(triangle->v));
+    std::memcpy(triangle->t, textures, sizeof(triangle->t));
+    triangle->texture = texture;
+}
+
+obj2voxel_texture *obj2voxel_texture_alloc(void) { return new obj2voxel_texture; }
+
+void obj2voxel_texture_free(obj2voxel_texture *texture)
+{
+    O2V_ASSERT(texture != nullptr, "null texture");
+    delete texture;
+}
+
+bool obj2voxel_texture_load_from_file(obj2voxel_texture *texture, const char *file, const char *type)
+{
+    O2V_ASSERT(texture != nullptr, "null texture");
+    O2V_ASSERT(file != nullptr, "null file");
+    if (detect_format(file, type) != FileFormat::PNG) return false;
+    std::vector<uint8_t> bytes;
+    if (!read_whole_file(file, bytes)) return false;
+    return obj2voxel_texture_load_from_memory(texture, bytes.data(), bytes.size(), "png");
+}
+
+bool obj2voxel_texture_load_from_memory(obj2voxel_texture *texture, const obj2voxel_byte_t *data, size_t size,
+                                        const char *type)
+{
+    O2V_ASSERT(texture != nullptr, "null texture");
+    O2V_ASSERT(data != nullptr, "null data");
+    if (detect_format(nullptr, type) != FileFormat::PNG) return false;
+    std::vector<uint8_t> argb;
+    size_t w = 0, h = 0;
+    std::string err;
+    if (!decode_png_argb(data, size, argb, w, h, err)) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_WARNING, "PNG decode failed: " + err);
+        return false;
+    }
+    texture->pixels = std::move(argb);
+    texture->width = w;
+    texture->height = h;
+    texture->channels = 4;
+    return true;
+}
+
+bool obj2voxel_texture_load_pixels(obj2voxel_texture *texture, const obj2voxel_byte_t *pixels, size_t width,
+                                   size_t height, size_t channels)
+{
+    O2V_ASSERT(texture != nullptr, "null texture");
+    O2V_ASSERT(pixels != nullptr, "null pixels");
+    O2V_ASSERT(channels == 3 || channels == 4, "channels must be 3 (RGB) or 4 (ARGB)");
+    texture->pixels.assign(pixels, pixels + width * height * channels);
+    texture->width = width;
+    texture->height = height;
+    texture->channels = channels;
+    return true;
+}
+
+void obj2voxel_teture_set_uv_mode(obj2voxel_texture *texture, obj2voxel_enum_t mode)
+{
+    O2V_ASSERT(texture != nullptr && texture->loaded(), "can't set UV mode of empty texture");
+    texture->wrap = mode == OBJ2VOXEL_UV_CLAMP ? 0u : 1u;
+}
+
+void obj2voxel_texture_get_meta(obj2voxel_texture *texture, size_t *out_width, size_t *out_height, size_t *out_channels)
+{
+    O2V_ASSERT(texture != nullptr && texture->loaded(), "can't get metadata of empty texture");
+    *out_width = texture->width;
+    *out_height = texture->height;
+    *out_channels = texture->channels;
+}
+
+void obj2voxel_texture_get_pixels(obj2voxel_texture *texture, obj2voxel_byte_t *out_pixels)
+{
+    O2V_ASSERT(texture != nullptr && texture->loaded(), "can't get pixels of empty texture");
+    O2V_ASSERT(out_pixels != nullptr, "null output");
+    std::memcpy(out_pixels, texture->pixels.data(), texture->pixels.size());
+}
+
+obj2voxel_error_t obj2voxel_voxelize(obj2voxel_instance *instance)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    return voxelize(*instance);
+}
+
+// The GPU path retires the CPU worker pool (reference src/threading.hpp, obj2voxel.cpp:957-985): a worker only
+// registers, so that get_worker_count reflects it, and parks until stop_workers hands it an exit token.
+void obj2voxel_run_worker(obj2voxel_instance *instance)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    std::unique_lock<std::mutex> lock{instance->worker_mutex};
+    if (instance->workers_stopped) return;
+    ++instance->worker_count;
+    instance->worker_cv.wait(lock, [&] { return instance->exit_tokens != 0; });
+    --instance->exit_tokens;
+}
+
+void obj2voxel_stop_workers(obj2voxel_instance *instance)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    std::lock_guard<std::mutex> lock{instance->worker_mutex};
+    instance->workers_stopped = true;
+    instance->exit_tokens += instance->worker_count;  // one EXIT per registered worker (reference :993-995)
+    instance->worker_count = 0;
+    instance->worker_cv.notify_all();
+}
+
+uint32_t obj2voxel_get_worker_count(obj2voxel_instance *instance)
+{
+    O2V_ASSERT(instance != nullptr, "null instance");
+    std::lock_guard<std::mutex> lock{instance->worker_mutex};
+    return instance->worker_count;
+}
+
+}  // extern "C"
+
+// texture accessors for o2v_io.cpp (OBJ loader creates textures it owns)
+namespace o2v {
+obj2voxel_texture *texture_new() { return new obj2voxel_texture; }
+void texture_delete(obj2voxel_texture *t) { delete t; }
+bool texture_set_argb(obj2voxel_texture *t, std::vector<uint8_t> &&argb, size_t w, size_t h)
+{
+    t->pixels = std::move(argb);
+    t->width = w;
+    t->height = h;
+    t->channels = 4;
+    t->wrap = 1;
+    return true;
+}
+}  // namespace o2v

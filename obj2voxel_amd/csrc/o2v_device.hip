@@ -1,0 +1,1500 @@
+// o2v_device.hip -- the MI355X (gfx950) voxelization pipeline behind include/o2v_hip.h.
+//
+// Replaces, for one GPU's z-slab of the grid, the reference's chunk loop (src/obj2voxel.cpp:467-520) and
+// Voxelizer::voxelize (src/voxelization.cpp:480-526).  Written for CDNA4: 64-wide wavefronts, LDS-staged leaf
+// geometry, LDS-resident clip stacks, 32-bit atomics on a dense HBM grid of list heads.  No MFMA: the path is
+// float32 VALU + HBM/atomic traffic.
+//
+// Stages (all on one HIP stream, no host round trips between them):
+//   K0  k_bounds / k_setup     mesh bounds (obj2voxel.cpp:180-200) and mesh transform (obj2voxel.cpp:370-402)
+//   K1  k_expand_roots         transform (obj2voxel.cpp:202-224), alignment test (voxelization.cpp:335-347),
+//       k_expand_nodes         exact LIFO subdivision (voxelization.cpp:349-379) done breadth-first with an
+//                              order key that reproduces the reference's processing order,
+//       k_expand_big           tiles of <= 256 candidate voxels for large leaves
+//   K2  k_voxelize<UV>         AABB walk + plane cull (voxelization.cpp:426-472) + six-plane clip by triangle
+//                              splitting (voxelization.cpp:175-331,383-424); every hit is appended to the hit
+//                              pool and linked into its cell's list with one atomicExch on the dense grid
+//   K5a k_scan                 streams the dense grid once, compacts occupied cells, resets them to empty
+//   K3  k_resolve              per occupied cell: orders the hits like the reference's sequential loops
+//                              (sub-voxel, triangle index, leaf order), replays insertWeighted
+//                              (voxelization.cpp:56-63,466-468) and moveUvBufferIntoVoxels (:513-526) with
+//                              MAX / BLEND, then packs (x, y, z, argb) (obj2voxel.cpp:279-297)
+//
+// Compile with -ffp-contract=off (see o2v_math.h).
+#include "o2v_math.h"
+
+#include "../../include/o2v_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace o2v;
+
+namespace {
+
+// ---- device-side records ----------------------------------------------------------------------------------
+
+constexpr uint32_t kTileSize = 256;       // candidate voxels per work tile
+constexpr uint32_t kTilesPerBatch = 32;   // tiles a workgroup stages at once (<= 8192 candidates)
+constexpr uint32_t kBlock = 256;          // threads per workgroup (4 wavefronts)
+constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key holds 15 levels)
+constexpr uint32_t kHitChunk = 256;       // hit-pool slots a wavefront reserves per global atomic
+constexpr uint32_t kInlineTiles = 4;      // leaves with more tiles are expanded by k_expand_big
+
+struct __attribute__((aligned(16))) Leaf {  // 96 B
+    float v[9];        // sample-space vertices
+    float n[3];        // normalize(normal): plane of the distance cull
+    float t[6];        // uv per vertex
+    uint32_t tri;      // input triangle index
+    uint32_t pathkey;  // order key of this leaf among the leaves of `tri` (0 = unsplit triangle)
+    uint32_t bmin_xy;  // clamped AABB min: x | y << 16
+    uint32_t bmin_z_dx;  // z | dx << 16
+    uint32_t dy_dz;      // dy | dz << 16
+    float area;          // area of the whole input triangle (voxelization.cpp:416)
+};
+static_assert(sizeof(Leaf) == 96, "Leaf layout");
+
+struct __attribute__((aligned(16))) Node {  // 80 B: a sub-triangle that still has to be subdivided
+    float v[9];
+    float t[6];
+    uint32_t tri;
+    uint32_t pathkey;
+    uint32_t depth;
+    float area;
+    uint32_t pad;
+};
+static_assert(sizeof(Node) == 80, "Node layout");
+
+struct Tile {
+    uint32_t leaf;
+    uint32_t start;  // first candidate index inside the leaf's clamped AABB
+};
+
+struct BigLeaf {
+    uint32_t leaf, first_tile, ntiles, pad;
+};
+
+struct __attribute__((aligned(8))) HitRec {  // 24 B
+    uint32_t next;   // 1-based index of the next record of the same cell, 0 = end
+    uint32_t keyhi;  // sub-voxel << 29 | triangle index
+    uint32_t keylo;  // leaf order key
+    float w, u, v;   // WeightedUv of this (leaf, voxel) pair (voxelization.cpp:414-423)
+};
+
+struct Occ {
+    uint32_t cell_lo, cell_hi;  // linear cell index inside the slab
+    uint32_t head;
+};
+
+struct DevTexture {
+    const uint8_t *pixels;
+    uint32_t width, height, channels, wrap;
+};
+
+struct Counters {
+    uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
+    uint32_t n_vox, batch_cursor, err_flags, pad0;
+    uint32_t n_nodes[kMaxRounds + 1];
+    uint32_t pad1[3];
+    unsigned long long n_candidates, n_hits;
+    uint32_t bounds_enc[6];
+    uint32_t pad2[2];
+    float xform[12];
+};
+
+enum : uint32_t {
+    kErrLeafTooLarge = 1u,
+    kErrDepth = 2u,
+};
+
+struct Params {
+    uint64_t n_tris;
+    uint32_t S;            // sample resolution = resolution * supersampling
+    uint32_t G;            // output resolution
+    uint32_t Gx;           // row pitch of the dense grid (G rounded up to 4)
+    uint32_t ss_shift;     // 0, or 1 for 2x supersampling
+    uint32_t zs0, zs1;     // slab in sample space
+    uint32_t zo0;          // slab begin in output space
+    uint32_t blend;
+    uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
+    uint32_t bounds_known;
+    float bounds[6];
+    int32_t unit[9];
+    uint32_t has_uv;
+};
+
+// ---- small device helpers ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// exclusive scan of one uint32 per thread over a 256-thread block; returns the block total in `total`
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &total)
+{
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        uint32_t c = s_wave[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+// ---- K0: bounds + transform ---------------------------------------------------------------------------------
+
+__global__ void k_init(Counters *c)
+{
+    uint32_t i = threadIdx.x;
+    uint32_t *w = reinterpret_cast<uint32_t *>(c);
+    for (uint32_t k = i; k < sizeof(Counters) / 4; k += blockDim.x) w[k] = 0;
+    __syncthreads();
+    if (i < 3) c->bounds_enc[i] = f2ord(__builtin_inff());
+    else if (i < 6) c->bounds_enc[i] = f2ord(-__builtin_inff());
+}
+
+// findMeshBounds (obj2voxel.cpp:180-200): min/max are exact and order-free, so one reduce replaces the batches.
+__global__ __launch_bounds__(kBlock) void k_bounds(const float *__restrict__ verts, uint64_t n_floats, Counters *c)
+{
+    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    // a thread always reads whole vertices: index = 3 * vertex + axis
+    uint64_t n_vert = n_floats / 3;
+    for (uint64_t vtx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; vtx < n_vert;
+         vtx += (uint64_t) gridDim.x * blockDim.x) {
+        const float *p = verts + vtx * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float f = p[a];
+            mn[a] = fmin2(f, mn[a]);
+            mx[a] = fmax2(f, mx[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&c->bounds_enc[a], f2ord(mn[a]));
+            atomicMax(&c->bounds_enc[3 + a], f2ord(mx[a]));
+        }
+    }
+}
+
+__global__ void k_setup(Counters *c, Params p)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    V3 mn, mx;
+    if (p.bounds_known) {
+        mn = {p.bounds[0], p.bounds[1], p.bounds[2]};
+        mx = {p.bounds[3], p.bounds[4], p.bounds[5]};
+    }
+    else {
+        mn = {ord2f(c->bounds_enc[0]), ord2f(c->bounds_enc[1]), ord2f(c->bounds_enc[2])};
+        mx = {ord2f(c->bounds_enc[3]), ord2f(c->bounds_enc[4]), ord2f(c->bounds_enc[5])};
+    }
+    Affine a = compute_mesh_transform(mn, mx, p.S, p.unit);
+    for (int i = 0; i < 3; ++i) {
+        c->xform[i * 3 + 0] = a.m[i].x;
+        c->xform[i * 3 + 1] = a.m[i].y;
+        c->xform[i * 3 + 2] = a.m[i].z;
+    }
+    c->xform[9] = a.t.x;
+    c->xform[10] = a.t.y;
+    c->xform[11] = a.t.z;
+}
+
+// ---- K1: leaves --------------------------------------------------------------------------------------------
+
+struct Sub {  // a (sub-)triangle in registers
+    V3 v0, v1, v2;
+    V2 t0, t1, t2;
+};
+
+struct LeafPlan {
+    uint32_t lo[3], d[3];
+    uint32_t ntiles;  // 0 = nothing to do (outside the slab)
+    uint64_t count;
+};
+
+// Clamp the voxel AABB of a leaf to the grid and the slab: voxelization.cpp:440-444 with min/max = slab bounds.
+__device__ __forceinline__ LeafPlan plan_leaf(const Sub &s, const Params &p)
+{
+    LeafPlan pl;
+    V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
+    uint32_t lo[3] = {floor_u32(mn.x), floor_u32(mn.y), floor_u32(mn.z)};
+    uint32_t hi[3] = {floor_u32(mx.x) + 1u, floor_u32(mx.y) + 1u, floor_u32(mx.z) + 1u};
+    uint32_t glo[3] = {0u, 0u, p.zs0}, ghi[3] = {p.S, p.S, p.zs1};
+    bool empty = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = lo[a] > glo[a] ? lo[a] : glo[a];
+        hi[a] = hi[a] < ghi[a] ? hi[a] : ghi[a];
+        empty |= lo[a] >= hi[a];
+        pl.lo[a] = lo[a];
+        pl.d[a] = empty ? 0u : hi[a] - lo[a];
+    }
+    pl.count = empty ? 0ull : (uint64_t) pl.d[0] * pl.d[1] * pl.d[2];
+    pl.ntiles = (uint32_t) ((pl.count + kTileSize - 1) / kTileSize);
+    return pl;
+}
+
+// u32 voxel AABB volume, wrapping like the reference's Vec3u32 product (voxelization.cpp:357-361)
+__device__ __forceinline__ uint32_t voxel_volume(const Sub &s)
+{
+    V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
+    uint32_t dx = (floor_u32(mx.x) + 1u) - floor_u32(mn.x);
+    uint32_t dy = (floor_u32(mx.y) + 1u) - floor_u32(mn.y);
+    uint32_t dz = (floor_u32(mx.z) + 1u) - floor_u32(mn.z);
+    return dx * dy * dz;
+}
+
+// true if the sub-triangle's voxel AABB misses the slab entirely (then none of its descendants can touch it:
+// midpoints stay inside the parent's AABB because rounding is monotonic)
+__device__ __forceinline__ bool misses_slab(const Sub &s, const Params &p)
+{
+    V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
+    uint32_t zlo = floor_u32(mn.z), zhi = floor_u32(mx.z) + 1u;
+    uint32_t xlo = floor_u32(mn.x), ylo = floor_u32(mn.y);
+    return zhi <= p.zs0 || zlo >= p.zs1 || xlo >= p.S || ylo >= p.S;
+}
+
+__device__ __forceinline__ void write_leaf(Leaf *leaves, uint32_t idx, const Sub &s, uint32_t tri, uint32_t pathkey,
+                                           float area, const LeafPlan &pl)
+{
+    V3 n = normalize(tri_normal(s.v0, s.v1, s.v2));  // voxelization.cpp:438
+    Leaf l;
+    l.v[0] = s.v0.x; l.v[1] = s.v0.y; l.v[2] = s.v0.z;
+    l.v[3] = s.v1.x; l.v[4] = s.v1.y; l.v[5] = s.v1.z;
+    l.v[6] = s.v2.x; l.v[7] = s.v2.y; l.v[8] = s.v2.z;
+    l.n[0] = n.x; l.n[1] = n.y; l.n[2] = n.z;
+    l.t[0] = s.t0.x; l.t[1] = s.t0.y; l.t[2] = s.t1.x; l.t[3] = s.t1.y; l.t[4] = s.t2.x; l.t[5] = s.t2.y;
+    l.tri = tri;
+    l.pathkey = pathkey;
+    l.bmin_xy = pl.lo[0] | (pl.lo[1] << 16);
+    l.bmin_z_dx = pl.lo[2] | (pl.d[0] << 16);
+    l.dy_dz = pl.d[1] | (pl.d[2] << 16);
+    l.area = area;
+    leaves[idx] = l;
+}
+
+__device__ __forceinline__ void write_tiles(Tile *tiles, BigLeaf *big, uint32_t leaf_idx, uint32_t first_tile,
+                                            uint32_t ntiles, uint32_t big_slot, const Params &p)
+{
+    if (ntiles <= kInlineTiles) {
+        for (uint32_t k = 0; k < ntiles; ++k)
+            if (first_tile + k < p.cap_tiles) tiles[first_tile + k] = Tile{leaf_idx, k * kTileSize};
+    }
+    else if (big_slot < p.cap_big) {
+        big[big_slot] = BigLeaf{leaf_idx, first_tile, ntiles, 0};
+    }
+}
+
+struct Emit {  // what one lane wants to append this round
+    uint32_t n_leaf, n_tile, n_big, n_node;
+};
+
+struct BlockSlots {
+    uint32_t leaf, tile, big, node;
+};
+
+// One reservation per counter per workgroup (a per-lane atomic on one address would serialise at ~88/us).
+__device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, uint32_t node_round, uint32_t *s_wave,
+                                                    uint32_t *s_base)
+{
+    uint32_t tot_leaf, tot_tile, tot_big, tot_node;
+    BlockSlots off;
+    off.leaf = block_exscan(e.n_leaf, s_wave, tot_leaf);
+    off.tile = block_exscan(e.n_tile, s_wave, tot_tile);
+    off.big = block_exscan(e.n_big, s_wave, tot_big);
+    off.node = block_exscan(e.n_node, s_wave, tot_node);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base[0] = tot_leaf ? atomicAdd(&c->n_leaves, tot_leaf) : 0u;
+        s_base[1] = tot_tile ? atomicAdd(&c->n_tiles, tot_tile) : 0u;
+        s_base[2] = tot_big ? atomicAdd(&c->n_big, tot_big) : 0u;
+        s_base[3] = tot_node ? atomicAdd(&c->n_nodes[node_round], tot_node) : 0u;
+    }
+    __syncthreads();
+    off.leaf += s_base[0];
+    off.tile += s_base[1];
+    off.big += s_base[2];
+    off.node += s_base[3];
+    return off;
+}
+
+// Roots: one lane per input triangle.  applyMeshTransform (obj2voxel.cpp:202-224) then the head of
+// voxelizeTriangleToUvBuffer (voxelization.cpp:488-511).
+__global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict__ verts, const float *__restrict__ uvs,
+                                                         Counters *c, Leaf *leaves, Tile *tiles, BigLeaf *big,
+                                                         Node *nodes_out, Params p)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base[4];
+    __shared__ float s_v[kBlock * 9];
+    __shared__ float s_t[kBlock * 6];
+    __shared__ unsigned long long s_cand;
+
+    Affine xf;
+    xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
+    xf.m[1] = {c->xform[3], c->xform[4], c->xform[5]};
+    xf.m[2] = {c->xform[6], c->xform[7], c->xform[8]};
+    xf.t = {c->xform[9], c->xform[10], c->xform[11]};
+
+    const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
+    for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t base = blk * kBlock;
+        const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
+        __syncthreads();
+        if (threadIdx.x == 0) s_cand = 0;
+        // coalesced staging of this block's vertices / uvs through LDS
+        for (uint32_t i = threadIdx.x; i < n_here * 9; i += kBlock) s_v[i] = verts[base * 9 + i];
+        if (p.has_uv)
+            for (uint32_t i = threadIdx.x; i < n_here * 6; i += kBlock) s_t[i] = uvs[base * 6 + i];
+        __syncthreads();
+
+        const bool live = threadIdx.x < n_here;
+        Sub s{};
+        Emit e{0, 0, 0, 0};
+        LeafPlan pl{};
+        float area = 0;
+        bool as_leaf = false, as_node = false;
+        if (live) {
+            const float *q = &s_v[threadIdx.x * 9];
+            s.v0 = affine_apply(xf, V3{q[0], q[1], q[2]});
+            s.v1 = affine_apply(xf, V3{q[3], q[4], q[5]});
+            s.v2 = affine_apply(xf, V3{q[6], q[7], q[8]});
+            if (p.has_uv) {
+                const float *r = &s_t[threadIdx.x * 6];
+                s.t0 = {r[0], r[1]};
+                s.t1 = {r[2], r[3]};
+                s.t2 = {r[4], r[5]};
+            }
+            if (!misses_slab(s, p)) {
+                area = tri_area(s.v0, s.v1, s.v2);
+                if (roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit) {
+                    pl = plan_leaf(s, p);
+                    if (pl.count >> 32) {
+                        atomicOr(&c->err_flags, kErrLeafTooLarge);
+                    }
+                    else if (pl.ntiles) {
+                        as_leaf = true;
+                        e.n_leaf = 1;
+                        e.n_tile = pl.ntiles;
+                        e.n_big = pl.ntiles > kInlineTiles ? 1u : 0u;
+                    }
+                }
+                else {
+                    as_node = true;
+                    e.n_node = 1;
+                }
+            }
+        }
+        BlockSlots slot = reserve_slots(e, c, 0, s_wave, s_base);
+        if (as_leaf) {
+            if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, (uint32_t) (base + threadIdx.x), 0u, area, pl);
+            write_tiles(tiles, big, slot.leaf, slot.tile, pl.ntiles, slot.big, p);
+            atomicAdd(&s_cand, pl.count);
+        }
+        if (as_node && slot.node < p.cap_nodes) {
+            Node n;
+            n.v[0] = s.v0.x; n.v[1] = s.v0.y; n.v[2] = s.v0.z;
+            n.v[3] = s.v1.x; n.v[4] = s.v1.y; n.v[5] = s.v1.z;
+            n.v[6] = s.v2.x; n.v[7] = s.v2.y; n.v[8] = s.v2.z;
+            n.t[0] = s.t0.x; n.t[1] = s.t0.y; n.t[2] = s.t1.x; n.t[3] = s.t1.y; n.t[4] = s.t2.x; n.t[5] = s.t2.y;
+            n.tri = (uint32_t) (base + threadIdx.x);
+            n.pathkey = 0;
+            n.depth = 0;
+            n.area = area;
+            n.pad = 0;
+            nodes_out[slot.node] = n;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
+    }
+}
+
+// One breadth-first round of forEachSubdividedTriangle (voxelization.cpp:349-379).  The reference pops a LIFO
+// stack: after subdivide4 the centre piece (index 0) replaces the parent and pieces 1,2,3 are pushed, so the
+// processing order of the children is 3, 2, 1, 0 (depth first).  A leaf's position in that order is encoded
+// in `pathkey`: two bits (3 - childIndex) per level, most significant first, then a terminating 1 bit, so that
+// unsigned comparison of keys of one triangle equals the reference's processing order.
+__global__ __launch_bounds__(kBlock) void k_expand_nodes(const Node *__restrict__ nodes_in, uint32_t round, Counters *c,
+                                                         Leaf *leaves, Tile *tiles, BigLeaf *big, Node *nodes_out,
+                                                         Params p)
+{
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base[4];
+    __shared__ unsigned long long s_cand;
+    const uint32_t n_in = c->n_nodes[round] < p.cap_nodes ? c->n_nodes[round] : p.cap_nodes;
+    const uint32_t n_blocks = (n_in + kBlock - 1) / kBlock;
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint32_t i = blk * kBlock + threadIdx.x;
+        const bool live = i < n_in;
+        __syncthreads();
+        if (threadIdx.x == 0) s_cand = 0;
+        Sub ch[4];
+        LeafPlan pl[4];
+        uint32_t kind[4] = {0, 0, 0, 0};  // 0 drop, 1 leaf, 2 node
+        uint32_t tri = 0, pathkey = 0, depth = 0;
+        float area = 0;
+        Emit e{0, 0, 0, 0};
+        if (live) {
+            const Node n = nodes_in[i];
+            tri = n.tri;
+            pathkey = n.pathkey;
+            depth = n.depth;
+            area = n.area;
+            V3 v0{n.v[0], n.v[1], n.v[2]}, v1{n.v[3], n.v[4], n.v[5]}, v2{n.v[6], n.v[7], n.v[8]};
+            V2 t0{n.t[0], n.t[1]}, t1{n.t[2], n.t[3]}, t2{n.t[4], n.t[5]};
+            // subdivide4, triangle.hpp:134-143
+            V3 g0 = mix(v0, v1, 0.5f), g1 = mix(v1, v2, 0.5f), g2 = mix(v2, v0, 0.5f);
+            V2 x0 = mix(t0, t1, 0.5f), x1 = mix(t1, t2, 0.5f), x2 = mix(t2, t0, 0.5f);
+            ch[0] = Sub{g0, g1, g2, x0, x1, x2};
+            ch[1] = Sub{v0, g0, g2, t0, x0, x2};
+            ch[2] = Sub{v1, g1, g0, t1, x1, x0};
+            ch[3] = Sub{v2, g2, g1, t2, x2, x1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (misses_slab(ch[k], p)) continue;
+                if (voxel_volume(ch[k]) < kSubdivisionVolumeLimit) {
+                    pl[k] = plan_leaf(ch[k], p);
+                    if (pl[k].count >> 32) {
+                        atomicOr(&c->err_flags, kErrLeafTooLarge);
+                    }
+                    else if (pl[k].ntiles) {
+                        kind[k] = 1;
+                        e.n_leaf += 1;
+                        e.n_tile += pl[k].ntiles;
+                        e.n_big += pl[k].ntiles > kInlineTiles ? 1u : 0u;
+                    }
+                }
+                else if (depth + 1 >= 15) {
+                    atomicOr(&c->err_flags, kErrDepth);
+                }
+                else {
+                    kind[k] = 2;
+                    e.n_node += 1;
+                }
+            }
+        }
+        BlockSlots slot = reserve_slots(e, c, round + 1, s_wave, s_base);
+        if (live) {
+            unsigned long long cand = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // child digit at this level, then the terminator bit one position below it
+                const uint32_t shift = 30u - 2u * depth;
+                const uint32_t digit_key = pathkey | ((3u - (uint32_t) k) << shift);
+                if (kind[k] == 1) {
+                    const uint32_t key = digit_key | (1u << (shift - 1u));
+                    if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, ch[k], tri, key, area, pl[k]);
+                    write_tiles(tiles, big, slot.leaf, slot.tile, pl[k].ntiles, slot.big, p);
+                    cand += pl[k].count;
+                    slot.leaf += 1;
+                    slot.tile += pl[k].ntiles;
+                    slot.big += pl[k].ntiles > kInlineTiles ? 1u : 0u;
+                }
+                else if (kind[k] == 2) {
+                    if (slot.node < p.cap_nodes) {
+                        Node o;
+                        const Sub &s = ch[k];
+                        o.v[0] = s.v0.x; o.v[1] = s.v0.y; o.v[2] = s.v0.z;
+                        o.v[3] = s.v1.x; o.v[4] = s.v1.y; o.v[5] = s.v1.z;
+                        o.v[6] = s.v2.x; o.v[7] = s.v2.y; o.v[8] = s.v2.z;
+                        o.t[0] = s.t0.x; o.t[1] = s.t0.y; o.t[2] = s.t1.x; o.t[3] = s.t1.y; o.t[4] = s.t2.x; o.t[5] = s.t2.y;
+                        o.tri = tri;
+                        o.pathkey = digit_key;
+                        o.depth = depth + 1;
+                        o.area = area;
+                        o.pad = 0;
+                        nodes_out[slot.node] = o;
+                    }
+                    slot.node += 1;
+                }
+            }
+            if (cand) atomicAdd(&s_cand, cand);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
+    }
+}
+
+
+__global__ __launch_bounds__(kBlock) void k_expand_big(const BigLeaf *__restrict__ big, const Counters *c, Tile *tiles,
+                                                       Params p)
+{
+    const uint32_t n = c->n_big < p.cap_big ? c->n_big : p.cap_big;
+    for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+        const BigLeaf bl = big[b];
+        for (uint32_t k = threadIdx.x; k < bl.ntiles; k += kBlock)
+            if (bl.first_tile + k < p.cap_tiles) tiles[bl.first_tile + k] = Tile{bl.leaf, k * kTileSize};
+    }
+}
+
+// ---- K2: voxelize -------------------------------------------------------------------------------------------
+
+template <bool UV>
+struct Piece {  // TexturedTriangle (triangle.hpp:113-144); the uv members are dead code when !UV
+    V3 a, b, c;
+    V2 ta, tb, tc;
+};
+
+__device__ __forceinline__ V3 sel3(uint32_t r, V3 x0, V3 x1, V3 x2) { return r == 0 ? x0 : (r == 1 ? x1 : x2); }
+__device__ __forceinline__ V2 sel2(uint32_t r, V2 x0, V2 x1, V2 x2) { return r == 0 ? x0 : (r == 1 ? x1 : x2); }
+
+// splitTriangle<DISCARD_LO|DISCARD_HI> (voxelization.cpp:175-331) for one piece.  keep_lo selects DISCARD_HI.
+// Returns the number of kept pieces (0, 1 or 2): `cur` becomes the first kept piece in emission order, `sec` the
+// second.  Vertex order inside emitted pieces is the reference's, because later splits depend on it.
+template <bool UV>
+__device__ __forceinline__ uint32_t split_keep(Piece<UV> &cur, Piece<UV> &sec, uint32_t axis, float plane, bool keep_lo)
+{
+    const float c0 = comp(cur.a, axis), c1 = comp(cur.b, axis), c2 = comp(cur.c, axis);
+    // SplittingValues, voxelization.cpp:121-131
+    const bool p0 = abs_f(c0 - plane) < kEpsilon, p1 = abs_f(c1 - plane) < kEpsilon, p2 = abs_f(c2 - plane) < kEpsilon;
+    const bool l0 = c0 < plane, l1 = c1 < plane, l2 = c2 < plane;
+    const uint32_t lo_sum = (uint32_t) l0 + (uint32_t) l1 + (uint32_t) l2;
+    const uint32_t pl_sum = (uint32_t) p0 + (uint32_t) p1 + (uint32_t) p2;
+
+    uint32_t mode = 0;  // 0: triangle passes whole to one side, 1: one-planar split, 2: regular split
+    bool side_lo = false;
+    uint32_t r = 0;
+    bool iso_lo = false;
+    if (lo_sum == 0) side_lo = false;
+    else if (lo_sum == 3) side_lo = true;
+    else if (pl_sum == 3) side_lo = false;  // parallel to the plane: pushed by bias (IS_LO_BIASED = false)
+    else if (pl_sum == 2) side_lo = !p0 ? l0 : (!p1 ? l1 : l2);
+    else if (pl_sum == 1) {
+        r = p0 ? 0u : (p1 ? 1u : 2u);
+        const bool lq = r == 0 ? l1 : (r == 1 ? l2 : l0);
+        const bool lr = r == 0 ? l2 : (r == 1 ? l0 : l1);
+        if (lq == lr) side_lo = lq;
+        else mode = 1;
+    }
+    else {
+        iso_lo = lo_sum == 1;
+        r = iso_lo ? (l0 ? 0u : (l1 ? 1u : 2u)) : (!l0 ? 0u : (!l1 ? 1u : 2u));
+        mode = 2;
+    }
+    if (mode == 0) return side_lo == keep_lo ? 1u : 0u;
+
+    const V3 P = sel3(r, cur.a, cur.b, cur.c), Q = sel3(r, cur.b, cur.c, cur.a), R = sel3(r, cur.c, cur.a, cur.b);
+    V2 tP{}, tQ{}, tR{};
+    if (UV) {
+        tP = sel2(r, cur.ta, cur.tb, cur.tc);
+        tQ = sel2(r, cur.tb, cur.tc, cur.ta);
+        tR = sel2(r, cur.tc, cur.ta, cur.tb);
+    }
+    const float cP = r == 0 ? c0 : (r == 1 ? c1 : c2);
+    const float cQ = r == 0 ? c1 : (r == 1 ? c2 : c0);
+    const float cR = r == 0 ? c2 : (r == 1 ? c0 : c1);
+
+    if (mode == 1) {
+        // splitTriangle_onePlanarCase, voxelization.cpp:255-276: P planar, split edge Q->R
+        const bool lq = r == 0 ? l1 : (r == 1 ? l2 : l0);
+        const float d = -(cR - cQ);
+        const float t = abs_f(d) < kEpsilon ? 0.f : (cQ - plane) / d;
+        const V3 G = mix(Q, R, t);
+        V2 tG{};
+        if (UV) tG = mix(tQ, tR, t);
+        if (lq == keep_lo) {
+            cur.a = P; cur.b = Q; cur.c = G;
+            if (UV) { cur.ta = tP; cur.tb = tQ; cur.tc = tG; }
+        }
+        else {
+            cur.a = P; cur.b = G; cur.c = R;
+            if (UV) { cur.ta = tP; cur.tb = tG; cur.tc = tR; }
+        }
+        return 1;
+    }
+    // splitTriangle_regularCase, voxelization.cpp:279-331: P isolated
+    const float d0 = -(cQ - cP), d1 = -(cR - cP);
+    const float i0 = abs_f(d0) < kEpsilon ? 0.f : (cP - plane) / d0;
+    const float i1 = abs_f(d1) < kEpsilon ? 0.f : (cP - plane) / d1;
+    const V3 G0 = mix(P, Q, i0), G1 = mix(P, R, i1);
+    V2 x0{}, x1{};
+    if (UV) {
+        x0 = mix(tP, tQ, i0);
+        x1 = mix(tP, tR, i1);
+    }
+    if (iso_lo == keep_lo) {
+        cur.a = P; cur.b = G0; cur.c = G1;
+        if (UV) { cur.ta = tP; cur.tb = x0; cur.tc = x1; }
+        return 1;
+    }
+    cur.a = G0; cur.b = Q; cur.c = R;
+    sec.a = G0; sec.b = G1; sec.c = R;
+    if (UV) {
+        cur.ta = x0; cur.tb = tQ; cur.tc = tR;
+        sec.ta = x0; sec.tb = x1; sec.tc = tR;
+    }
+    return 2;
+}
+
+template <bool UV>
+__device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area, float &w, float &u, float &v)
+{
+    // result = mix(result, {area(inputTriangle), piece.textureCenter()}), voxelization.cpp:414-420, util.hpp:160-165
+    const float ws = w + area;
+    if (UV) {
+        const float uc = ((pc.ta.x + pc.tb.x) + pc.tc.x) / 3;
+        const float vc = ((pc.ta.y + pc.tb.y) + pc.tc.y) / 3;
+        u = (w * u + area * uc) / ws;
+        v = (w * v + area * vc) / ws;
+    }
+    w = ws;
+}
+
+template <bool UV>
+__device__ __forceinline__ void stack_store(float *s_stk, uint32_t slot, const Piece<UV> &pc)
+{
+    constexpr uint32_t NC = UV ? 15 : 9;
+    float *b = s_stk + (size_t) slot * NC * kBlock + threadIdx.x;
+    b[0 * kBlock] = pc.a.x; b[1 * kBlock] = pc.a.y; b[2 * kBlock] = pc.a.z;
+    b[3 * kBlock] = pc.b.x; b[4 * kBlock] = pc.b.y; b[5 * kBlock] = pc.b.z;
+    b[6 * kBlock] = pc.c.x; b[7 * kBlock] = pc.c.y; b[8 * kBlock] = pc.c.z;
+    if (UV) {
+        b[9 * kBlock] = pc.ta.x; b[10 * kBlock] = pc.ta.y; b[11 * kBlock] = pc.tb.x;
+        b[12 * kBlock] = pc.tb.y; b[13 * kBlock] = pc.tc.x; b[14 * kBlock] = pc.tc.y;
+    }
+}
+template <bool UV>
+__device__ __forceinline__ void stack_load(const float *s_stk, uint32_t slot, Piece<UV> &pc)
+{
+    constexpr uint32_t NC = UV ? 15 : 9;
+    const float *b = s_stk + (size_t) slot * NC * kBlock + threadIdx.x;
+    pc.a = {b[0 * kBlock], b[1 * kBlock], b[2 * kBlock]};
+    pc.b = {b[3 * kBlock], b[4 * kBlock], b[5 * kBlock]};
+    pc.c = {b[6 * kBlock], b[7 * kBlock], b[8 * kBlock]};
+    if (UV) {
+        pc.ta = {b[9 * kBlock], b[10 * kBlock]};
+        pc.tb = {b[11 * kBlock], b[12 * kBlock]};
+        pc.tc = {b[13 * kBlock], b[14 * kBlock]};
+    }
+}
+
+// computeTrianglesUvInVoxel (voxelization.cpp:383-424) for one (leaf, voxel) pair.  The reference clips level
+// by level with two 64-entry buffers; here the same split tree is walked depth first (first emitted piece
+// first), which visits the surviving pieces in the reference's buffer order, so the running mean of
+// voxelization.cpp:414-420 accumulates in the identical sequence.  Under DISCARD every split keeps at most
+// two pieces, so at most one sibling per level 1..5 is pending: five LDS slots per lane.
+template <bool UV>
+__device__ __forceinline__ void clip_voxel(const Leaf &lf, uint32_t px, uint32_t py, uint32_t pz, float *s_stk,
+                                           float &w, float &u, float &v)
+{
+    Piece<UV> cur, sec;
+    cur.a = {lf.v[0], lf.v[1], lf.v[2]};
+    cur.b = {lf.v[3], lf.v[4], lf.v[5]};
+    cur.c = {lf.v[6], lf.v[7], lf.v[8]};
+    if (UV) {
+        cur.ta = {lf.t[0], lf.t[1]};
+        cur.tb = {lf.t[2], lf.t[3]};
+        cur.tc = {lf.t[4], lf.t[5]};
+    }
+    const float area = lf.area;
+    uint32_t level = 0, pending = 0;
+    bool active = true;
+    w = 0.f;
+    u = 0.f;
+    v = 0.f;
+    for (;;) {
+        if (!active) {
+            if (!pending) break;
+            level = 31u - (uint32_t) __clz((int) pending);
+            pending ^= 1u << level;
+            stack_load<UV>(s_stk, level - 1u, cur);
+        }
+        const bool keep_lo = level >= 3u;
+        const uint32_t axis = keep_lo ? level - 3u : level;
+        const uint32_t pa = axis == 0 ? px : (axis == 1 ? py : pz);
+        const float plane = (float) (pa + (keep_lo ? 1u : 0u));
+        const uint32_t n = split_keep<UV>(cur, sec, axis, plane, keep_lo);
+        active = n != 0;
+        if (n) {
+            if (level == 5u) {
+                accumulate_piece<UV>(cur, area, w, u, v);
+                if (n == 2) accumulate_piece<UV>(sec, area, w, u, v);
+                active = false;
+            }
+            else {
+                if (n == 2) {
+                    stack_store<UV>(s_stk, level, sec);  // slot of level+1
+                    pending |= 1u << (level + 1u);
+                }
+                level += 1u;
+            }
+        }
+    }
+}
+
+template <bool UV>
+__global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+                                                     Counters *c, uint32_t *grid, HitRec *pool, Params p)
+{
+    extern __shared__ __align__(16) float s_stk[];  // [5][UV ? 15 : 9][kBlock]
+    __shared__ Leaf s_leaf[kTilesPerBatch];
+    __shared__ uint32_t s_tleaf[kTilesPerBatch];
+    __shared__ uint32_t s_tstart[kTilesPerBatch];
+    __shared__ uint32_t s_prefix[kTilesPerBatch + 1];
+    __shared__ uint8_t s_owner[kTilesPerBatch * kTileSize];
+    __shared__ uint32_t s_batch;
+    __shared__ uint32_t s_hits;
+
+    const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
+    const uint32_t n_batches = (n_tiles + kTilesPerBatch - 1) / kTilesPerBatch;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
+    if (threadIdx.x == 0) s_hits = 0;
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_batch = atomicAdd(&c->batch_cursor, 1u);
+        __syncthreads();
+        const uint32_t batch = s_batch;
+        if (batch >= n_batches) break;
+        const uint32_t first = batch * kTilesPerBatch;
+        const uint32_t nt = n_tiles - first < kTilesPerBatch ? n_tiles - first : kTilesPerBatch;
+        if (threadIdx.x < nt) {
+            const Tile t = tiles[first + threadIdx.x];
+            s_tleaf[threadIdx.x] = t.leaf;
+            s_tstart[threadIdx.x] = t.start;
+        }
+        __syncthreads();
+        // stage the leaves of this batch in LDS (24 dwords each)
+        for (uint32_t i = threadIdx.x; i < nt * 24u; i += kBlock) {
+            const uint32_t k = i / 24u, j = i - k * 24u;
+            reinterpret_cast<uint32_t *>(s_leaf)[i] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k < nt; ++k) {
+                const Leaf &lf = s_leaf[k];
+                const uint32_t cnt = (lf.bmin_z_dx >> 16) * (lf.dy_dz & 0xffffu) * (lf.dy_dz >> 16);
+                const uint32_t rem = cnt - s_tstart[k];
+                s_prefix[k] = acc;
+                acc += rem < kTileSize ? rem : kTileSize;
+            }
+            s_prefix[nt] = acc;
+        }
+        __syncthreads();
+        const uint32_t total = s_prefix[nt];
+        for (uint32_t k = 0; k < nt; ++k) {
+            const uint32_t b = s_prefix[k], n = s_prefix[k + 1] - b;
+            if (threadIdx.x < n) s_owner[b + threadIdx.x] = (uint8_t) k;
+        }
+        __syncthreads();
+
+        for (uint32_t cbase = 0; cbase < total; cbase += kBlock) {
+            const uint32_t cidx = cbase + threadIdx.x;
+            float w = 0.f, u = 0.f, v = 0.f;
+            uint64_t cell = 0;
+            uint32_t keyhi = 0, keylo = 0;
+            if (cidx < total) {
+                const uint32_t k = s_owner[cidx];
+                const Leaf &lf = s_leaf[k];
+                const uint32_t j = s_tstart[k] + (cidx - s_prefix[k]);
+                const uint32_t dx = lf.bmin_z_dx >> 16, dy = lf.dy_dz & 0xffffu;
+                const uint32_t row = j / dx;
+                const uint32_t lx = j - row * dx;
+                const uint32_t lz = row / dy;
+                const uint32_t ly = row - lz * dy;
+                const uint32_t x = (lf.bmin_xy & 0xffffu) + lx, y = (lf.bmin_xy >> 16) + ly,
+                               z = (lf.bmin_z_dx & 0xffffu) + lz;
+                // plane distance cull, voxelization.cpp:451-458
+                const V3 center = {(float) x + 0.5f, (float) y + 0.5f, (float) z + 0.5f};
+                const float sd = dot(V3{lf.n[0], lf.n[1], lf.n[2]}, center - V3{lf.v[0], lf.v[1], lf.v[2]});
+                if (!(abs_f(sd) > kPlaneDistanceLimit)) {
+                    clip_voxel<UV>(lf, x, y, z, s_stk, w, u, v);
+                    const uint32_t ox = x >> p.ss_shift, oy = y >> p.ss_shift, oz = z >> p.ss_shift;
+                    cell = ((uint64_t) (oz - p.zo0) * p.G + oy) * p.Gx + ox;
+                    const uint32_t sub = p.ss_shift ? ((x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2)) : 0u;
+                    keyhi = (sub << 29) | lf.tri;
+                    keylo = lf.pathkey;
+                }
+            }
+            // `not eqExactly(uv.weight, 0.f)` -> insertWeighted (voxelization.cpp:466-468): here the hit is
+            // appended to the cell's list; the ordered combine happens in k_resolve.
+            const bool hit = w != 0.f;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const uint32_t cnt = (uint32_t) __popcll(mask);
+                if (chunk_used + cnt > kHitChunk) {
+                    uint32_t base = 0;
+                    if (lane == (uint32_t) (__ffsll((long long) mask) - 1)) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
+                    chunk_base = __shfl(base, __ffsll((long long) mask) - 1, 64);
+                    chunk_used = 0;
+                }
+                const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+                chunk_used += cnt;
+                if (hit && mine < p.cap_hits) {
+                    const uint32_t prev = atomicExch(&grid[cell], mine + 1u);
+                    pool[mine] = HitRec{prev, keyhi, keylo, w, u, v};
+                }
+                if (lane == 0) atomicAdd(&s_hits, cnt);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hits) atomicAdd(&c->n_hits, (unsigned long long) s_hits);
+}
+
+// ---- K5a: scan + compact + reset ---------------------------------------------------------------------------
+
+constexpr uint32_t kScanUnroll = 4;                              // uint4 loads in flight per thread
+constexpr uint32_t kScanCellsPerIter = kBlock * 4 * kScanUnroll;  // 4096 cells = 16 KiB per block iteration
+constexpr uint32_t kScanFlushAt = 2048;
+constexpr uint32_t kScanCap = kScanFlushAt + kScanCellsPerIter;
+
+__global__ __launch_bounds__(kBlock) void k_scan(uint32_t *grid, uint64_t n_quads, Counters *c, Occ *occ, Params p)
+{
+    __shared__ uint32_t s_lo[kScanCap], s_hi[kScanCap], s_head[kScanCap];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t quads_per_iter = (uint64_t) kBlock * kScanUnroll;
+    const uint64_t n_iters = (n_quads + quads_per_iter - 1) / quads_per_iter;
+    uint4 *g4 = reinterpret_cast<uint4 *>(grid);
+    for (uint64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const uint64_t q0 = it * quads_per_iter + threadIdx.x;
+        uint4 h[kScanUnroll];
+#pragma unroll
+        for (uint32_t k = 0; k < kScanUnroll; ++k) {
+            const uint64_t q = q0 + (uint64_t) k * kBlock;
+            h[k] = q < n_quads ? g4[q] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kScanUnroll; ++k) {
+            if (h[k].x | h[k].y | h[k].z | h[k].w) {
+                const uint64_t q = q0 + (uint64_t) k * kBlock;
+                const uint32_t hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
+#pragma unroll
+                for (uint32_t e = 0; e < 4; ++e) {
+                    if (hv[e]) {
+                        const uint64_t cell = q * 4 + e;
+                        const uint32_t slot = atomicAdd(&s_n, 1u);
+                        s_lo[slot] = (uint32_t) cell;
+                        s_hi[slot] = (uint32_t) (cell >> 32);
+                        s_head[slot] = hv[e];
+                    }
+                }
+                g4[q] = make_uint4(0, 0, 0, 0);  // leave the grid clean for the next voxelization
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n >= kScanFlushAt) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&c->n_vox, n);
+            __syncthreads();
+            const uint32_t base = s_base;
+            for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+                if (base + i < p.cap_vox) occ[base + i] = Occ{s_lo[i], s_hi[i], s_head[i]};
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+        }
+        __syncthreads();
+    }
+    const uint32_t n = s_n;
+    if (n) {
+        if (threadIdx.x == 0) s_base = atomicAdd(&c->n_vox, n);
+        __syncthreads();
+        const uint32_t base = s_base;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+            if (base + i < p.cap_vox) occ[base + i] = Occ{s_lo[i], s_hi[i], s_head[i]};
+    }
+}
+
+// ---- K3: resolve ---------------------------------------------------------------------------------------------
+
+struct Materials {
+    const uint32_t *types;   // nullable: all MATERIALLESS
+    const float *colors;     // nullable
+    const int32_t *texids;   // nullable: all 0
+    const DevTexture *textures;
+    uint32_t n_textures;
+};
+
+// colorAt_f, triangle.hpp:181-194 (+ texture get, triangle.hpp:161-166; getPixel semantics: see DESIGN.md)
+__device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float u, float v, float &r, float &g, float &b)
+{
+    const uint32_t type = m.types ? m.types[tri] : (uint32_t) kTriMaterialless;
+    if (type == kTriMaterialless) {
+        r = g = b = 1.f;
+    }
+    else if (type == kTriUntextured) {
+        r = m.colors ? m.colors[(size_t) tri * 3 + 0] : 0.f;
+        g = m.colors ? m.colors[(size_t) tri * 3 + 1] : 0.f;
+        b = m.colors ? m.colors[(size_t) tri * 3 + 2] : 0.f;
+    }
+    else if (type == kTriTextured && m.n_textures) {
+        uint32_t id = m.texids ? (uint32_t) m.texids[tri] : 0u;
+        if (id >= m.n_textures) id = 0;
+        const DevTexture tx = m.textures[id];
+        float tu = u, tv = 1 - v;
+        if (tx.wrap) {
+            tu = tu - floor_f(tu);
+            tv = tv - floor_f(tv);
+        }
+        else {
+            tu = tu < 0.f ? 0.f : (tu > 1.f ? 1.f : tu);
+            tv = tv < 0.f ? 0.f : (tv > 1.f ? 1.f : tv);
+        }
+        uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
+        if (px >= tx.width) px = tx.width - 1;
+        if (py >= tx.height) py = tx.height - 1;
+        const uint8_t *q = tx.pixels + ((size_t) py * tx.width + px) * tx.channels;
+        const uint32_t o = tx.channels == 4 ? 1u : 0u;
+        r = (float) q[o] / 255.f;
+        g = (float) q[o + 1] / 255.f;
+        b = (float) q[o + 2] / 255.f;
+    }
+    else {
+        r = 1.f;
+        g = 0.f;
+        b = 1.f;
+    }
+}
+
+// One lane per occupied cell.  The hits of a cell arrive in arbitrary order; the reference's result is a
+// sequential fold, so the list is replayed in the reference's order by repeated minimum selection on the key
+// (sub-voxel, triangle index, leaf order):
+//   leaves of one triangle   -> insertWeighted<BLEND>(uvBuffer, ...)  voxelization.cpp:466-468 (new, existing)
+//   triangles, ascending     -> moveUvBufferIntoVoxels                voxelization.cpp:513-526 (new, existing)
+//   sub-voxels, ascending    -> documented downscale semantics        voxelization.hpp:82-85
+__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, const HitRec *__restrict__ pool,
+                                                    const Counters *c, Materials m, uint4 *out, Params p)
+{
+    const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const Occ o = occ[i];
+        bool first = true;
+        uint64_t last = 0;
+        uint32_t cur_group = 0;
+        bool have_tri = false, have_sub = false, have_cell = false;
+        uint32_t cur_sub = 0;
+        WUv tri_acc{0, 0, 0};
+        WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
+        for (;;) {
+            uint32_t best = 0;
+            uint64_t best_key = ~0ull;
+            for (uint32_t q = o.head; q; q = pool[q - 1].next) {
+                const HitRec &r = pool[q - 1];
+                const uint64_t key = ((uint64_t) r.keyhi << 32) | r.keylo;
+                if ((first || key > last) && (best == 0 || key < best_key)) {
+                    best = q;
+                    best_key = key;
+                }
+            }
+            const bool done = best == 0;
+            HitRec r{};
+            if (!done) r = pool[best - 1];
+            // close the triangle group when the (sub-voxel, triangle) changes or the list ends
+            if (have_tri && (done || r.keyhi != cur_group)) {
+                float cr, cg, cb;
+                color_at(m, cur_group & 0x1fffffffu, tri_acc.u, tri_acc.v, cr, cg, cb);
+                const WCol fresh{tri_acc.w, cr, cg, cb};
+                sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
+                have_sub = true;
+                have_tri = false;
+            }
+            if (have_sub && (done || (r.keyhi >> 29) != cur_sub)) {
+                cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                have_cell = true;
+                have_sub = false;
+            }
+            if (done) break;
+            const WUv hit{r.w, r.u, r.v};
+            if (have_tri) tri_acc = wmix(hit, tri_acc);
+            else tri_acc = hit;
+            have_tri = true;
+            cur_group = r.keyhi;
+            cur_sub = r.keyhi >> 29;
+            last = best_key;
+            first = false;
+        }
+        const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+        const uint64_t row = cell / p.Gx;
+        const uint32_t x = (uint32_t) (cell - row * p.Gx);
+        const uint32_t zrel = (uint32_t) (row / p.G);
+        const uint32_t y = (uint32_t) (row - (uint64_t) zrel * p.G);
+        out[i] = make_uint4(x, y, zrel + p.zo0, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b));
+    }
+}
+
+}  // namespace
+
+// ---- host side: context, buffers, launch sequence ------------------------------------------------------------
+
+struct o2v_hip_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    std::string err;
+
+    // inputs
+    float *d_verts = nullptr, *d_uvs = nullptr, *d_colors = nullptr;
+    uint32_t *d_types = nullptr;
+    int32_t *d_texids = nullptr;
+    uint64_t n_tris = 0;
+    bool any_textured = false;
+    DevTexture *d_textures = nullptr;
+    std::vector<uint8_t *> d_texpix;
+    uint32_t n_textures = 0;
+
+    // work buffers (grown on demand)
+    Counters *d_ctr = nullptr;
+    Counters *h_ctr = nullptr;  // pinned
+    Leaf *d_leaves = nullptr;
+    Tile *d_tiles = nullptr;
+    BigLeaf *d_big = nullptr;
+    Node *d_nodes[2] = {nullptr, nullptr};
+    HitRec *d_pool = nullptr;
+    Occ *d_occ = nullptr;
+    uint4 *d_out = nullptr;
+    uint32_t cap_leaves = 0, cap_tiles = 0, cap_big = 0, cap_nodes = 0, cap_hits = 0, cap_vox = 0;
+
+    // dense grid of list heads for this context's slab
+    uint32_t *d_grid = nullptr;
+    uint64_t grid_cells = 0;      // allocated
+    bool grid_dirty = false;
+
+    // results of the last run
+    uint64_t n_vox = 0;
+    o2v_hip_timings timings = {};
+    o2v_hip_stats stats = {};
+    float xform[12] = {};
+};
+
+namespace {
+
+#define O2V_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                 \
+            return e_ == hipErrorOutOfMemory ? O2V_HIP_ERR_OUT_OF_MEMORY : O2V_HIP_ERR_HIP;               \
+        }                                                                                                 \
+    } while (0)
+
+template <typename T>
+int grow(o2v_hip_ctx *ctx, T *&ptr, uint32_t &cap, uint64_t want)
+{
+    if (want <= cap && ptr) return O2V_HIP_OK;
+    if (want > 0xfffffff0ull) {
+        ctx->err = "device buffer would exceed 2^32 records";
+        return O2V_HIP_ERR_LIMIT;
+    }
+    if (ptr) O2V_CHECK(hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), want * sizeof(T)));
+    cap = (uint32_t) want;
+    return O2V_HIP_OK;
+}
+
+template <typename T>
+int upload(o2v_hip_ctx *ctx, T *&dptr, const T *host, uint64_t count)
+{
+    if (dptr) O2V_CHECK(hipFree(dptr));
+    dptr = nullptr;
+    if (!host || !count) return O2V_HIP_OK;
+    O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&dptr), count * sizeof(T)));
+    O2V_CHECK(hipMemcpy(dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return O2V_HIP_OK;
+}
+
+uint32_t lds_bytes_voxelize(bool uv) { return 5u * (uv ? 15u : 9u) * kBlock * (uint32_t) sizeof(float); }
+
+// One pass of the pipeline with the current capacities.  Fills h_ctr; the caller checks for overflow.
+int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
+{
+    hipStream_t s = ctx->stream;
+    const uint32_t persistent = (uint32_t) ctx->num_cus * 8u;
+    O2V_CHECK(hipEventRecord(ctx->ev[0], s));
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    if (!p.bounds_known)
+        hipLaunchKernelGGL(k_bounds, dim3(std::min<uint64_t>(persistent, (p.n_tris * 3 + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
+    O2V_CHECK(hipEventRecord(ctx->ev[1], s));
+
+    hipLaunchKernelGGL(k_expand_roots, dim3(std::min<uint64_t>(persistent, (p.n_tris + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
+                       ctx->d_big, ctx->d_nodes[0], p);
+    for (uint32_t round = 0; round < kMaxRounds; ++round)
+        hipLaunchKernelGGL(k_expand_nodes, dim3(persistent), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
+                           ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
+    hipLaunchKernelGGL(k_expand_big, dim3(persistent), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
+    O2V_CHECK(hipEventRecord(ctx->ev[2], s));
+
+    {
+        const uint32_t lds = lds_bytes_voxelize(use_uv);
+        const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? 1u : 2u);
+        if (use_uv)
+            hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), lds, s, ctx->d_leaves, ctx->d_tiles,
+                               ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
+        else
+            hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(kBlock), lds, s, ctx->d_leaves, ctx->d_tiles,
+                               ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
+    }
+    O2V_CHECK(hipEventRecord(ctx->ev[3], s));
+
+    {
+        const uint64_t slab_z = (p.zs1 - p.zs0) >> p.ss_shift;
+        const uint64_t n_quads = slab_z * p.G * (p.Gx / 4);
+        const uint64_t iters = (n_quads + (uint64_t) kBlock * kScanUnroll - 1) / ((uint64_t) kBlock * kScanUnroll);
+        hipLaunchKernelGGL(k_scan, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 8u, std::max<uint64_t>(iters, 1))),
+                           dim3(kBlock), 0, s, ctx->d_grid, n_quads, ctx->d_ctr, ctx->d_occ, p);
+    }
+    O2V_CHECK(hipEventRecord(ctx->ev[4], s));
+
+    {
+        Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
+        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_pool, ctx->d_ctr, m,
+                           ctx->d_out, p);
+    }
+    O2V_CHECK(hipEventRecord(ctx->ev[5], s));
+    O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    O2V_CHECK(hipStreamSynchronize(s));
+    O2V_CHECK(hipGetLastError());
+    return O2V_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int o2v_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
+{
+    if (!out_ctx) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return O2V_HIP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return O2V_HIP_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return O2V_HIP_ERR_NO_DEVICE;
+    o2v_hip_ctx *ctx = new o2v_hip_ctx;
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return O2V_HIP_ERR_HIP;
+    }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return O2V_HIP_ERR_HIP;
+        }
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_ctr), sizeof(Counters)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&ctx->h_ctr), sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
+        delete ctx;
+        return O2V_HIP_ERR_OUT_OF_MEMORY;
+    }
+    // the clip stacks of k_voxelize<true> need more than the default 64 KiB of dynamic LDS
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_voxelize<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes_voxelize(true));
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_voxelize<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes_voxelize(false));
+    *out_ctx = ctx;
+    return O2V_HIP_OK;
+}
+
+void o2v_hip_destroy(o2v_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
+                    ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
+                    ctx->d_pool,  ctx->d_occ,  ctx->d_out,      ctx->d_grid};
+    for (void *q : ptrs)
+        if (q) (void) hipFree(q);
+    for (uint8_t *q : ctx->d_texpix)
+        if (q) (void) hipFree(q);
+    if (ctx->h_ctr) (void) hipHostFree(ctx->h_ctr);
+    for (auto &e : ctx->ev)
+        if (e) (void) hipEventDestroy(e);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *o2v_hip_last_error(const o2v_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int o2v_hip_set_triangles(o2v_hip_ctx *ctx, const float *verts, const float *uvs, const uint32_t *types,
+                          const float *colors, const int32_t *texids, uint64_t count)
+{
+    if (!ctx || (count && !verts)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    if (count >= (1ull << 29)) {
+        ctx->err = "triangle count must be below 2^29";
+        return O2V_HIP_ERR_LIMIT;
+    }
+    O2V_CHECK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->d_verts, verts, count * 9))) return rc;
+    if ((rc = upload(ctx, ctx->d_uvs, uvs, count * 6))) return rc;
+    if ((rc = upload(ctx, ctx->d_types, types, count))) return rc;
+    if ((rc = upload(ctx, ctx->d_colors, colors, count * 3))) return rc;
+    if ((rc = upload(ctx, ctx->d_texids, texids, count))) return rc;
+    ctx->n_tris = count;
+    ctx->any_textured = false;
+    if (types)
+        for (uint64_t i = 0; i < count; ++i)
+            if (types[i] == O2V_HIP_TRI_TEXTURED) {
+                ctx->any_textured = true;
+                break;
+            }
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_set_textures(o2v_hip_ctx *ctx, const o2v_hip_texture *textures, uint32_t count)
+{
+    if (!ctx || (count && !textures)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    for (uint8_t *q : ctx->d_texpix)
+        if (q) O2V_CHECK(hipFree(q));
+    ctx->d_texpix.clear();
+    if (ctx->d_textures) O2V_CHECK(hipFree(ctx->d_textures));
+    ctx->d_textures = nullptr;
+    ctx->n_textures = 0;
+    if (!count) return O2V_HIP_OK;
+    std::vector<DevTexture> host(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        const o2v_hip_texture &t = textures[i];
+        if (!t.pixels || !t.width || !t.height || (t.channels != 3 && t.channels != 4)) {
+            ctx->err = "texture must have pixels, a non-zero size and 3 or 4 channels";
+            return O2V_HIP_ERR_BAD_ARGUMENT;
+        }
+        const size_t bytes = (size_t) t.width * t.height * t.channels;
+        uint8_t *d = nullptr;
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+        ctx->d_texpix.push_back(d);
+        O2V_CHECK(hipMemcpy(d, t.pixels, bytes, hipMemcpyHostToDevice));
+        host[i] = DevTexture{d, t.width, t.height, t.channels, t.wrap};
+    }
+    O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_textures), count * sizeof(DevTexture)));
+    O2V_CHECK(hipMemcpy(ctx->d_textures, host.data(), count * sizeof(DevTexture), hipMemcpyHostToDevice));
+    ctx->n_textures = count;
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *out_voxel_count)
+{
+    if (!ctx || !params) return O2V_HIP_ERR_BAD_ARGUMENT;
+    if (out_voxel_count) *out_voxel_count = 0;
+    const uint32_t ss = params->supersampling ? params->supersampling : 1u;
+    if (params->resolution == 0 || ss > 2 || params->strategy > 1) {
+        ctx->err = "resolution must be non-zero, supersampling 1 or 2, strategy 0 or 1";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
+    const uint64_t S64 = (uint64_t) params->resolution * ss;
+    if (S64 > 65535u) {
+        ctx->err = "sample resolution must be below 65536";
+        return O2V_HIP_ERR_LIMIT;
+    }
+    uint32_t z0 = params->z_begin, z1 = params->z_end;
+    if (z0 == 0 && z1 == 0) z1 = params->resolution;
+    if (z1 > params->resolution || z0 >= z1) {
+        ctx->err = "z slab must satisfy z_begin < z_end <= resolution";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
+    O2V_CHECK(hipSetDevice(ctx->device));
+    ctx->n_vox = 0;
+    ctx->timings = {};
+    ctx->stats = {};
+    ctx->stats.triangles = ctx->n_tris;
+
+    Params p{};
+    p.n_tris = ctx->n_tris;
+    p.S = (uint32_t) S64;
+    p.G = params->resolution;
+    p.Gx = (p.G + 3u) & ~3u;
+    p.ss_shift = ss == 2 ? 1u : 0u;
+    p.zs0 = z0 * ss;
+    p.zs1 = z1 * ss;
+    p.zo0 = z0;
+    p.blend = params->strategy;
+    p.bounds_known = params->bounds_known;
+    for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
+    for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];
+    p.has_uv = ctx->d_uvs ? 1u : 0u;
+    const bool use_uv = ctx->d_uvs && ctx->any_textured;
+
+    // dense grid for the slab; allocated zeroed, kept clean by k_scan
+    const uint64_t cells = (uint64_t) (z1 - z0) * p.G * p.Gx;
+    ctx->stats.grid_cells = cells;
+    ctx->stats.grid_bytes = cells * sizeof(uint32_t);
+    if (cells > ctx->grid_cells || !ctx->d_grid) {
+        if (ctx->d_grid) O2V_CHECK(hipFree(ctx->d_grid));
+        ctx->d_grid = nullptr;
+        ctx->grid_cells = 0;
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_grid), cells * sizeof(uint32_t)));
+        ctx->grid_cells = cells;
+        ctx->grid_dirty = true;
+    }
+    if (ctx->grid_dirty) {
+        O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
+        ctx->grid_dirty = false;
+    }
+    if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
+
+    // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
+    uint64_t want_leaves = std::max<uint64_t>(ctx->cap_leaves, ctx->n_tris + ctx->n_tris / 4 + (1u << 16));
+    uint64_t want_tiles = std::max<uint64_t>(ctx->cap_tiles, ctx->n_tris + ctx->n_tris / 2 + (1u << 16));
+    uint64_t want_big = std::max<uint64_t>(ctx->cap_big, 1u << 16);
+    uint64_t want_nodes = std::max<uint64_t>(ctx->cap_nodes, 1u << 18);
+    uint64_t want_hits = std::max<uint64_t>(ctx->cap_hits, std::min<uint64_t>(16 * ctx->n_tris + (4u << 20), 1ull << 31));
+    uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
+
+    ctx->grid_dirty = true;  // until a pass completes (k_scan leaves it clean)
+    for (uint32_t pass = 1; pass <= 12; ++pass) {
+        int rc;
+        if ((rc = grow(ctx, ctx->d_leaves, ctx->cap_leaves, want_leaves))) return rc;
+        if ((rc = grow(ctx, ctx->d_tiles, ctx->cap_tiles, want_tiles))) return rc;
+        if ((rc = grow(ctx, ctx->d_big, ctx->cap_big, want_big))) return rc;
+        uint32_t cap_n0 = ctx->cap_nodes, cap_n1 = ctx->cap_nodes;
+        if ((rc = grow(ctx, ctx->d_nodes[0], cap_n0, want_nodes))) return rc;
+        if ((rc = grow(ctx, ctx->d_nodes[1], cap_n1, want_nodes))) return rc;
+        ctx->cap_nodes = cap_n0;
+        if ((rc = grow(ctx, ctx->d_pool, ctx->cap_hits, want_hits))) return rc;
+        uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
+        if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
+        if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
+        ctx->cap_vox = cap_v0;
+        p.cap_leaves = ctx->cap_leaves;
+        p.cap_tiles = ctx->cap_tiles;
+        p.cap_big = ctx->cap_big;
+        p.cap_nodes = ctx->cap_nodes;
+        p.cap_hits = ctx->cap_hits;
+        p.cap_vox = ctx->cap_vox;
+
+        if ((rc = run_pass(ctx, p, use_uv))) return rc;
+        const Counters &h = *ctx->h_ctr;
+        ctx->timings.passes = pass;
+        if (h.err_flags) {
+            ctx->grid_dirty = false;
+            ctx->err = (h.err_flags & kErrLeafTooLarge) ? "a leaf's voxel AABB has 2^32 or more candidate voxels"
+                                                        : "subdivision deeper than 15 levels";
+            return O2V_HIP_ERR_LIMIT;
+        }
+        uint32_t max_nodes = 0;
+        for (uint32_t r = 0; r <= kMaxRounds; ++r) max_nodes = std::max(max_nodes, h.n_nodes[r]);
+        bool again = false;
+        auto need = [&](uint64_t used, uint32_t cap, uint64_t &want) {
+            if (used > cap) {
+                want = used + used / 4 + 1024;
+                again = true;
+            }
+        };
+        need(h.n_leaves, ctx->cap_leaves, want_leaves);
+        need(h.n_tiles, ctx->cap_tiles, want_tiles);
+        need(h.n_big, ctx->cap_big, want_big);
+        need(max_nodes, ctx->cap_nodes, want_nodes);
+        need(h.n_hits_reserved, ctx->cap_hits, want_hits);
+        need(h.n_vox, ctx->cap_vox, want_vox);
+        if (!again) {
+            ctx->grid_dirty = false;
+            ctx->n_vox = h.n_vox;
+            ctx->stats.leaves = h.n_leaves;
+            ctx->stats.tiles = h.n_tiles;
+            ctx->stats.candidates = h.n_candidates;
+            ctx->stats.hits = h.n_hits;
+            ctx->stats.voxels = h.n_vox;
+            std::memcpy(ctx->xform, h.xform, sizeof(ctx->xform));
+            float ms[5];
+            for (int i = 0; i < 5; ++i) O2V_CHECK(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+            ctx->timings.bounds_ms = ms[0];
+            ctx->timings.expand_ms = ms[1];
+            ctx->timings.voxelize_ms = ms[2];
+            ctx->timings.scan_ms = ms[3];
+            ctx->timings.resolve_ms = ms[4];
+            O2V_CHECK(hipEventElapsedTime(&ctx->timings.total_ms, ctx->ev[0], ctx->ev[5]));
+            if (out_voxel_count) *out_voxel_count = ctx->n_vox;
+            return O2V_HIP_OK;
+        }
+    }
+    ctx->err = "device buffers did not converge after 12 passes";
+    return O2V_HIP_ERR_LIMIT;
+}
+
+int o2v_hip_read_voxels(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count)
+{
+    if (!ctx || (!out && count)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    if (first + count > ctx->n_vox) {
+        ctx->err = "voxel range out of bounds";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
+    if (!count) return O2V_HIP_OK;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    O2V_CHECK(hipMemcpy(out, ctx->d_out + first, count * sizeof(uint4), hipMemcpyDeviceToHost));
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_voxels_device_ptr(o2v_hip_ctx *ctx, const uint32_t **out_ptr, uint64_t *out_count)
+{
+    if (!ctx || !out_ptr || !out_count) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out_ptr = reinterpret_cast<const uint32_t *>(ctx->d_out);
+    *out_count = ctx->n_vox;
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_get_timings(const o2v_hip_ctx *ctx, o2v_hip_timings *out)
+{
+    if (!ctx || !out) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out = ctx->timings;
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_get_stats(const o2v_hip_ctx *ctx, o2v_hip_stats *out)
+{
+    if (!ctx || !out) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out = ctx->stats;
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_get_transform(const o2v_hip_ctx *ctx, float out12[12])
+{
+    if (!ctx || !out12) return O2V_HIP_ERR_BAD_ARGUMENT;
+    std::memcpy(out12, ctx->xform, sizeof(ctx->xform));
+    return O2V_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,562 @@
+// o2v_io.cpp -- triangle sources (binary STL, Wavefront OBJ + MTL, PNG textures) and voxel sinks
+// (VL32, PLY, XYZRGB; file or memory).  Formats as documented in the reference's README.adoc:210-264.
+#include "o2v_io.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+namespace o2v {
+
+namespace {
+
+enum { LOG_ERROR = 1, LOG_WARNING = 2, LOG_INFO = 3, LOG_DEBUG = 4 };
+
+std::string lower(std::string s)
+{
+    for (char &c : s) c = (char) std::tolower((unsigned char) c);
+    return s;
+}
+
+}  // namespace
+
+FileFormat detect_format(const char *path, const char *type)
+{
+    std::string ext;
+    if (type) ext = type;
+    else if (path) {
+        std::string p{path};
+        size_t dot = p.find_last_of('.');
+        if (dot == std::string::npos) return FileFormat::UNKNOWN;
+        ext = p.substr(dot + 1);
+    }
+    ext = lower(ext);
+    if (ext == "obj") return FileFormat::OBJ;
+    if (ext == "stl") return FileFormat::STL;
+    if (ext == "vl32") return FileFormat::VL32;
+    if (ext == "ply") return FileFormat::PLY;
+    if (ext == "xyzrgb" || ext == "xyz") return FileFormat::XYZRGB;
+    if (ext == "qef") return FileFormat::QEF;
+    if (ext == "vox") return FileFormat::VOX;
+    if (ext == "png") return FileFormat::PNG;
+    return FileFormat::UNKNOWN;
+}
+
+bool read_whole_file(const char *path, std::vector<uint8_t> &out)
+{
+    std::FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    if (n < 0) {
+        std::fclose(f);
+        return false;
+    }
+    out.resize((size_t) n);
+    size_t got = n ? std::fread(out.data(), 1, (size_t) n, f) : 0;
+    std::fclose(f);
+    return got == (size_t) n;
+}
+
+// ---- PNG ---------------------------------------------------------------------------------------------------
+
+namespace {
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t) p[0] << 24) | ((uint32_t) p[1] << 16) | ((uint32_t) p[2] << 8) | p[3]; }
+
+int paeth(int a, int b, int c)
+{
+    int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+}  // namespace
+
+bool decode_png_argb(const uint8_t *data, size_t size, std::vector<uint8_t> &argb, size_t &width, size_t &height,
+                     std::string &err)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (size < 8 || std::memcmp(data, sig, 8) != 0) {
+        err = "not a PNG file";
+        return false;
+    }
+    size_t pos = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, palette, trns;
+    bool have_ihdr = false;
+    while (pos + 12 <= size) {
+        uint32_t len = be32(data + pos);
+        const uint8_t *tag = data + pos + 4;
+        const uint8_t *body = data + pos + 8;
+        if (pos + 12 + (size_t) len > size) {
+            err = "truncated chunk";
+            return false;
+        }
+        if (!std::memcmp(tag, "IHDR", 4) && len >= 13) {
+            w = be32(body);
+            h = be32(body + 4);
+            depth = body[8];
+            ctype = body[9];
+            interlace = body[12];
+            have_ihdr = true;
+        }
+        else if (!std::memcmp(tag, "PLTE", 4)) palette.assign(body, body + len);
+        else if (!std::memcmp(tag, "tRNS", 4)) trns.assign(body, body + len);
+        else if (!std::memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!std::memcmp(tag, "IEND", 4)) break;
+        pos += 12 + (size_t) len;
+    }
+    if (!have_ihdr || w == 0 || h == 0) {
+        err = "missing IHDR";
+        return false;
+    }
+    if (interlace) {
+        err = "interlaced PNG is not supported";
+        return false;
+    }
+    int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!channels || (depth != 8 && depth != 16 && !(depth < 8 && (ctype == 0 || ctype == 3)))) {
+        err = "unsupported colour type / bit depth";
+        return false;
+    }
+    const size_t bpp_bits = (size_t) channels * depth;
+    const size_t stride = (w * bpp_bits + 7) / 8;
+    const size_t bpp = std::max<size_t>(1, bpp_bits / 8);
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf raw_len = (uLongf) raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong) idat.size()) != Z_OK || raw_len != raw.size()) {
+        err = "zlib inflate failed";
+        return false;
+    }
+    // undo the scanline filters
+    std::vector<uint8_t> img(stride * h);
+    for (size_t y = 0; y < h; ++y) {
+        const uint8_t ft = raw[y * (stride + 1)];
+        const uint8_t *in = &raw[y * (stride + 1) + 1];
+        uint8_t *out = &img[y * stride];
+        const uint8_t *up = y ? &img[(y - 1) * stride] : nullptr;
+        for (size_t x = 0; x < stride; ++x) {
+            int a = x >= bpp ? out[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+            int v = in[x];
+            switch (ft) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) / 2; break;
+            case 4: v += paeth(a, b, c); break;
+            default: err = "bad filter type"; return false;
+            }
+            out[x] = (uint8_t) v;
+        }
+    }
+    argb.resize((size_t) w * h * 4);
+    for (size_t y = 0; y < h; ++y) {
+        const uint8_t *row = &img[y * stride];
+        for (size_t x = 0; x < w; ++x) {
+            uint8_t r = 0, g = 0, b = 0, a = 255;
+            auto sample = [&](size_t idx) -> uint8_t {
+                if (depth == 8) return row[idx];
+                if (depth == 16) return row[idx * 2];
+                size_t bit = idx * depth;
+                uint8_t v = (row[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
+                return ctype == 3 ? v : (uint8_t) (v * 255 / ((1 << depth) - 1));
+            };
+            switch (ctype) {
+            case 0: r = g = b = sample(x); break;
+            case 2: r = sample(x * 3); g = sample(x * 3 + 1); b = sample(x * 3 + 2); break;
+            case 3: {
+                size_t i = sample(x);
+                if (i * 3 + 2 < palette.size()) {
+                    r = palette[i * 3];
+                    g = palette[i * 3 + 1];
+                    b = palette[i * 3 + 2];
+                }
+                if (i < trns.size()) a = trns[i];
+                break;
+            }
+            case 4: r = g = b = sample(x * 2); a = sample(x * 2 + 1); break;
+            case 6: r = sample(x * 4); g = sample(x * 4 + 1); b = sample(x * 4 + 2); a = sample(x * 4 + 3); break;
+            }
+            uint8_t *o = &argb[(y * w + x) * 4];
+            o[0] = a; o[1] = r; o[2] = g; o[3] = b;
+        }
+    }
+    width = w;
+    height = h;
+    return true;
+}
+
+// ---- STL (reference io.cpp:395-435; binary only, like the reference) ------------------------------------------
+
+namespace {
+
+struct VectorTriangleSource final : TriangleSource {
+    std::vector<HostTriangle> tris;
+    size_t index = 0;
+    std::vector<obj2voxel_texture *> owned_textures;
+    ~VectorTriangleSource() override
+    {
+        for (auto *t : owned_textures) texture_delete(t);
+    }
+    bool next(HostTriangle &out) override
+    {
+        if (index >= tris.size()) return false;
+        out = tris[index++];
+        return true;
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<TriangleSource> open_stl_file(const char *path)
+{
+    std::vector<uint8_t> bytes;
+    if (!read_whole_file(path, bytes)) {
+        log_message(LOG_ERROR, std::string("Failed to open STL file: \"") + path + "\"");
+        return nullptr;
+    }
+    if (bytes.size() < 84) {
+        log_message(LOG_ERROR, "Binary STL file must start with a header of 80 characters and a triangle count");
+        return nullptr;
+    }
+    if (std::memcmp(bytes.data(), "solid", 5) == 0) {
+        log_message(LOG_ERROR, "The given file is an ASCII STL file which is not supported");
+        return nullptr;
+    }
+    uint32_t count;
+    std::memcpy(&count, bytes.data() + 80, 4);
+    if (bytes.size() < 84 + (size_t) count * 50) {
+        log_message(LOG_ERROR, "Unexpected EOF when reading STL triangles");
+        return nullptr;
+    }
+    auto src = std::make_unique<VectorTriangleSource>();
+    src->tris.resize(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        // 12 floats (normal, v0, v1, v2) + u16 attribute.  All three vertices of record i are used (the
+        // reference's StlTriangleStream::next, io.cpp:171-187, is off by one vertex; not reproduced).
+        HostTriangle &t = src->tris[i];
+        std::memset(&t, 0, sizeof(t));
+        std::memcpy(t.v, bytes.data() + 84 + (size_t) i * 50 + 12, 36);
+        t.type = 1;  // MATERIALLESS
+    }
+    return src;
+}
+
+// ---- OBJ + MTL (the subset obj2voxel consumes through tinyobjloader: io.cpp:244-312,351-393) -----------------
+
+namespace {
+
+struct Material {
+    std::string name;
+    float kd[3] = {0.6f, 0.6f, 0.6f};  // tinyobjloader's default diffuse is 0.6 when Kd is absent
+    std::string map_kd;
+};
+
+std::string dir_of(const std::string &p)
+{
+    size_t s = p.find_last_of("/\\");
+    return s == std::string::npos ? std::string{} : p.substr(0, s + 1);
+}
+
+void load_mtl(const std::string &path, std::vector<Material> &materials, std::map<std::string, int> &by_name)
+{
+    std::ifstream in(path);
+    if (!in) {
+        log_message(LOG_WARNING, "Material file \"" + path + "\" not found");
+        return;
+    }
+    std::string line;
+    Material *cur = nullptr;
+    while (std::getline(in, line)) {
+        std::istringstream ss(line);
+        std::string key;
+        if (!(ss >> key)) continue;
+        if (key == "newmtl") {
+            Material m;
+            ss >> m.name;
+            by_name[m.name] = (int) materials.size();
+            materials.push_back(m);
+            cur = &materials.back();
+        }
+        else if (!cur) continue;
+        else if (key == "Kd") ss >> cur->kd[0] >> cur->kd[1] >> cur->kd[2];
+        else if (key == "map_Kd") {
+            std::string rest;
+            std::getline(ss, rest);
+            size_t b = rest.find_first_not_of(" \t");
+            size_t e = rest.find_last_not_of(" \t\r");
+            if (b != std::string::npos) cur->map_kd = rest.substr(b, e - b + 1);
+        }
+    }
+}
+
+}  // namespace
+
+std::unique_ptr<TriangleSource> open_obj_file(const char *path, const obj2voxel_texture *default_texture)
+{
+    std::ifstream in(path);
+    if (!in) {
+        log_message(LOG_ERROR, std::string("Failed to open OBJ file: \"") + path + "\"");
+        return nullptr;
+    }
+    const std::string base = dir_of(path);
+    std::vector<float> pos, tex;
+    std::vector<Material> materials;
+    std::map<std::string, int> material_by_name;
+    std::map<std::string, obj2voxel_texture *> textures;
+    auto src = std::make_unique<VectorTriangleSource>();
+    int cur_material = -1;
+    std::string line;
+    struct Idx {
+        long v, t;
+    };
+    std::vector<Idx> face;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        std::string key;
+        if (!(ss >> key)) continue;
+        if (key == "v") {
+            float x = 0, y = 0, z = 0;
+            ss >> x >> y >> z;
+            pos.insert(pos.end(), {x, y, z});
+        }
+        else if (key == "vt") {
+            float u = 0, v = 0;
+            ss >> u >> v;
+            tex.insert(tex.end(), {u, v});
+        }
+        else if (key == "mtllib") {
+            std::string name;
+            ss >> name;
+            load_mtl(base + name, materials, material_by_name);
+        }
+        else if (key == "usemtl") {
+            std::string name;
+            ss >> name;
+            auto it = material_by_name.find(name);
+            cur_material = it == material_by_name.end() ? -1 : it->second;
+        }
+        else if (key == "f") {
+            face.clear();
+            std::string item;
+            while (ss >> item) {
+                Idx ix{0, 0};
+                ix.v = std::strtol(item.c_str(), nullptr, 10);
+                size_t s1 = item.find('/');
+                if (s1 != std::string::npos && s1 + 1 < item.size() && item[s1 + 1] != '/')
+                    ix.t = std::strtol(item.c_str() + s1 + 1, nullptr, 10);
+                const long nv = (long) (pos.size() / 3), nt = (long) (tex.size() / 2);
+                ix.v = ix.v < 0 ? nv + ix.v : ix.v - 1;
+                ix.t = ix.t < 0 ? nt + ix.t : ix.t - 1;  // -1 when absent
+                if (ix.v < 0 || ix.v >= nv) {
+                    log_message(LOG_ERROR, "OBJ face references a vertex that does not exist");
+                    return nullptr;
+                }
+                if (ix.t >= nt) ix.t = -1;
+                face.push_back(ix);
+            }
+            // fan triangulation, as tinyobjloader does for convex polygons
+            for (size_t k = 1; k + 1 < face.size(); ++k) {
+                const Idx tri[3] = {face[0], face[k], face[k + 1]};
+                HostTriangle t;
+                std::memset(&t, 0, sizeof(t));
+                bool has_uv = true;
+                for (int c = 0; c < 3; ++c) {
+                    std::memcpy(&t.v[c * 3], &pos[(size_t) tri[c].v * 3], 12);
+                    if (tri[c].t >= 0) std::memcpy(&t.t[c * 2], &tex[(size_t) tri[c].t * 2], 8);
+                    else has_uv = false;
+                }
+                if (!has_uv) std::memset(t.t, 0, sizeof(t.t));
+                // material decision: reference io.cpp:277-303
+                const Material *m = cur_material < 0 ? nullptr : &materials[(size_t) cur_material];
+                if (!m) {
+                    if (has_uv && default_texture) {
+                        t.type = 3;
+                        t.texture = default_texture;
+                    }
+                    else t.type = 1;
+                }
+                else {
+                    const obj2voxel_texture *tx = nullptr;
+                    if (has_uv && !m->map_kd.empty()) {
+                        auto it = textures.find(m->map_kd);
+                        if (it == textures.end()) {
+                            std::string file = m->map_kd;
+                            std::replace(file.begin(), file.end(), '\\', '/');
+                            std::vector<uint8_t> bytes, argb;
+                            size_t w = 0, h = 0;
+                            std::string err;
+                            obj2voxel_texture *made = nullptr;
+                            if (!read_whole_file((base + file).c_str(), bytes) && !read_whole_file(file.c_str(), bytes))
+                                log_message(LOG_WARNING, "Failed to open texture file \"" + file + "\" of material \"" + m->name + "\"");
+                            else if (!decode_png_argb(bytes.data(), bytes.size(), argb, w, h, err))
+                                log_message(LOG_WARNING, "Failed to decode texture \"" + file + "\": " + err);
+                            else {
+                                made = texture_new();
+                                texture_set_argb(made, std::move(argb), w, h);
+                                src->owned_textures.push_back(made);
+                                log_message(LOG_INFO, "Loaded texture \"" + file + "\"");
+                            }
+                            it = textures.emplace(m->map_kd, made).first;
+                        }
+                        tx = it->second;
+                    }
+                    if (tx) {
+                        t.type = 3;
+                        t.texture = tx;
+                    }
+                    else {
+                        t.type = 2;
+                        std::memcpy(t.color, m->kd, sizeof(t.color));
+                    }
+                }
+                src->tris.push_back(t);
+            }
+        }
+    }
+    return src;
+}
+
+// ---- sinks ---------------------------------------------------------------------------------------------------
+
+namespace {
+
+// Writes through a FILE* or into a byte vector.
+struct ByteOut {
+    std::FILE *file = nullptr;
+    std::vector<uint8_t> mem;
+    bool ok = true;
+    ~ByteOut()
+    {
+        if (file) std::fclose(file);
+    }
+    void put(const void *p, size_t n)
+    {
+        if (!ok || !n) return;
+        if (file) ok = std::fwrite(p, 1, n, file) == n;
+        else {
+            const uint8_t *b = static_cast<const uint8_t *>(p);
+            mem.insert(mem.end(), b, b + n);
+        }
+    }
+    void patch(size_t offset, const void *p, size_t n)
+    {
+        if (!ok) return;
+        if (file) {
+            long cur = std::ftell(file);
+            ok = std::fseek(file, (long) offset, SEEK_SET) == 0 && std::fwrite(p, 1, n, file) == n &&
+                 std::fseek(file, cur, SEEK_SET) == 0;
+        }
+        else std::memcpy(mem.data() + offset, p, n);
+    }
+    void flush()
+    {
+        if (file && ok) ok = std::fflush(file) == 0;
+    }
+};
+
+void put_be32(uint8_t *o, uint32_t v)
+{
+    o[0] = (uint8_t) (v >> 24);
+    o[1] = (uint8_t) (v >> 16);
+    o[2] = (uint8_t) (v >> 8);
+    o[3] = (uint8_t) v;
+}
+
+// VL32: big-endian (x, y, z) int32 then a, r, g, b bytes (README.adoc:233-252).  PLY: 300-byte header followed
+// by the same records (README.adoc:214-231).  XYZRGB: one "x y z r g b" text line per voxel.
+struct ListSink final : VoxelSink {
+    ByteOut out;
+    FileFormat format;
+    bool is_memory;
+    bool finalized = false;
+    static constexpr size_t kPlyHeader = 300;
+    size_t count_offset = 0;
+    std::vector<uint8_t> scratch;
+
+    ListSink(FileFormat f, bool memory) : format{f}, is_memory{memory} {}
+
+    void begin()
+    {
+        if (format != FileFormat::PLY) return;
+        std::string h = "ply\nformat binary_big_endian 1.0\nelement vertex ";
+        count_offset = h.size();
+        h += "00000000000000000000\n";  // patched in finalize(); fixed width keeps the header at 300 bytes
+        h += "property int x\nproperty int y\nproperty int z\n"
+             "property uchar alpha\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n";
+        const std::string tail = "end_header\n";
+        std::string pad = "comment ";
+        const size_t used = h.size() + tail.size() + pad.size() + 1;
+        pad += std::string(kPlyHeader > used ? kPlyHeader - used : 0, ' ');
+        pad += "\n";
+        h += pad + tail;
+        out.put(h.data(), h.size());
+    }
+    bool can_write() const override { return out.ok; }
+    void write(uint32_t *voxels, size_t count) override
+    {
+        written += count;
+        if (format == FileFormat::XYZRGB) {
+            std::string s;
+            char buf[96];
+            for (size_t i = 0; i < count; ++i) {
+                const uint32_t *v = voxels + i * 4;
+                int n = std::snprintf(buf, sizeof(buf), "%u %u %u %u %u %u\n", v[0], v[1], v[2], (v[3] >> 16) & 255u,
+                                      (v[3] >> 8) & 255u, v[3] & 255u);
+                s.append(buf, (size_t) n);
+            }
+            out.put(s.data(), s.size());
+            return;
+        }
+        scratch.resize(count * 16);
+        for (size_t i = 0; i < count * 4; ++i) put_be32(&scratch[i * 4], voxels[i]);
+        out.put(scratch.data(), scratch.size());
+    }
+    void finalize() override
+    {
+        if (finalized) return;
+        finalized = true;
+        if (format == FileFormat::PLY) {
+            char digits[32];
+            std::snprintf(digits, sizeof(digits), "%020llu", (unsigned long long) written);
+            out.patch(count_offset, digits, 20);
+        }
+        out.flush();
+    }
+    const std::vector<uint8_t> *memory() const override { return is_memory ? &out.mem : nullptr; }
+};
+
+std::unique_ptr<VoxelSink> make_list_sink(FileFormat format, const char *path)
+{
+    if (format != FileFormat::VL32 && format != FileFormat::PLY && format != FileFormat::XYZRGB) {
+        log_message(LOG_ERROR, "This build writes VL32, PLY and XYZRGB; palette formats (QEF, VOX) are not implemented");
+        return nullptr;
+    }
+    auto sink = std::make_unique<ListSink>(format, path == nullptr);
+    if (path) {
+        sink->out.file = std::fopen(path, "wb");
+        if (!sink->out.file) {
+            log_message(LOG_ERROR, std::string("Failed to open output file: \"") + path + "\"");
+            return nullptr;
+        }
+    }
+    sink->begin();
+    return sink;
+}
+
+}  // namespace
+
+std::unique_ptr<VoxelSink> open_file_sink(const char *path, FileFormat format, uint32_t) { return make_list_sink(format, path); }
+std::unique_ptr<VoxelSink> open_memory_sink(FileFormat format, uint32_t) { return make_list_sink(format, nullptr); }
+
+}  // namespace o2v

@@ -1,0 +1,65 @@
+// o2v_io.hpp -- host-side triangle sources and voxel sinks (the steps either side of the hot path).
+//
+// Mirrors the reference's ITriangleStream / IVoxelSink pair (src/io.hpp:29-92).  These are plumbing around
+// the GPU path: file parsing and encoding stay on the CPU.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+struct obj2voxel_texture;
+
+namespace o2v {
+
+enum class FileFormat { UNKNOWN, OBJ, STL, VL32, PLY, XYZRGB, QEF, VOX, PNG };
+
+/// Format from an explicit extension (without dot) or, if type is null, from the path's extension.
+FileFormat detect_format(const char *path, const char *type);
+
+void log_message(int level, const std::string &msg);
+
+/// What the reference caches per triangle (obj2voxel_triangle, src/triangle.hpp:170-195).
+struct HostTriangle {
+    float v[9];
+    float t[6];
+    uint32_t type;
+    float color[3];
+    const obj2voxel_texture *texture;
+};
+
+struct TriangleSource {  // reference io.hpp:29-67
+    virtual ~TriangleSource() = default;
+    virtual bool next(HostTriangle &out) = 0;
+};
+
+struct VoxelSink {  // reference io.hpp:69-92
+    size_t written = 0;
+    virtual ~VoxelSink() = default;
+    virtual bool can_write() const = 0;
+    /// `voxels` holds count (x, y, z, argb) quadruples; a sink may modify the buffer.
+    virtual void write(uint32_t *voxels, size_t count) = 0;
+    virtual void finalize() = 0;
+    /// The in-memory bytes of a memory sink, else null.
+    virtual const std::vector<uint8_t> *memory() const { return nullptr; }
+};
+
+std::unique_ptr<TriangleSource> open_stl_file(const char *path);
+std::unique_ptr<TriangleSource> open_obj_file(const char *path, const obj2voxel_texture *default_texture);
+
+std::unique_ptr<VoxelSink> open_file_sink(const char *path, FileFormat format, uint32_t resolution);
+std::unique_ptr<VoxelSink> open_memory_sink(FileFormat format, uint32_t resolution);
+
+bool read_whole_file(const char *path, std::vector<uint8_t> &out);
+/// Decodes a non-interlaced PNG into 8-bit ARGB (4 bytes per pixel, alpha first).
+bool decode_png_argb(const uint8_t *data, size_t size, std::vector<uint8_t> &argb, size_t &width, size_t &height,
+                     std::string &err);
+
+// implemented in o2v_api.cpp, where obj2voxel_texture is complete
+obj2voxel_texture *texture_new();
+void texture_delete(obj2voxel_texture *t);
+bool texture_set_argb(obj2voxel_texture *t, std::vector<uint8_t> &&argb, size_t w, size_t h);
+
+}  // namespace o2v

@@ -1,0 +1,153 @@
+"""ctypes binding of the device C-ABI (include/o2v_hip.h): one DeviceVoxelizer per GPU / z-slab."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib
+
+TRI_MATERIALLESS, TRI_UNTEXTURED, TRI_TEXTURED = 1, 2, 3
+STRATEGY_MAX, STRATEGY_BLEND = 0, 1
+
+
+class _Params(C.Structure):
+    _fields_ = [("resolution", C.c_uint32), ("supersampling", C.c_uint32), ("strategy", C.c_uint32),
+                ("unit_transform", C.c_int32 * 9), ("bounds_known", C.c_uint32), ("bounds", C.c_float * 6),
+                ("z_begin", C.c_uint32), ("z_end", C.c_uint32)]
+
+
+class _Texture(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("channels", C.c_uint32), ("wrap", C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("bounds_ms", C.c_float), ("expand_ms", C.c_float), ("voxelize_ms", C.c_float),
+                ("scan_ms", C.c_float), ("resolve_ms", C.c_float), ("total_ms", C.c_float), ("passes", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("triangles", "leaves", "tiles", "candidates", "hits", "voxels",
+                                          "grid_cells", "grid_bytes")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def _bind():
+    L = lib()
+    L.o2v_hip_device_count.restype = C.c_int
+    L.o2v_hip_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.o2v_hip_destroy.argtypes = [C.c_void_p]
+    L.o2v_hip_last_error.argtypes = [C.c_void_p]
+    L.o2v_hip_last_error.restype = C.c_char_p
+    L.o2v_hip_set_triangles.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint64]
+    L.o2v_hip_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.o2v_hip_voxelize.argtypes = [C.c_void_p, C.POINTER(_Params), C.POINTER(C.c_uint64)]
+    L.o2v_hip_read_voxels.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.o2v_hip_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    L.o2v_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.o2v_hip_get_transform.argtypes = [C.c_void_p, C.c_void_p]
+    return L
+
+
+def device_count():
+    return _bind().o2v_hip_device_count()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceVoxelizer:
+    """Owns one GPU's dense grid slab and work buffers; reusable across voxelize() calls."""
+
+    def __init__(self, device=0):
+        self._L = _bind()
+        self._ctx = C.c_void_p()
+        rc = self._L.o2v_hip_create(device, C.byref(self._ctx))
+        if rc != 0:
+            raise DeviceError(f"o2v_hip_create(device={device}) failed with code {rc}: no usable MI355X / HIP runtime")
+        self._keep = []
+
+    def close(self):
+        if self._ctx:
+            self._L.o2v_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise DeviceError(f"{what} failed with code {rc}: {self._L.o2v_hip_last_error(self._ctx).decode()}")
+
+    def set_triangles(self, verts, uvs=None, types=None, colors=None, texids=None):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+        T = verts.shape[0]
+        uvs = None if uvs is None else np.ascontiguousarray(uvs, dtype=np.float32).reshape(T, 6)
+        types = None if types is None else np.ascontiguousarray(types, dtype=np.uint32).reshape(T)
+        colors = None if colors is None else np.ascontiguousarray(colors, dtype=np.float32).reshape(T, 3)
+        texids = None if texids is None else np.ascontiguousarray(texids, dtype=np.int32).reshape(T)
+        self._check(self._L.o2v_hip_set_triangles(self._ctx, _ptr(verts), _ptr(uvs), _ptr(types), _ptr(colors),
+                                                  _ptr(texids), T), "o2v_hip_set_triangles")
+        self.n_tris = T
+
+    def set_textures(self, textures):
+        """textures: sequence of (uint8 [h, w, c] pixels, wrap) with c in (3, 4)."""
+        arr = (_Texture * max(1, len(textures)))()
+        keep = []
+        for i, (pix, wrap) in enumerate(textures):
+            pix = np.ascontiguousarray(pix, dtype=np.uint8)
+            keep.append(pix)
+            h, w, c = pix.shape
+            arr[i] = _Texture(pix.ctypes.data, w, h, c, int(wrap))
+        self._check(self._L.o2v_hip_set_textures(self._ctx, C.cast(arr, C.c_void_p), len(textures)),
+                    "o2v_hip_set_textures")
+
+    def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
+                 zslab=(0, 0), read=True):
+        p = _Params()
+        p.resolution, p.supersampling, p.strategy = resolution, supersampling, strategy
+        ut = (1, 0, 0, 0, 1, 0, 0, 0, 1) if unit_transform is None else tuple(int(x) for x in np.ravel(unit_transform))
+        p.unit_transform = (C.c_int32 * 9)(*ut)
+        if bounds is not None:
+            p.bounds_known = 1
+            p.bounds = (C.c_float * 6)(*[float(x) for x in np.ravel(bounds)])
+        p.z_begin, p.z_end = zslab
+        n = C.c_uint64(0)
+        self._check(self._L.o2v_hip_voxelize(self._ctx, C.byref(p), C.byref(n)), "o2v_hip_voxelize")
+        self.count = n.value
+        if not read:
+            return self.count
+        return self.read_voxels()
+
+    def read_voxels(self):
+        out = np.empty((self.count, 4), dtype=np.uint32)
+        if self.count:
+            self._check(self._L.o2v_hip_read_voxels(self._ctx, _ptr(out), 0, self.count), "o2v_hip_read_voxels")
+        return out
+
+    def timings(self):
+        t = Timings()
+        self._L.o2v_hip_get_timings(self._ctx, C.byref(t))
+        return t.as_dict()
+
+    def stats(self):
+        s = Stats()
+        self._L.o2v_hip_get_stats(self._ctx, C.byref(s))
+        return s.as_dict()
+
+    def transform(self):
+        out = np.zeros(12, dtype=np.float32)
+        self._L.o2v_hip_get_transform(self._ctx, _ptr(out))
+        return out

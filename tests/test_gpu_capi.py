@@ -1,0 +1,114 @@
+"""The reference's own API-level tests (test/main.cpp:128-252), restated against the drop-in C API."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected_unit_cube(res):
+    return 8 + 12 * (res - 2) + 6 * (res - 2) * (res - 2)
+
+
+def _instance(a, verts):
+    from obj2voxel_amd import capi
+    inst = a.obj2voxel_alloc()
+    inp = capi.TriangleInput(verts)
+    a.obj2voxel_set_input_callback(inst, inp.callback, None)
+    return inst, inp
+
+
+def test_unit_cube_produces_expected_voxel_count():  # test/main.cpp:128-156
+    from obj2voxel_amd import capi
+    a = capi.api()
+    inst, inp = _instance(a, meshes.unit_cube())
+    out = capi.CountingOutput()
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    a.obj2voxel_set_resolution(inst, 64)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    a.obj2voxel_free(inst)
+    assert out.voxel_count == _expected_unit_cube(64) == 23816
+
+
+def test_unit_cube_produces_expected_byte_count():  # test/main.cpp:158-179
+    from obj2voxel_amd import capi
+    a = capi.api()
+    inst, inp = _instance(a, meshes.unit_cube())
+    a.obj2voxel_set_output_memory(inst, b"vl32")
+    a.obj2voxel_set_resolution(inst, 64)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    size = C.c_size_t(0)
+    ptr = a.obj2voxel_get_output_memory(inst, C.byref(size))
+    assert bool(ptr)
+    assert size.value == _expected_unit_cube(64) * 16
+    raw = np.ctypeslib.as_array(ptr, shape=(size.value,)).copy()
+    a.obj2voxel_free(inst)
+    rec = raw.view(">u4").reshape(-1, 4)  # VL32: big-endian x, y, z, argb (README.adoc:233-252)
+    assert rec[:, :3].max() == 63 and (rec[:, 3] == 0xFFFFFFFF).all()
+
+
+def test_unit_cube_multiple_chunks():  # test/main.cpp:194-208
+    from obj2voxel_amd import capi
+    a = capi.api()
+    inst, inp = _instance(a, meshes.unit_cube())
+    res = a.obj2voxel_get_chunk_size(inst) * 2
+    a.obj2voxel_set_resolution(inst, res)
+    assert a.obj2voxel_get_resolution(inst) == res == 128
+    out = capi.CountingOutput()
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    a.obj2voxel_free(inst)
+    assert out.voxel_count == 96776
+
+
+@pytest.mark.parametrize("res,expected", [(32, 3072), (128, 49152)])  # test/main.cpp:225-252
+def test_three_planes(res, expected):
+    from obj2voxel_amd import capi
+    a = capi.api()
+    inst, inp = _instance(a, meshes.three_planes())
+    out = capi.CountingOutput()
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    a.obj2voxel_set_resolution(inst, res)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    a.obj2voxel_free(inst)
+    assert out.voxel_count == expected == 3 * res * res
+
+
+def test_double_voxelization_and_sink_failure():
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    inst, inp = _instance(a, meshes.unit_cube())
+    out = capi.CountingOutput(fail_after=0)  # sink reports failure on its first write
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    a.obj2voxel_set_resolution(inst, 32)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_VOXEL_WRITE  # obj2voxel.cpp:509-512
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_DOUBLE_VOXELIZATION  # obj2voxel.cpp:604-606
+    a.obj2voxel_free(inst)
+    a.obj2voxel_set_log_level(capi.LOG_INFO)
+
+
+def test_textured_callback_path_matches_oracle(oracle):
+    from obj2voxel_amd import capi
+    a = capi.api()
+    v, uv = meshes.uv_sphere(10, with_uv=True)
+    pix = meshes.checker_texture(64, 8)
+    tex = a.obj2voxel_texture_alloc()
+    assert a.obj2voxel_texture_load_pixels(tex, pix.ctypes.data, 64, 64, 3)
+    inst = a.obj2voxel_alloc()
+    inp = capi.TriangleInput(v, uvs=uv, texture=tex)
+    out = capi.CollectingOutput()
+    a.obj2voxel_set_input_callback(inst, inp.callback, None)
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    a.obj2voxel_set_resolution(inst, 96)
+    a.obj2voxel_set_color_strategy(inst, capi.BLEND_STRATEGY)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    a.obj2voxel_free(inst)
+    a.obj2voxel_texture_free(tex)
+    T = len(v)
+    want = oracle.voxelize(v, 96, uvs=uv, types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32),
+                           textures=[(pix, 1)], strategy=1)
+    assert np.array_equal(meshes.sorted_voxels(out.voxels()), meshes.sorted_voxels(want))

@@ -1,0 +1,215 @@
+"""Parity of the HIP path against the CPU oracle, through the device C-ABI (include/o2v_hip.h).
+
+Bar: bit-exact occupancy and bit-exact ARGB for both strategies (the device replays every voxel's hits in the
+reference's sequential order, so even BLEND is expected to match exactly; BASELINE.json allows 1 LSB per
+channel for blended colour, asserted as the fallback bound below).
+"""
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dv():
+    from obj2voxel_amd import hip
+    d = hip.DeviceVoxelizer(0)
+    yield d
+    d.close()
+
+
+def _compare(got, want, blend_tolerance=False):
+    got, want = meshes.sorted_voxels(got), meshes.sorted_voxels(want)
+    assert got.shape == want.shape, f"voxel count {got.shape[0]} != oracle {want.shape[0]}"
+    assert np.array_equal(got[:, :3], want[:, :3]), "occupancy differs"
+    if np.array_equal(got[:, 3], want[:, 3]):
+        return
+    if blend_tolerance:
+        ga = got[:, 3:4] >> np.array([24, 16, 8, 0], dtype=np.uint32) & 255
+        wa = want[:, 3:4] >> np.array([24, 16, 8, 0], dtype=np.uint32) & 255
+        assert np.abs(ga.astype(int) - wa.astype(int)).max() <= 1
+    else:
+        bad = np.flatnonzero(got[:, 3] != want[:, 3])
+        raise AssertionError(f"{len(bad)} colours differ, first: {got[bad[0]]} vs {want[bad[0]]}")
+
+
+def _run_both(dv, oracle, verts, res, **kw):
+    from obj2voxel_amd import hip  # noqa: F401
+    uvs, types, colors = kw.get("uvs"), kw.get("types"), kw.get("colors")
+    texids, textures = kw.get("texids"), kw.get("textures", ())
+    if textures:
+        dv.set_textures(list(textures))
+    dv.set_triangles(verts, uvs=uvs, types=types, colors=colors, texids=texids)
+    run = dict(supersampling=kw.get("supersampling", 1), strategy=kw.get("strategy", 0),
+               unit_transform=kw.get("unit_transform"), bounds=kw.get("bounds"), zslab=kw.get("zslab", (0, 0)))
+    got = dv.voxelize(res, **run)
+    want = oracle.voxelize(verts, res, uvs=uvs, types=types, colors=colors, texids=texids, textures=textures, **run)
+    return got, want
+
+
+@pytest.mark.parametrize("res", [32, 64, 128])
+def test_unit_cube(dv, oracle, res):
+    got, want = _run_both(dv, oracle, meshes.unit_cube(), res)
+    _compare(got, want)
+    assert len(got) == 8 + 12 * (res - 2) + 6 * (res - 2) ** 2  # reference test/main.cpp:120-126
+
+
+@pytest.mark.parametrize("res", [32, 128])
+def test_three_planes(dv, oracle, res):
+    got, want = _run_both(dv, oracle, meshes.three_planes(), res)
+    _compare(got, want)
+    assert len(got) == 3 * res * res  # reference test/main.cpp:225-252
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+@pytest.mark.parametrize("nv,res", [(9, 48), (9, 100), (12, 256), (40, 200), (5, 300)])
+def test_colored_sphere(dv, oracle, nv, res, strategy):
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(nv)
+    T = len(v)
+    got, want = _run_both(dv, oracle, v, res, types=np.full(T, hip.TRI_UNTEXTURED, np.uint32),
+                          colors=meshes.triangle_colors(T), strategy=strategy)
+    _compare(got, want, blend_tolerance=False)
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+@pytest.mark.parametrize("wrap", [0, 1])
+def test_textured_sphere(dv, oracle, strategy, wrap):
+    from obj2voxel_amd import hip
+    v, uv = meshes.uv_sphere(14, with_uv=True)
+    uv = uv * 1.5 - 0.2  # leave [0,1] so that wrap / clamp matter
+    T = len(v)
+    tex = [(meshes.checker_texture(64, 8), wrap)]
+    got, want = _run_both(dv, oracle, v, 160, uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32),
+                          texids=np.zeros(T, np.int32), textures=tex, strategy=strategy)
+    _compare(got, want)
+
+
+def test_mixed_materials_two_textures(dv, oracle):
+    v, uv = meshes.uv_sphere(12, with_uv=True)
+    T = len(v)
+    types = (np.arange(T) % 3 + 1).astype(np.uint32)
+    argb = np.concatenate([np.full((32, 32, 1), 255, np.uint8), meshes.checker_texture(32, 4)], axis=2)
+    tex = [(meshes.checker_texture(64, 8), 1), (argb, 0)]
+    got, want = _run_both(dv, oracle, v, 128, uvs=uv, types=types, colors=meshes.triangle_colors(T),
+                          texids=(np.arange(T) % 2).astype(np.int32), textures=tex, strategy=1)
+    _compare(got, want)
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_random_soup(dv, oracle, strategy):
+    from obj2voxel_amd import hip
+    v = meshes.random_soup(400, seed=7, scale=0.5)
+    T = len(v)
+    got, want = _run_both(dv, oracle, v, 150, types=np.full(T, hip.TRI_UNTEXTURED, np.uint32),
+                          colors=meshes.triangle_colors(T), strategy=strategy)
+    _compare(got, want)
+
+
+def test_box_room_large_aligned(dv, oracle):
+    got, want = _run_both(dv, oracle, meshes.box_room(2), 256)
+    _compare(got, want)
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_supersampling(dv, oracle, strategy):
+    from obj2voxel_amd import hip
+    v, uv = meshes.uv_sphere(12, with_uv=True)
+    T = len(v)
+    got, want = _run_both(dv, oracle, v, 64, uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32),
+                          texids=np.zeros(T, np.int32), textures=[(meshes.checker_texture(64, 8), 1)],
+                          strategy=strategy, supersampling=2)
+    _compare(got, want)
+
+
+def test_unit_transform_and_bounds(dv, oracle):
+    v = meshes.uv_sphere(10, radius=0.7, center=(0.1, -0.2, 0.3))
+    got, want = _run_both(dv, oracle, v, 90, unit_transform=[0, 0, 1, 0, -1, 0, 1, 0, 0],
+                          bounds=[-1, -1, -1, 1, 1, 1])
+    _compare(got, want)
+
+
+def test_non_multiple_of_four_resolution(dv, oracle):
+    got, want = _run_both(dv, oracle, meshes.uv_sphere(8), 77)
+    _compare(got, want)
+
+
+def test_degenerate_and_tiny_triangles(dv, oracle):
+    v = np.array([[0, 0, 0, 1, 1, 1, 0, 0, 0],            # zero area (two equal vertices)
+                  [0, 0, 0, 0.5, 0.5, 0.5, 1, 1, 1],      # collinear
+                  [0.2, 0.2, 0.2, 0.2001, 0.2, 0.2, 0.2, 0.2001, 0.2],  # sub-voxel
+                  [0, 0, 0, 1, 0, 0, 0, 1, 0],
+                  [0, 0, 1, 1, 0, 1, 1, 1, 0.3]], dtype=np.float32)
+    got, want = _run_both(dv, oracle, v, 64)
+    _compare(got, want)
+
+
+def test_slabs_union_equals_whole(dv, oracle):
+    """z-slab sharding: every slab equals the matching subset of the full run."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(16)
+    T = len(v)
+    kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=1)
+    full, want = _run_both(dv, oracle, v, 128, **kw)
+    _compare(full, want)
+    parts = []
+    for z in range(0, 128, 32):
+        got, want_slab = _run_both(dv, oracle, v, 128, zslab=(z, z + 32), **kw)
+        _compare(got, want_slab)
+        parts.append(got)
+    _compare(np.concatenate(parts), full)
+
+
+def test_context_reuse_is_idempotent(dv, oracle):
+    v = meshes.uv_sphere(9)
+    a, want = _run_both(dv, oracle, v, 80)
+    b = dv.voxelize(80)
+    c = dv.voxelize(40)
+    d = dv.voxelize(80)
+    _compare(a, want)
+    _compare(b, a)
+    _compare(d, a)
+    _compare(c, oracle.voxelize(v, 40))
+
+
+def test_golden_fixtures(dv, oracle):
+    """Committed vectors (tests/golden/oracle_regression.npz, produced by the oracle) against the device."""
+    import os
+    from tests.golden.make_golden import CASES
+
+    class DeviceAsOracle:
+        TRI_UNTEXTURED, TRI_TEXTURED, STRATEGY_MAX, STRATEGY_BLEND = 2, 3, 0, 1
+
+        @staticmethod
+        def voxelize(verts, res, uvs=None, types=None, colors=None, texids=None, textures=(), **kw):
+            if textures:
+                dv.set_textures(list(textures))
+            dv.set_triangles(verts, uvs=uvs, types=types, colors=colors, texids=texids)
+            return dv.voxelize(res, **kw)
+
+    data = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_regression.npz"))
+    for name in CASES:
+        _compare(CASES[name](DeviceAsOracle), data[name])
+
+
+def test_full_size_properties(dv):
+    """BASELINE.json-size grids (1024^3) through size-independent properties the reference's tests define."""
+    res = 1024
+    dv.set_triangles(meshes.unit_cube())
+    vox = dv.voxelize(res)
+    assert len(vox) == 8 + 12 * (res - 2) + 6 * (res - 2) ** 2
+    xyz = vox[:, :3]
+    assert ((xyz == 0) | (xyz == res - 1)).any(axis=1).all()
+    assert len(np.unique(xyz[:, 0].astype(np.uint64) << 40 | xyz[:, 1].astype(np.uint64) << 20 | xyz[:, 2])) == len(vox)
+    dv.set_triangles(meshes.three_planes())
+    assert dv.voxelize(res, read=False) == 3 * res * res
+    # slab union == whole, determinism
+    v = meshes.uv_sphere(120)
+    dv.set_triangles(v)
+    whole = meshes.sorted_voxels(dv.voxelize(res))
+    again = meshes.sorted_voxels(dv.voxelize(res))
+    assert np.array_equal(whole, again)
+    parts = [dv.voxelize(res, zslab=(z, z + 256)) for z in range(0, res, 256)]
+    assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), whole)

@@ -102,6 +102,11 @@ int o2v_hip_get_stats(const o2v_hip_ctx *ctx, o2v_hip_stats *out);
 /* The mesh transform of the last run: row-major 3x3 then translation (reference obj2voxel.cpp:370-402). */
 int o2v_hip_get_transform(const o2v_hip_ctx *ctx, float out12[12]);
 
+/* Debugging aid for parity work: hit records of one output cell of the last run, 6 words each
+ * (keyhi = sub-voxel<<29 | triangle, keylo = leaf order key, w, u, v as float bits, pool index). */
+int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t *out, uint32_t max_records,
+                            uint32_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1476,6 +1476,41 @@ int o2v_hip_voxels_device_ptr(o2v_hip_ctx *ctx, const uint32_t **out_ptr, uint64
     return O2V_HIP_OK;
 }
 
+// Debugging aid: the hit records of one output cell of the last run (the occupied-cell list and the hit pool
+// stay valid after a run).  Each record is 6 words: keyhi, keylo, w, u, v (as float bits) and the pool index.
+int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t *out, uint32_t max_records,
+                            uint32_t *out_count)
+{
+    if (!ctx || !out || !out_count) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out_count = 0;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    std::vector<Occ> occ(ctx->n_vox);
+    std::vector<uint4> vox(ctx->n_vox);
+    if (!ctx->n_vox) return O2V_HIP_OK;
+    O2V_CHECK(hipMemcpy(occ.data(), ctx->d_occ, occ.size() * sizeof(Occ), hipMemcpyDeviceToHost));
+    O2V_CHECK(hipMemcpy(vox.data(), ctx->d_out, vox.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < ctx->n_vox; ++i) {
+        if (vox[i].x != x || vox[i].y != y || vox[i].z != z) continue;
+        uint32_t q = occ[i].head, n = 0;
+        while (q && n < max_records) {
+            HitRec r;
+            O2V_CHECK(hipMemcpy(&r, ctx->d_pool + (q - 1), sizeof(HitRec), hipMemcpyDeviceToHost));
+            uint32_t *o = out + n * 6;
+            o[0] = r.keyhi;
+            o[1] = r.keylo;
+            std::memcpy(&o[2], &r.w, 4);
+            std::memcpy(&o[3], &r.u, 4);
+            std::memcpy(&o[4], &r.v, 4);
+            o[5] = q - 1;
+            q = r.next;
+            ++n;
+        }
+        *out_count = n;
+        break;
+    }
+    return O2V_HIP_OK;
+}
+
 int o2v_hip_get_timings(const o2v_hip_ctx *ctx, o2v_hip_timings *out)
 {
     if (!ctx || !out) return O2V_HIP_ERR_BAD_ARGUMENT;

@@ -53,14 +53,10 @@ O2V_HD float comp(V3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z)
 O2V_HD float fmin2(float a, float b) { return (b < a) ? b : a; }  // std::min
 O2V_HD float fmax2(float a, float b) { return (a < b) ? b : a; }  // std::max
 
-O2V_HD float sqrt_rn(float x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return sqrtf(x);
-#endif
-}
+// Correctly rounded sqrt.  On gfx950 plain sqrtf() gets the IEEE expansion (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn() lowers to the bare approximate v_sqrt_f32 and must
+// not be used here (it changed triangle areas by 1 ulp, visible as 1-LSB BLEND colour differences).
+O2V_HD float sqrt_rn(float x) { return sqrtf(x); }
 O2V_HD float floor_f(float x) { return floorf(x); }
 O2V_HD float abs_f(float x) { return fabsf(x); }
 

@@ -55,6 +55,20 @@ typedef struct {
 
 static o2v_oracle_stats g_stats;
 
+/* optional trace of one sample-space voxel (debugging aid for parity work) */
+static int g_trace_on = 0;
+static uint32_t g_trace_pos[3];
+static uint64_t g_trace_tri = 0;
+static uint32_t g_trace_leaf = 0;
+#include <stdio.h>
+void o2v_oracle_trace_voxel(int on, uint32_t x, uint32_t y, uint32_t z)
+{
+    g_trace_on = on;
+    g_trace_pos[0] = x;
+    g_trace_pos[1] = y;
+    g_trace_pos[2] = z;
+}
+
 /* ---- voxel-io value-type operations (restated; see header for what is unpinned) ------------------------- */
 static inline v3 v3sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
 static inline v3 v3add(v3 a, v3 b) { v3 r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
@@ -427,6 +441,7 @@ static void voxelize_sub_triangle(voxelizer *vz, float input_area, const ttri *s
         if (hi[i] > cmax[i]) hi[i] = cmax[i];
     }
     g_stats.leaves++;
+    g_trace_leaf++;
     for (uint32_t z = lo[2]; z < hi[2]; ++z)
         for (uint32_t y = lo[1]; y < hi[1]; ++y)
             for (uint32_t x = lo[0]; x < hi[0]; ++x) {
@@ -446,6 +461,9 @@ static void voxelize_sub_triangle(voxelizer *vz, float input_area, const ttri *s
                     /* insertWeighted<BLEND>(uvBuffer, pos, uv), voxelization.cpp:56-63,466-468 */
                     uint32_t li = ((z - cmin[2]) * O2V_CHUNK + (y - cmin[1])) * O2V_CHUNK + (x - cmin[0]);
                     g_stats.hits++;
+                    if (g_trace_on && x == g_trace_pos[0] && y == g_trace_pos[1] && z == g_trace_pos[2])
+                        printf("oracle hit tri=%llu leafseq=%u w=%a (%.9g) u=%a v=%a area=%a\n", (unsigned long long) g_trace_tri,
+                               g_trace_leaf, uv.w, uv.w, uv.uv.x, uv.uv.y, input_area);
                     if (vz->uv_stamp[li] != vz->serial) {
                         vz->uv_stamp[li] = vz->serial;
                         vz->uvbuf[li] = uv;
@@ -529,6 +547,7 @@ static void voxelizer_voxelize(voxelizer *vz, const cached_tri *tri, const uint3
                                unsigned strategy, const o2v_oracle_texture *textures)
 {
     const float input_area = tri_area(&tri->geo); /* voxelization.cpp:416 evaluates this per piece; same value */
+    g_trace_leaf = 0;
     vz->serial++;
     vz->uv_count = 0;
 
@@ -738,8 +757,10 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                         uint32_t cmin[3] = {cx * O2V_CHUNK, cy * O2V_CHUNK, cz * O2V_CHUNK};
                         uint32_t cmax[3] = {cmin[0] + O2V_CHUNK, cmin[1] + O2V_CHUNK, cmin[2] + O2V_CHUNK};
                         vz->voxel_count = 0;
-                        for (uint64_t k = chunk_start[c]; k < chunk_start[c + 1]; ++k)
+                        for (uint64_t k = chunk_start[c]; k < chunk_start[c + 1]; ++k) {
+                            g_trace_tri = chunk_items[k];
                             voxelizer_voxelize(vz, &tris[chunk_items[k]], cmin, cmax, strategy, textures);
+                        }
 
                         if (supersampling > 1) {
                             /* documented downscale semantics (see header): 2x2x2 blocks, ascending sub order */

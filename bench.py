@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the voxelization hot path on N MI355X GPUs of one node.
+
+Metric (BASELINE.json): Mvoxels/s (output voxels / second) at a 1024^3 grid, with Mtris/s beside it.
+
+Workload at N=1: BASELINE.json configs[2] ("Stanford Dragon (~870k tris) at 1024^3, 1xMI355X"), which is the
+configuration the metric is quoted on ("at 1024^3 grid").  The asset is not in the reference tree and there is
+no network, so the stand-in is the deterministic UV sphere of SURVEY.md section 8d: nv = 467 -> 870 488
+triangles, MATERIALLESS, MAX strategy, resolution 1024.
+
+One step = one pass of the whole device pipeline (bounds -> transform -> exact subdivision -> AABB walk + clip
+-> grid scan -> ordered resolve) over triangles already resident in HBM, leaving the (x, y, z, argb) records
+in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the grid is split into N z-slabs,
+every rank voxelizes its slab from the replicated triangle list (triangles are binned to slabs on the device
+by AABB; no data-path collective is needed: SURVEY.md section 8e).  Scaling is weak: the job grows with N so
+that triangles and output voxels per GPU stay fixed (resolution 1024*sqrt(N), nv = 467*sqrt(N)).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def workload_for(n_gpus):
+    s = math.sqrt(n_gpus)
+    res = int(round(1024 * s / (2 * n_gpus))) * 2 * n_gpus  # even slabs of equal height
+    nv = int(round(467 * s))
+    return res, nv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resolution", type=int, default=0, help="override (debugging only; invalidates the metric)")
+    ap.add_argument("--nv", type=int, default=0, help="override (debugging only; invalidates the metric)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: the HIP runtime torch bundles must be the one that gets loaded
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = args.gpus
+    if world != n:
+        if world == 1 and n > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        n = world
+    dist = None
+    if n > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from obj2voxel_amd import hip, meshes
+
+    res, nv = workload_for(n)
+    if args.resolution:
+        res = args.resolution
+    if args.nv:
+        nv = args.nv
+    verts = meshes.uv_sphere(nv)
+    T = len(verts)
+    slab = res // n
+    z0, z1 = rank * slab, (rank + 1) * slab if rank < n - 1 else res
+
+    dv = hip.DeviceVoxelizer(local_rank if n > 1 else 0)
+    dv.set_triangles(verts)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return dv.voxelize(res, zslab=(z0, z1) if n > 1 else (0, 0), read=False)
+
+    for _ in range(args.warmup):
+        step()
+    stage_names = ("bounds_ms", "expand_ms", "voxelize_ms", "scan_ms", "resolve_ms", "total_ms")
+    stage_sum = {k: 0.0 for k in stage_names}
+    barrier()
+    t0 = time.perf_counter()
+    count = 0
+    for _ in range(args.steps):
+        count = step()
+        tm = dv.timings()
+        for k in stage_names:
+            stage_sum[k] += tm[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = dv.stats()
+
+    total_voxels = count
+    max_elapsed = elapsed
+    if dist is not None:
+        t = torch.tensor([float(count), elapsed], dtype=torch.float64, device="cuda")
+        cnt = t[:1].clone()
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        mx = t[1:].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        total_voxels = int(cnt.item())
+        max_elapsed = float(mx.item())
+
+    if rank == 0:
+        ms_per_step = max_elapsed / args.steps * 1e3
+        value = total_voxels / (max_elapsed / args.steps) / 1e6
+        stage_avg = {k: stage_sum[k] / args.steps for k in stage_names}
+        # dominant kernel and its algorithmic bytes per launch (DESIGN.md section "Kernels and rooflines")
+        L, tiles, H, V, cells = stats["leaves"], stats["tiles"], stats["hits"], stats["voxels"], stats["grid_cells"]
+        alg_bytes = {
+            "expand_ms": 60 * T + 96 * L + 8 * tiles,
+            "voxelize_ms": 96 * L + 8 * tiles + 28 * H,
+            "scan_ms": 4 * cells + 16 * V,
+            "resolve_ms": 12 * V + 24 * H + 16 * V,
+        }
+        kernel_of = {"expand_ms": "k_expand_roots+k_expand_nodes", "voxelize_ms": "k_voxelize", "scan_ms": "k_scan",
+                     "resolve_ms": "k_resolve"}
+        dom = max(alg_bytes, key=lambda k: stage_avg[k])
+        achieved = alg_bytes[dom] / (stage_avg[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(kernel_of[dom])
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "algorithmic_bytes": alg_bytes[dom], "kernel_ms": round(stage_avg[dom], 4)}
+        # the fixed whole-pipeline numerator of SURVEY.md section 8d: 8*G^3 + 16*V + 76*T
+        b_alg = 8 * cells + 16 * V + 76 * T
+        pipeline = {"b_alg_bytes": b_alg, "device_ms": round(stage_avg["total_ms"], 4),
+                    "gbs": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "stages_ms": {k: round(v, 4) for k, v in stage_avg.items()}}
+        out = {
+            "metric": "Mvoxels/sec at 1024^3 grid", "value": round(value, 2), "unit": "Mvoxels/s", "n_gpus": n,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mtris_per_s": round(T / (max_elapsed / args.steps) / 1e6, 2),
+            "config": {"workload": f"uv-sphere nv={nv} ({T} tris, Stanford Dragon stand-in) at {res}^3, MATERIALLESS, "
+                                   f"MAX, {n} z-slab(s)", "resolution": res, "triangles": T, "voxels": total_voxels,
+                       "parallelism": f"zslab{n}"},
+            "roofline": roofline, "pipeline": pipeline,
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(verts, res, total_voxels)
+        print(json.dumps(out), flush=True)
+    dv.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(verts, res, expect_voxels):
+    """The CPU oracle (a port of the reference algorithm, oracle/o2v_oracle.c) timed on this host's cores on the
+    same workload, chunk-parallel like the reference's worker pool. Baseline only, not the optimisation target."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    oracle.build()
+    oracle.set_threads(cores)
+    t0 = time.perf_counter()
+    vox = oracle.voxelize(verts, res)
+    dt = time.perf_counter() - t0
+    oracle.set_threads(1)
+    return {"value": round(len(vox) / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+            "sample": f"the full workload once ({len(verts)} tris at {res}^3 -> {len(vox)} voxels, {dt:.1f} s wall, "
+                      f"{cores} threads over 64^3 chunks)", "matches_gpu_voxel_count": len(vox) == expect_voxels}
+
+
+if __name__ == "__main__":
+    main()

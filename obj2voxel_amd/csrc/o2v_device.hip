@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -99,6 +100,8 @@ struct DevTexture {
 struct Counters {
     uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
     uint32_t n_vox, batch_cursor, err_flags, pad0;
+    uint32_t n_mid, n_long, n_huge, scratch_used;
+    uint32_t cursor_mid, cursor_long, cursor_huge, pad3;
     uint32_t n_nodes[kMaxRounds + 1];
     uint32_t pad1[3];
     unsigned long long n_candidates, n_hits;
@@ -179,22 +182,35 @@ __global__ void k_init(Counters *c)
 }
 
 // findMeshBounds (obj2voxel.cpp:180-200): min/max are exact and order-free, so one reduce replaces the batches.
+// The vertex array is streamed as float4 triples (12 floats = 4 vertices, so the axis of every element is static);
+// one set of six atomics per workgroup.
 __global__ __launch_bounds__(kBlock) void k_bounds(const float *__restrict__ verts, uint64_t n_floats, Counters *c)
 {
-    float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
-    float mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    // a thread always reads whole vertices: index = 3 * vertex + axis
-    uint64_t n_vert = n_floats / 3;
-    for (uint64_t vtx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; vtx < n_vert;
-         vtx += (uint64_t) gridDim.x * blockDim.x) {
-        const float *p = verts + vtx * 3;
+    __shared__ float s_red[6][kBlock / 64];
+    const float inf = __builtin_inff();
+    float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+    const uint64_t n_groups = n_floats / 12;
+    const float4 *v4 = reinterpret_cast<const float4 *>(verts);
+    for (uint64_t g = (uint64_t) blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += (uint64_t) gridDim.x * kBlock) {
+        const float4 a = v4[g * 3], b = v4[g * 3 + 1], d = v4[g * 3 + 2];
+        const float e[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float f = p[a];
-            mn[a] = fmin2(f, mn[a]);
-            mx[a] = fmax2(f, mx[a]);
+        for (int k = 0; k < 12; ++k) {
+            mn[k % 3] = fmin2(e[k], mn[k % 3]);
+            mx[k % 3] = fmax2(e[k], mx[k % 3]);
         }
     }
+    if (blockIdx.x == 0)
+        for (uint64_t i = n_groups * 12 + threadIdx.x; i < n_floats; i += kBlock) {
+            const float f = verts[i];
+            const int a = (int) (i % 3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k == a) {
+                    mn[k] = fmin2(f, mn[k]);
+                    mx[k] = fmax2(f, mx[k]);
+                }
+        }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -206,9 +222,16 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float *__restrict__ ver
     if ((threadIdx.x & 63u) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&c->bounds_enc[a], f2ord(mn[a]));
-            atomicMax(&c->bounds_enc[3 + a], f2ord(mx[a]));
+            s_red[a][threadIdx.x >> 6] = mn[a];
+            s_red[3 + a][threadIdx.x >> 6] = mx[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = s_red[threadIdx.x][0];
+        for (uint32_t w = 1; w < kBlock / 64; ++w) r = threadIdx.x < 3 ? fminf(r, s_red[threadIdx.x][w]) : fmaxf(r, s_red[threadIdx.x][w]);
+        if (threadIdx.x < 3) atomicMin(&c->bounds_enc[threadIdx.x], f2ord(r));
+        else atomicMax(&c->bounds_enc[threadIdx.x], f2ord(r));
     }
 }
 
@@ -986,69 +1009,279 @@ __device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float
     }
 }
 
-// One lane per occupied cell.  The hits of a cell arrive in arbitrary order; the reference's result is a
-// sequential fold, so the list is replayed in the reference's order by repeated minimum selection on the key
-// (sub-voxel, triangle index, leaf order):
+// ---- ordered replay of one cell's hits --------------------------------------------------------------------------
+// The hits of a cell arrive in arbitrary order; the reference's result is a sequential fold, so they are
+// replayed in the reference's order, i.e. ascending in the key (sub-voxel, triangle index, leaf order):
 //   leaves of one triangle   -> insertWeighted<BLEND>(uvBuffer, ...)  voxelization.cpp:466-468 (new, existing)
 //   triangles, ascending     -> moveUvBufferIntoVoxels                voxelization.cpp:513-526 (new, existing)
 //   sub-voxels, ascending    -> documented downscale semantics        voxelization.hpp:82-85
+struct CellFold {
+    bool have_tri = false, have_sub = false, have_cell = false;
+    uint32_t cur_group = 0;
+    WUv tri_acc{0, 0, 0};
+    WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
+
+    __device__ __forceinline__ void close_tri(const Materials &m, uint32_t blend)
+    {
+        float cr, cg, cb;
+        color_at(m, cur_group & 0x1fffffffu, tri_acc.u, tri_acc.v, cr, cg, cb);
+        const WCol fresh{tri_acc.w, cr, cg, cb};
+        sub_acc = have_sub ? wcombine(blend, fresh, sub_acc) : fresh;
+        have_sub = true;
+        have_tri = false;
+    }
+    __device__ __forceinline__ void close_sub(uint32_t blend)
+    {
+        cell_acc = have_cell ? wcombine(blend, sub_acc, cell_acc) : sub_acc;
+        have_cell = true;
+        have_sub = false;
+    }
+    // hits must be added in ascending key order
+    __device__ __forceinline__ void add(const Materials &m, uint32_t blend, uint32_t keyhi, float w, float u, float v)
+    {
+        if (have_tri && keyhi != cur_group) close_tri(m, blend);
+        if (have_sub && (keyhi >> 29) != (cur_group >> 29)) close_sub(blend);
+        const WUv hit{w, u, v};
+        tri_acc = have_tri ? wmix(hit, tri_acc) : hit;
+        have_tri = true;
+        cur_group = keyhi;
+    }
+    __device__ __forceinline__ uint32_t finish(const Materials &m, uint32_t blend)
+    {
+        if (have_tri) close_tri(m, blend);
+        if (have_sub) close_sub(blend);
+        return pack_argb(cell_acc.r, cell_acc.g, cell_acc.b);
+    }
+};
+
+__device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const Params &p)
+{
+    const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+    const uint64_t row = cell / p.Gx;
+    const uint32_t x = (uint32_t) (cell - row * p.Gx);
+    const uint32_t zrel = (uint32_t) (row / p.G);
+    const uint32_t y = (uint32_t) (row - (uint64_t) zrel * p.G);
+    return make_uint4(x, y, zrel + p.zo0, argb);
+}
+
+constexpr uint32_t kShortList = 8;     // lists up to this length are sorted in registers by k_resolve
+constexpr uint32_t kMidList = 256;     // up to this: one wavefront per cell, LDS bitonic sort
+constexpr uint32_t kLongList = 2048;   // up to this: one workgroup per cell, LDS bitonic sort; beyond: global sort
+
+struct ResolveLists {  // cells k_resolve defers, by list length class (indices into occ[])
+    uint32_t *mid, *lng, *huge;
+    uint32_t cap;
+};
+
+// Tier 1: one lane per occupied cell.  Lists of up to 8 hits (the common case) are insertion-sorted in registers
+// while they are walked; longer ones are classified and deferred to the cooperative kernels below.
 __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, const HitRec *__restrict__ pool,
-                                                    const Counters *c, Materials m, uint4 *out, Params p)
+                                                    Counters *c, Materials m, uint4 *out, ResolveLists lists, Params p)
 {
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
-        bool first = true;
-        uint64_t last = 0;
-        uint32_t cur_group = 0;
-        bool have_tri = false, have_sub = false, have_cell = false;
-        uint32_t cur_sub = 0;
-        WUv tri_acc{0, 0, 0};
-        WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
-        for (;;) {
-            uint32_t best = 0;
-            uint64_t best_key = ~0ull;
-            for (uint32_t q = o.head; q; q = pool[q - 1].next) {
-                const HitRec &r = pool[q - 1];
-                const uint64_t key = ((uint64_t) r.keyhi << 32) | r.keylo;
-                if ((first || key > last) && (best == 0 || key < best_key)) {
-                    best = q;
-                    best_key = key;
+        uint64_t key[kShortList];
+        float w[kShortList], u[kShortList], v[kShortList];
+        uint32_t cnt = 0;
+        uint32_t q = o.head;
+#pragma unroll
+        for (uint32_t k = 0; k < kShortList; ++k) {
+            if (q) {
+                const HitRec r = pool[q - 1];
+                q = r.next;
+                uint64_t rk = ((uint64_t) r.keyhi << 32) | r.keylo;
+                float rw = r.w, ru = r.u, rv = r.v;
+                // insert into the sorted prefix [0, k): bubble the new record down from slot k
+                key[k] = rk; w[k] = rw; u[k] = ru; v[k] = rv;
+#pragma unroll
+                for (uint32_t j = k; j > 0; --j) {
+                    if (key[j] < key[j - 1]) {
+                        uint64_t tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk;
+                        float t;
+                        t = w[j]; w[j] = w[j - 1]; w[j - 1] = t;
+                        t = u[j]; u[j] = u[j - 1]; u[j - 1] = t;
+                        t = v[j]; v[j] = v[j - 1]; v[j - 1] = t;
+                    }
+                }
+                cnt = k + 1;
+            }
+        }
+        if (q) {
+            // more than kShortList hits: count on (bounded) to pick the cooperative tier
+            uint32_t len = kShortList;
+            while (q && len <= kLongList) {
+                q = pool[q - 1].next;
+                ++len;
+            }
+            uint32_t *list = len <= kMidList ? lists.mid : (len <= kLongList ? lists.lng : lists.huge);
+            uint32_t *ctr = len <= kMidList ? &c->n_mid : (len <= kLongList ? &c->n_long : &c->n_huge);
+            const uint32_t slot = atomicAdd(ctr, 1u);
+            if (slot < lists.cap) list[slot] = i;
+            continue;
+        }
+        CellFold f;
+#pragma unroll
+        for (uint32_t k = 0; k < kShortList; ++k)
+            if (k < cnt) f.add(m, p.blend, (uint32_t) (key[k] >> 32), w[k], u[k], v[k]);
+        out[i] = cell_record(o, f.finish(m, p.blend), p);
+    }
+}
+
+// In-place ascending bitonic sort of (key, idx) pairs; n_pow2 >= n entries, the padding holds key = ~0.
+template <typename KeyPtr, typename IdxPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_pow2, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < n_pow2; t += nthreads) {
+                const uint32_t partner = t ^ j;
+                if (partner > t) {
+                    const bool up = (t & k) == 0;
+                    const uint64_t a = key[t], b = key[partner];
+                    if ((a > b) == up) {
+                        key[t] = b;
+                        key[partner] = a;
+                        const uint32_t ia = idx[t];
+                        idx[t] = idx[partner];
+                        idx[partner] = ia;
+                    }
                 }
             }
-            const bool done = best == 0;
-            HitRec r{};
-            if (!done) r = pool[best - 1];
-            // close the triangle group when the (sub-voxel, triangle) changes or the list ends
-            if (have_tri && (done || r.keyhi != cur_group)) {
-                float cr, cg, cb;
-                color_at(m, cur_group & 0x1fffffffu, tri_acc.u, tri_acc.v, cr, cg, cb);
-                const WCol fresh{tri_acc.w, cr, cg, cb};
-                sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
-                have_sub = true;
-                have_tri = false;
-            }
-            if (have_sub && (done || (r.keyhi >> 29) != cur_sub)) {
-                cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
-                have_cell = true;
-                have_sub = false;
-            }
-            if (done) break;
-            const WUv hit{r.w, r.u, r.v};
-            if (have_tri) tri_acc = wmix(hit, tri_acc);
-            else tri_acc = hit;
-            have_tri = true;
-            cur_group = r.keyhi;
-            cur_sub = r.keyhi >> 29;
-            last = best_key;
-            first = false;
+            __syncthreads();
         }
-        const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
-        const uint64_t row = cell / p.Gx;
-        const uint32_t x = (uint32_t) (cell - row * p.Gx);
-        const uint32_t zrel = (uint32_t) (row / p.G);
-        const uint32_t y = (uint32_t) (row - (uint64_t) zrel * p.G);
-        out[i] = make_uint4(x, y, zrel + p.zo0, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b));
+    }
+}
+
+// Tiers 2 and 3: THREADS lanes cooperate on one cell (a wavefront for lists up to 256, a workgroup up to 2048).
+// Lane 0 walks the list, everyone fetches keys, the pairs are bitonic-sorted in LDS, the payload is gathered in
+// sorted order, and lane 0 replays the fold (which is inherently sequential: float combine is not associative).
+template <uint32_t THREADS, uint32_t CAP>
+__global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                            uint32_t *cursor, const Occ *__restrict__ occ,
+                                                            const HitRec *__restrict__ pool, Materials m, uint4 *out,
+                                                            uint32_t list_cap, Params p)
+{
+    __shared__ uint64_t s_key[CAP];
+    __shared__ uint32_t s_idx[CAP];
+    __shared__ uint32_t s_hi[CAP];
+    __shared__ float s_w[CAP], s_u[CAP], s_v[CAP];
+    __shared__ uint32_t s_item, s_n;
+    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(cursor, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        if (threadIdx.x == 0) {
+            uint32_t q = o.head, n = 0;
+            while (q && n < CAP) {
+                s_idx[n++] = q - 1;
+                q = pool[q - 1].next;
+            }
+            s_n = n;
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += THREADS) {
+            if (t < n) {
+                const HitRec &r = pool[s_idx[t]];
+                s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+            }
+            else {
+                s_key[t] = ~0ull;
+                s_idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, THREADS);
+        for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+            const HitRec &r = pool[s_idx[t]];
+            s_hi[t] = r.keyhi;
+            s_w[t] = r.w;
+            s_u[t] = r.u;
+            s_v[t] = r.v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            CellFold f;
+            for (uint32_t t = 0; t < n; ++t) f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
+            out[i] = cell_record(o, f.finish(m, p.blend), p);
+        }
+    }
+}
+
+// Tier 4: lists longer than 2048 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
+// pairs in a global scratch area; each cell bump-allocates a power-of-two range (scratch holds 2 * cap_hits pairs).
+__global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restrict__ list, Counters *c,
+                                                         const Occ *__restrict__ occ, const HitRec *__restrict__ pool,
+                                                         Materials m, uint4 *out, uint64_t *scratch_key,
+                                                         uint32_t *scratch_idx, uint32_t scratch_cap, uint32_t list_cap, Params p)
+{
+    __shared__ uint32_t s_item, s_n, s_base;
+    const uint32_t total = c->n_huge < list_cap ? c->n_huge : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(&c->cursor_huge, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        if (threadIdx.x == 0) {
+            uint32_t q = o.head, n = 0;
+            while (q) {
+                q = pool[q - 1].next;
+                ++n;
+            }
+            uint32_t n_pow2 = 1;
+            while (n_pow2 < n) n_pow2 <<= 1;
+            s_n = n;
+            s_base = atomicAdd(&c->scratch_used, n_pow2);
+            if ((uint64_t) s_base + n_pow2 > scratch_cap) {
+                s_n = 0;  // scratch too small: the host sees scratch_used > capacity, grows it and re-runs
+            }
+            else {
+                uint32_t *ix = scratch_idx + s_base;
+                q = o.head;
+                for (uint32_t k = 0; k < n; ++k) {
+                    ix[k] = q - 1;
+                    q = pool[q - 1].next;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n == 0) continue;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        uint64_t *key = scratch_key + s_base;
+        uint32_t *idx = scratch_idx + s_base;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
+            if (t < n) {
+                const HitRec &r = pool[idx[t]];
+                key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+            }
+            else {
+                key[t] = ~0ull;
+                idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(key, idx, n_pow2, threadIdx.x, kBlock);
+        if (threadIdx.x == 0) {
+            CellFold f;
+            for (uint32_t t = 0; t < n; ++t) {
+                const HitRec r = pool[idx[t]];
+                f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
+            }
+            out[i] = cell_record(o, f.finish(m, p.blend), p);
+        }
     }
 }
 
@@ -1083,6 +1316,10 @@ struct o2v_hip_ctx {
     HitRec *d_pool = nullptr;
     Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
+    uint32_t *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_huge = nullptr;  // cap_vox each
+    uint64_t *d_scratch_key = nullptr;  // tier-4 resolve scratch, allocated on first need
+    uint32_t *d_scratch_idx = nullptr;
+    uint32_t cap_scratch = 0;
     uint32_t cap_leaves = 0, cap_tiles = 0, cap_big = 0, cap_nodes = 0, cap_hits = 0, cap_vox = 0;
 
     // dense grid of list heads for this context's slab
@@ -1137,6 +1374,25 @@ int upload(o2v_hip_ctx *ctx, T *&dptr, const T *host, uint64_t count)
 
 uint32_t lds_bytes_voxelize(bool uv) { return 5u * (uv ? 15u : 9u) * kBlock * (uint32_t) sizeof(float); }
 
+// O2V_DEBUG_SYNC=1: synchronise and log after every launch (locates a faulting or hanging kernel).
+bool debug_sync_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("O2V_DEBUG_SYNC");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+#define O2V_STAGE(name)                                                          \
+    do {                                                                         \
+        if (debug_sync_enabled()) {                                              \
+            std::fprintf(stderr, "[o2v] launched %s ...", name);                 \
+            std::fflush(stderr);                                                 \
+            hipError_t e_ = hipStreamSynchronize(s);                             \
+            std::fprintf(stderr, " %s\n", hipGetErrorString(e_));                \
+        }                                                                        \
+    } while (0)
+
 // One pass of the pipeline with the current capacities.  Fills h_ctr; the caller checks for overflow.
 int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
 {
@@ -1144,30 +1400,41 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
     const uint32_t persistent = (uint32_t) ctx->num_cus * 8u;
     O2V_CHECK(hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
-    if (!p.bounds_known)
-        hipLaunchKernelGGL(k_bounds, dim3(std::min<uint64_t>(persistent, (p.n_tris * 3 + kBlock - 1) / kBlock)),
+    O2V_STAGE("k_init");
+    if (!p.bounds_known) {
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
+        O2V_STAGE("k_bounds");
+    }
     hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
+    O2V_STAGE("k_setup");
     O2V_CHECK(hipEventRecord(ctx->ev[1], s));
 
     hipLaunchKernelGGL(k_expand_roots, dim3(std::min<uint64_t>(persistent, (p.n_tris + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
                        ctx->d_big, ctx->d_nodes[0], p);
-    for (uint32_t round = 0; round < kMaxRounds; ++round)
+    O2V_STAGE("k_expand_roots");
+    for (uint32_t round = 0; round < kMaxRounds; ++round) {
         hipLaunchKernelGGL(k_expand_nodes, dim3(persistent), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
+        O2V_STAGE("k_expand_nodes");
+    }
     hipLaunchKernelGGL(k_expand_big, dim3(persistent), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
+    O2V_STAGE("k_expand_big");
     O2V_CHECK(hipEventRecord(ctx->ev[2], s));
 
     {
         const uint32_t lds = lds_bytes_voxelize(use_uv);
         const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? 1u : 2u);
-        if (use_uv)
+        if (use_uv) {
             hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), lds, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
-        else
+        }
+        else {
             hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(kBlock), lds, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
+        }
+        O2V_STAGE("k_voxelize");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
 
@@ -1177,13 +1444,30 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
         const uint64_t iters = (n_quads + (uint64_t) kBlock * kScanUnroll - 1) / ((uint64_t) kBlock * kScanUnroll);
         hipLaunchKernelGGL(k_scan, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 8u, std::max<uint64_t>(iters, 1))),
                            dim3(kBlock), 0, s, ctx->d_grid, n_quads, ctx->d_ctr, ctx->d_occ, p);
+        O2V_STAGE("k_scan");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
 
     {
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
+        ResolveLists lists{ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
         hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_pool, ctx->d_ctr, m,
-                           ctx->d_out, p);
+                           ctx->d_out, lists, p);
+        O2V_STAGE("k_resolve");
+        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, s,
+                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, ctx->d_pool, m,
+                           ctx->d_out, p.cap_vox, p);
+        O2V_STAGE("k_resolve_sorted");
+        hipLaunchKernelGGL((k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s,
+                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, ctx->d_pool, m,
+                           ctx->d_out, p.cap_vox, p);
+        O2V_STAGE("k_resolve_sorted");
+        if (ctx->d_scratch_key) {
+            hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus), dim3(kBlock), 0, s, ctx->d_list_huge,
+                               ctx->d_ctr, ctx->d_occ, ctx->d_pool, m, ctx->d_out, ctx->d_scratch_key,
+                               ctx->d_scratch_idx, ctx->cap_scratch, p.cap_vox, p);
+            O2V_STAGE("k_resolve_huge");
+        }
     }
     O2V_CHECK(hipEventRecord(ctx->ev[5], s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1245,7 +1529,8 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
-                    ctx->d_pool,  ctx->d_occ,  ctx->d_out,      ctx->d_grid};
+                    ctx->d_pool,  ctx->d_occ,  ctx->d_out,      ctx->d_grid,
+                    ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
     for (uint8_t *q : ctx->d_texpix)
@@ -1382,6 +1667,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     uint64_t want_big = std::max<uint64_t>(ctx->cap_big, 1u << 16);
     uint64_t want_nodes = std::max<uint64_t>(ctx->cap_nodes, 1u << 18);
     uint64_t want_hits = std::max<uint64_t>(ctx->cap_hits, std::min<uint64_t>(16 * ctx->n_tris + (4u << 20), 1ull << 31));
+    uint64_t want_scratch = ctx->cap_scratch;
     uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
 
     ctx->grid_dirty = true;  // until a pass completes (k_scan leaves it clean)
@@ -1398,7 +1684,17 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
+        for (uint32_t **lp : {&ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_huge}) {
+            uint32_t cap_l = ctx->cap_vox;
+            if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;
+        }
         ctx->cap_vox = cap_v0;
+        if (want_scratch) {
+            uint32_t cap_s0 = ctx->cap_scratch, cap_s1 = ctx->cap_scratch;
+            if ((rc = grow(ctx, ctx->d_scratch_key, cap_s0, want_scratch))) return rc;
+            if ((rc = grow(ctx, ctx->d_scratch_idx, cap_s1, want_scratch))) return rc;
+            ctx->cap_scratch = cap_s0;
+        }
         p.cap_leaves = ctx->cap_leaves;
         p.cap_tiles = ctx->cap_tiles;
         p.cap_big = ctx->cap_big;
@@ -1430,6 +1726,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(max_nodes, ctx->cap_nodes, want_nodes);
         need(h.n_hits_reserved, ctx->cap_hits, want_hits);
         need(h.n_vox, ctx->cap_vox, want_vox);
+        if (!again && h.n_huge && (!ctx->d_scratch_key || h.scratch_used > ctx->cap_scratch)) {
+            // some cell holds more than kLongList hits: the global-memory sort tier needs its scratch area
+            want_scratch = std::max<uint64_t>(2ull * ctx->cap_hits, (uint64_t) h.scratch_used + 1024);
+            again = true;
+        }
         if (!again) {
             ctx->grid_dirty = false;
             ctx->n_vox = h.n_vox;

@@ -53,13 +53,18 @@ typedef struct {
     uint64_t candidates, culled, clips, hits, pieces, splits, leaves;
 } o2v_oracle_stats;
 
-static o2v_oracle_stats g_stats;
+static o2v_oracle_stats g_stats;              /* totals of the last run */
+static _Thread_local o2v_oracle_stats t_stats;  /* per worker thread, merged at the end of a run */
+static int g_threads = 1;
+/* Chunk-parallel execution like the reference's worker pool (one VOXELIZE_CHUNK command per chunk,
+ * obj2voxel.cpp:415-424,979): results do not depend on the thread count because chunks are independent. */
+void o2v_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 
 /* optional trace of one sample-space voxel (debugging aid for parity work) */
 static int g_trace_on = 0;
 static uint32_t g_trace_pos[3];
-static uint64_t g_trace_tri = 0;
-static uint32_t g_trace_leaf = 0;
+static _Thread_local uint64_t g_trace_tri = 0;
+static _Thread_local uint32_t g_trace_leaf = 0;
 #include <stdio.h>
 void o2v_oracle_trace_voxel(int on, uint32_t x, uint32_t y, uint32_t z)
 {
@@ -251,7 +256,7 @@ static void split_triangle(unsigned axis, uint32_t plane, const ttri *t, splitbu
     int lo[3], planar[3];
     unsigned lo_sum = 0, planar_sum = 0;
     const float fplane = (float) plane;
-    g_stats.splits++;
+    t_stats.splits++;
     for (unsigned i = 0; i < 3; ++i) {
         const float c = comp(t->v[i], axis);
         planar[i] = is_zero(c - fplane);
@@ -353,7 +358,7 @@ static wuv triangles_uv_in_voxel(float input_area, const ttri *sub, const uint32
     pre->n = 0;
     post->n = 0;
     pre->d[pre->n++] = *sub;
-    g_stats.clips++;
+    t_stats.clips++;
     for (unsigned hi = 0; hi < 2; ++hi) {
         for (unsigned axis = 0; axis < 3; ++axis) {
             uint32_t plane = pos[axis] + hi;
@@ -374,7 +379,7 @@ static wuv triangles_uv_in_voxel(float input_area, const ttri *sub, const uint32
         piece.uv.y = ((t->t[0].y + t->t[1].y) + t->t[2].y) / 3;
         result = wuv_mix(result, piece);
     }
-    g_stats.pieces += pre->n;
+    t_stats.pieces += pre->n;
     return result;
 }
 
@@ -440,19 +445,19 @@ static void voxelize_sub_triangle(voxelizer *vz, float input_area, const ttri *s
         if (lo[i] < cmin[i]) lo[i] = cmin[i];
         if (hi[i] > cmax[i]) hi[i] = cmax[i];
     }
-    g_stats.leaves++;
+    t_stats.leaves++;
     g_trace_leaf++;
     for (uint32_t z = lo[2]; z < hi[2]; ++z)
         for (uint32_t y = lo[1]; y < hi[1]; ++y)
             for (uint32_t x = lo[0]; x < hi[0]; ++x) {
                 uint32_t pos[3] = {x, y, z};
-                g_stats.candidates++;
+                t_stats.candidates++;
                 {
                     /* ENABLE_PLANE_DISTANCE_TEST, voxelization.cpp:451-458 */
                     v3 center = {(float) x + 0.5f, (float) y + 0.5f, (float) z + 0.5f};
                     float sd = v3dot(nrm, v3sub(center, org));
                     if (fabsf(sd) > distance_limit) {
-                        g_stats.culled++;
+                        t_stats.culled++;
                         continue;
                     }
                 }
@@ -460,7 +465,7 @@ static void voxelize_sub_triangle(voxelizer *vz, float input_area, const ttri *s
                 if (uv.w != 0.f) {
                     /* insertWeighted<BLEND>(uvBuffer, pos, uv), voxelization.cpp:56-63,466-468 */
                     uint32_t li = ((z - cmin[2]) * O2V_CHUNK + (y - cmin[1])) * O2V_CHUNK + (x - cmin[0]);
-                    g_stats.hits++;
+                    t_stats.hits++;
                     if (g_trace_on && x == g_trace_pos[0] && y == g_trace_pos[1] && z == g_trace_pos[2])
                         printf("oracle hit tri=%llu leafseq=%u w=%a (%.9g) u=%a v=%a area=%a\n", (unsigned long long) g_trace_tri,
                                g_trace_leaf, uv.w, uv.w, uv.uv.x, uv.uv.y, input_area);
@@ -622,6 +627,59 @@ static void out_push(outvec *o, uint32_t x, uint32_t y, uint32_t z, uint32_t arg
     o->n++;
 }
 
+/* voxelizeChunk, obj2voxel.cpp:254-314: all triangles of one 64^3 chunk, optional downscale, pack */
+static void voxelize_chunk(voxelizer *vz, outvec *ov, const cached_tri *tris, const uint32_t *chunk_items, uint64_t k0,
+                           uint64_t k1, uint32_t cx, uint32_t cy, uint32_t cz, unsigned strategy, uint32_t supersampling,
+                           const o2v_oracle_texture *textures, uint32_t zlo, uint32_t zhi)
+{
+    uint32_t cmin[3] = {cx * O2V_CHUNK, cy * O2V_CHUNK, cz * O2V_CHUNK};
+    uint32_t cmax[3] = {cmin[0] + O2V_CHUNK, cmin[1] + O2V_CHUNK, cmin[2] + O2V_CHUNK};
+    vz->voxel_count = 0;
+    for (uint64_t k = k0; k < k1; ++k) {
+        g_trace_tri = chunk_items[k];
+        voxelizer_voxelize(vz, &tris[chunk_items[k]], cmin, cmax, strategy, textures);
+    }
+
+    if (supersampling > 1) {
+        /* documented downscale semantics (see header): 2x2x2 blocks, ascending sub order */
+        for (uint32_t bz = 0; bz < O2V_CHUNK; bz += 2)
+            for (uint32_t by = 0; by < O2V_CHUNK; by += 2)
+                for (uint32_t bx = 0; bx < O2V_CHUNK; bx += 2) {
+                    int have = 0;
+                    wcol acc;
+                    for (unsigned s = 0; s < 8; ++s) {
+                        uint32_t lx = bx + (s & 1u), ly = by + ((s >> 1) & 1u), lz = bz + (s >> 2);
+                        uint32_t li = (lz * O2V_CHUNK + ly) * O2V_CHUNK + lx;
+                        if (!vz->has_voxel[li]) continue;
+                        if (!have) {
+                            acc = vz->voxels[li];
+                            have = 1;
+                        }
+                        else {
+                            acc = wcol_combine(strategy, vz->voxels[li], acc);
+                        }
+                    }
+                    if (have) {
+                        uint32_t ox = (cmin[0] + bx) / 2, oy = (cmin[1] + by) / 2,
+                                 oz = (cmin[2] + bz) / 2;
+                        if (zlo == zhi || (oz >= zlo && oz < zhi))
+                            out_push(ov, ox, oy, oz, pack_argb(acc.c));
+                    }
+                }
+    }
+    else {
+        for (uint32_t k = 0; k < vz->voxel_count; ++k) {
+            uint32_t li = vz->voxel_list[k];
+            uint32_t lx = li % O2V_CHUNK, ly = (li / O2V_CHUNK) % O2V_CHUNK,
+                     lz = li / (O2V_CHUNK * O2V_CHUNK);
+            uint32_t oz = cmin[2] + lz;
+            if (zlo == zhi || (oz >= zlo && oz < zhi))
+                out_push(ov, cmin[0] + lx, cmin[1] + ly, oz, pack_argb(vz->voxels[li].c));
+        }
+    }
+    for (uint32_t k = 0; k < vz->voxel_count; ++k) vz->has_voxel[vz->voxel_list[k]] = 0;
+}
+
 /*
  * The whole path: cache -> bounds -> transform -> chunk binning -> per chunk voxelize (+downscale) -> pack.
  * obj2voxel.cpp:467-520 (voxelize_specialized<false>), :180-314.
@@ -748,60 +806,35 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
         }
         if (pass == 1) {
             /* voxelizeChunk for every chunk, obj2voxel.cpp:254-314,503-505 */
-            voxelizer *vz = voxelizer_new();
-            for (uint32_t cz = 0; cz < chunks_per_axis; ++cz)
-                for (uint32_t cy = 0; cy < chunks_per_axis; ++cy)
-                    for (uint32_t cx = 0; cx < chunks_per_axis; ++cx) {
-                        size_t c = ((size_t) cz * chunks_per_axis + cy) * chunks_per_axis + cx;
-                        if (chunk_start[c] == chunk_start[c + 1]) continue;
-                        uint32_t cmin[3] = {cx * O2V_CHUNK, cy * O2V_CHUNK, cz * O2V_CHUNK};
-                        uint32_t cmax[3] = {cmin[0] + O2V_CHUNK, cmin[1] + O2V_CHUNK, cmin[2] + O2V_CHUNK};
-                        vz->voxel_count = 0;
-                        for (uint64_t k = chunk_start[c]; k < chunk_start[c + 1]; ++k) {
-                            g_trace_tri = chunk_items[k];
-                            voxelizer_voxelize(vz, &tris[chunk_items[k]], cmin, cmax, strategy, textures);
-                        }
-
-                        if (supersampling > 1) {
-                            /* documented downscale semantics (see header): 2x2x2 blocks, ascending sub order */
-                            for (uint32_t bz = 0; bz < O2V_CHUNK; bz += 2)
-                                for (uint32_t by = 0; by < O2V_CHUNK; by += 2)
-                                    for (uint32_t bx = 0; bx < O2V_CHUNK; bx += 2) {
-                                        int have = 0;
-                                        wcol acc;
-                                        for (unsigned s = 0; s < 8; ++s) {
-                                            uint32_t lx = bx + (s & 1u), ly = by + ((s >> 1) & 1u), lz = bz + (s >> 2);
-                                            uint32_t li = (lz * O2V_CHUNK + ly) * O2V_CHUNK + lx;
-                                            if (!vz->has_voxel[li]) continue;
-                                            if (!have) {
-                                                acc = vz->voxels[li];
-                                                have = 1;
-                                            }
-                                            else {
-                                                acc = wcol_combine(strategy, vz->voxels[li], acc);
-                                            }
-                                        }
-                                        if (have) {
-                                            uint32_t ox = (cmin[0] + bx) / 2, oy = (cmin[1] + by) / 2,
-                                                     oz = (cmin[2] + bz) / 2;
-                                            if (zlo == zhi || (oz >= zlo && oz < zhi))
-                                                out_push(&ov, ox, oy, oz, pack_argb(acc.c));
-                                        }
-                                    }
-                        }
-                        else {
-                            for (uint32_t k = 0; k < vz->voxel_count; ++k) {
-                                uint32_t li = vz->voxel_list[k];
-                                uint32_t lx = li % O2V_CHUNK, ly = (li / O2V_CHUNK) % O2V_CHUNK,
-                                         lz = li / (O2V_CHUNK * O2V_CHUNK);
-                                uint32_t oz = cmin[2] + lz;
-                                if (zlo == zhi || (oz >= zlo && oz < zhi))
-                                    out_push(&ov, cmin[0] + lx, cmin[1] + ly, oz, pack_argb(vz->voxels[li].c));
-                            }
-                        }
-                        for (uint32_t k = 0; k < vz->voxel_count; ++k) vz->has_voxel[vz->voxel_list[k]] = 0;
-                    }
-            voxelizer_free(vz);
+            size_t n_work = 0;
+            size_t *work = (size_t *) malloc(sizeof(size_t) * (nchunks ? nchunks : 1));
+            for (size_t c = 0; c < nchunks; ++c)
+                if (chunk_start[c] != chunk_start[c + 1]) work[n_work++] = c;
+#pragma omp parallel num_threads(g_threads)
+            {
+                voxelizer *vz = voxelizer_new();
+                outvec lov = {0, 0, 0};
+                memset(&t_stats, 0, sizeof(t_stats));
+#pragma omp for schedule(dynamic, 1)
+                for (long wi = 0; wi < (long) n_work; ++wi) {
+                    const size_t c = work[wi];
+                    const uint32_t cx = (uint32_t) (c % chunks_per_axis), cy = (uint32_t) ((c / chunks_per_axis) % chunks_per_axis),
+                                   cz = (uint32_t) (c / ((size_t) chunks_per_axis * chunks_per_axis));
+                    voxelize_chunk(vz, &lov, tris, chunk_items, chunk_start[c], chunk_start[c + 1], cx, cy, cz, strategy,
+                                   supersampling, textures, zlo, zhi);
+                }
+#pragma omp critical
+                {
+                    for (size_t k = 0; k < lov.n; ++k)
+                        out_push(&ov, lov.d[k * 4], lov.d[k * 4 + 1], lov.d[k * 4 + 2], lov.d[k * 4 + 3]);
+                    uint64_t *dst = (uint64_t *) &g_stats;
+                    const uint64_t *src = (const uint64_t *) &t_stats;
+                    for (size_t k = 0; k < sizeof(g_stats) / sizeof(uint64_t); ++k) dst[k] += src[k];
+                }
+                free(lov.d);
+                voxelizer_free(vz);
+            }
+            free(work);
             free(chunk_items);
             free(fill);
         }

@@ -48,6 +48,7 @@ def lib():
         _lib.o2v_oracle_free.argtypes = [C.POINTER(C.c_uint32)]
         _lib.o2v_oracle_mesh_transform.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.o2v_oracle_get_stats.argtypes = [C.POINTER(_Stats)]
+        _lib.o2v_oracle_set_threads.argtypes = [C.c_int]
     return _lib
 
 
@@ -85,6 +86,11 @@ def voxelize(verts, resolution, *, uvs=None, types=None, colors=None, texids=Non
     res = np.ctypeslib.as_array(out, shape=(n, 4)).copy()
     lib().o2v_oracle_free(out)
     return res
+
+
+def set_threads(n):
+    """Chunk-parallel worker threads (default 1). Results are independent of the thread count."""
+    lib().o2v_oracle_set_threads(int(n))
 
 
 def stats():

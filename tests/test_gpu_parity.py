@@ -213,3 +213,16 @@ def test_full_size_properties(dv):
     assert np.array_equal(whole, again)
     parts = [dv.voxelize(res, zslab=(z, z + 256)) for z in range(0, res, 256)]
     assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), whole)
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_long_hit_lists(dv, oracle, strategy):
+    """Many triangles per voxel: exercises the cooperative resolve tiers (wavefront and workgroup LDS sorts and
+    the global-memory sort for lists longer than 2048 hits)."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(60)          # 14160 triangles
+    T = len(v)
+    kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=strategy)
+    for res in (24, 6, 2):            # up to thousands of hits per voxel at the coarse end
+        got, want = _run_both(dv, oracle, v, res, **kw)
+        _compare(got, want)

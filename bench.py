@@ -62,7 +62,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from obj2voxel_amd import hip, meshes
+    from obj2voxel_amd import hip, meshes, slab as slabs
 
     res, nv = workload_for(n)
     if args.resolution:
@@ -71,8 +71,7 @@ def main():
         nv = args.nv
     verts = meshes.uv_sphere(nv)
     T = len(verts)
-    slab = res // n
-    z0, z1 = rank * slab, (rank + 1) * slab if rank < n - 1 else res
+    z0, z1 = slabs.slab_range(rank, n, res)
 
     dv = hip.DeviceVoxelizer(local_rank if n > 1 else 0)
     dv.set_triangles(verts)
@@ -101,16 +100,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = dv.stats()
 
-    total_voxels = count
-    max_elapsed = elapsed
-    if dist is not None:
-        t = torch.tensor([float(count), elapsed], dtype=torch.float64, device="cuda")
-        cnt = t[:1].clone()
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        mx = t[1:].clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        total_voxels = int(cnt.item())
-        max_elapsed = float(mx.item())
+    total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed, device="cuda" if dist is not None else None)
 
     if rank == 0:
         ms_per_step = max_elapsed / args.steps * 1e3

@@ -41,7 +41,7 @@ namespace {
 // ---- device-side records ----------------------------------------------------------------------------------
 
 constexpr uint32_t kTileSize = 256;       // candidate voxels per work tile
-constexpr uint32_t kTilesPerBatch = 32;   // tiles a workgroup stages at once (<= 8192 candidates)
+constexpr uint32_t kTilesPerBatch = 64;   // tiles a workgroup stages at once
 constexpr uint32_t kBlock = 256;          // threads per workgroup (4 wavefronts)
 constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key holds 15 levels)
 constexpr uint32_t kHitChunk = 256;       // hit-pool slots a wavefront reserves per global atomic
@@ -597,41 +597,49 @@ struct Piece {  // TexturedTriangle (triangle.hpp:113-144); the uv members are d
 __device__ __forceinline__ V3 sel3(uint32_t r, V3 x0, V3 x1, V3 x2) { return r == 0 ? x0 : (r == 1 ? x1 : x2); }
 __device__ __forceinline__ V2 sel2(uint32_t r, V2 x0, V2 x1, V2 x2) { return r == 0 ? x0 : (r == 1 ? x1 : x2); }
 
-// splitTriangle<DISCARD_LO|DISCARD_HI> (voxelization.cpp:175-331) for one piece.  keep_lo selects DISCARD_HI.
-// Returns the number of kept pieces (0, 1 or 2): `cur` becomes the first kept piece in emission order, `sec` the
-// second.  Vertex order inside emitted pieces is the reference's, because later splits depend on it.
-template <bool UV>
-__device__ __forceinline__ uint32_t split_keep(Piece<UV> &cur, Piece<UV> &sec, uint32_t axis, float plane, bool keep_lo)
+// Classification of one piece against one axis plane: SplittingValues + the case switch of splitTriangle
+// (voxelization.cpp:110-153,190-232).  Packed so that it can be carried in one register between the cheap
+// classification pass and the expensive split pass of the clip loop.
+enum : uint32_t {
+    kClsModeMask = 3u,   // 0: whole triangle goes to one side, 1: one-planar split, 2: regular split
+    kClsSideLo = 4u,     // mode 0: the side is "lo"
+    kClsRotShift = 3u,   // bits 3..4: rotation index r (planar vertex for mode 1, isolated vertex for mode 2)
+    kClsFlagLo = 32u,    // mode 1: lo flag of vertex r+1;  mode 2: the isolated vertex is lo
+};
+
+__device__ __forceinline__ uint32_t classify_piece(float c0, float c1, float c2, float plane)
 {
-    const float c0 = comp(cur.a, axis), c1 = comp(cur.b, axis), c2 = comp(cur.c, axis);
     // SplittingValues, voxelization.cpp:121-131
     const bool p0 = abs_f(c0 - plane) < kEpsilon, p1 = abs_f(c1 - plane) < kEpsilon, p2 = abs_f(c2 - plane) < kEpsilon;
     const bool l0 = c0 < plane, l1 = c1 < plane, l2 = c2 < plane;
     const uint32_t lo_sum = (uint32_t) l0 + (uint32_t) l1 + (uint32_t) l2;
     const uint32_t pl_sum = (uint32_t) p0 + (uint32_t) p1 + (uint32_t) p2;
-
-    uint32_t mode = 0;  // 0: triangle passes whole to one side, 1: one-planar split, 2: regular split
-    bool side_lo = false;
-    uint32_t r = 0;
-    bool iso_lo = false;
-    if (lo_sum == 0) side_lo = false;
-    else if (lo_sum == 3) side_lo = true;
-    else if (pl_sum == 3) side_lo = false;  // parallel to the plane: pushed by bias (IS_LO_BIASED = false)
-    else if (pl_sum == 2) side_lo = !p0 ? l0 : (!p1 ? l1 : l2);
-    else if (pl_sum == 1) {
-        r = p0 ? 0u : (p1 ? 1u : 2u);
+    if (lo_sum == 0) return 0u;
+    if (lo_sum == 3) return kClsSideLo;
+    if (pl_sum == 3) return 0u;  // parallel to the plane: pushed by bias (IS_LO_BIASED = false) = hi
+    if (pl_sum == 2) return (!p0 ? l0 : (!p1 ? l1 : l2)) ? kClsSideLo : 0u;
+    if (pl_sum == 1) {
+        const uint32_t r = p0 ? 0u : (p1 ? 1u : 2u);
         const bool lq = r == 0 ? l1 : (r == 1 ? l2 : l0);
         const bool lr = r == 0 ? l2 : (r == 1 ? l0 : l1);
-        if (lq == lr) side_lo = lq;
-        else mode = 1;
+        if (lq == lr) return lq ? kClsSideLo : 0u;
+        return 1u | (r << kClsRotShift) | (lq ? kClsFlagLo : 0u);
     }
-    else {
-        iso_lo = lo_sum == 1;
-        r = iso_lo ? (l0 ? 0u : (l1 ? 1u : 2u)) : (!l0 ? 0u : (!l1 ? 1u : 2u));
-        mode = 2;
-    }
-    if (mode == 0) return side_lo == keep_lo ? 1u : 0u;
+    const bool iso_lo = lo_sum == 1;
+    const uint32_t r = iso_lo ? (l0 ? 0u : (l1 ? 1u : 2u)) : (!l0 ? 0u : (!l1 ? 1u : 2u));
+    return 2u | (r << kClsRotShift) | (iso_lo ? kClsFlagLo : 0u);
+}
 
+// The geometric part of splitTriangle<DISCARD_LO|DISCARD_HI> for a piece whose classification says it is cut
+// (modes 1 and 2).  keep_lo selects DISCARD_HI.  Returns the number of kept pieces (1 or 2): `cur` becomes the
+// first kept piece in emission order, `sec` the second.  Vertex order inside emitted pieces is the reference's,
+// because later splits depend on it.
+template <bool UV>
+__device__ __forceinline__ uint32_t split_cut(Piece<UV> &cur, Piece<UV> &sec, uint32_t cls, uint32_t axis, float plane,
+                                              bool keep_lo)
+{
+    const uint32_t r = (cls >> kClsRotShift) & 3u;
+    const bool flag_lo = (cls & kClsFlagLo) != 0;
     const V3 P = sel3(r, cur.a, cur.b, cur.c), Q = sel3(r, cur.b, cur.c, cur.a), R = sel3(r, cur.c, cur.a, cur.b);
     V2 tP{}, tQ{}, tR{};
     if (UV) {
@@ -639,39 +647,35 @@ __device__ __forceinline__ uint32_t split_keep(Piece<UV> &cur, Piece<UV> &sec, u
         tQ = sel2(r, cur.tb, cur.tc, cur.ta);
         tR = sel2(r, cur.tc, cur.ta, cur.tb);
     }
-    const float cP = r == 0 ? c0 : (r == 1 ? c1 : c2);
-    const float cQ = r == 0 ? c1 : (r == 1 ? c2 : c0);
-    const float cR = r == 0 ? c2 : (r == 1 ? c0 : c1);
-
-    if (mode == 1) {
-        // splitTriangle_onePlanarCase, voxelization.cpp:255-276: P planar, split edge Q->R
-        const bool lq = r == 0 ? l1 : (r == 1 ? l2 : l0);
-        const float d = -(cR - cQ);
-        const float t = abs_f(d) < kEpsilon ? 0.f : (cQ - plane) / d;
-        const V3 G = mix(Q, R, t);
-        V2 tG{};
-        if (UV) tG = mix(tQ, tR, t);
-        if (lq == keep_lo) {
-            cur.a = P; cur.b = Q; cur.c = G;
-            if (UV) { cur.ta = tP; cur.tb = tQ; cur.tc = tG; }
+    const float cP = comp(P, axis), cQ = comp(Q, axis), cR = comp(R, axis);
+    const bool regular = (cls & kClsModeMask) == 2u;
+    // first intersection: regular case P->Q (voxelization.cpp:305-311), one-planar case Q->R (:262-266)
+    const V3 A0 = regular ? P : Q, A1 = regular ? Q : R;
+    const float cA0 = regular ? cP : cQ, cA1 = regular ? cQ : cR;
+    const float d0 = -(cA1 - cA0);
+    const float i0 = abs_f(d0) < kEpsilon ? 0.f : (cA0 - plane) / d0;
+    const V3 G0 = mix(A0, A1, i0);
+    V2 x0{};
+    if (UV) x0 = mix(regular ? tP : tQ, regular ? tQ : tR, i0);
+    if (!regular) {
+        // splitTriangle_onePlanarCase: {P,Q,G} goes to Q's side, {P,G,R} to the other
+        if (flag_lo == keep_lo) {
+            cur.a = P; cur.b = Q; cur.c = G0;
+            if (UV) { cur.ta = tP; cur.tb = tQ; cur.tc = x0; }
         }
         else {
-            cur.a = P; cur.b = G; cur.c = R;
-            if (UV) { cur.ta = tP; cur.tb = tG; cur.tc = tR; }
+            cur.a = P; cur.b = G0; cur.c = R;
+            if (UV) { cur.ta = tP; cur.tb = x0; cur.tc = tR; }
         }
         return 1;
     }
-    // splitTriangle_regularCase, voxelization.cpp:279-331: P isolated
-    const float d0 = -(cQ - cP), d1 = -(cR - cP);
-    const float i0 = abs_f(d0) < kEpsilon ? 0.f : (cP - plane) / d0;
+    // splitTriangle_regularCase, voxelization.cpp:279-331: P isolated, second intersection P->R
+    const float d1 = -(cR - cP);
     const float i1 = abs_f(d1) < kEpsilon ? 0.f : (cP - plane) / d1;
-    const V3 G0 = mix(P, Q, i0), G1 = mix(P, R, i1);
-    V2 x0{}, x1{};
-    if (UV) {
-        x0 = mix(tP, tQ, i0);
-        x1 = mix(tP, tR, i1);
-    }
-    if (iso_lo == keep_lo) {
+    const V3 G1 = mix(P, R, i1);
+    V2 x1{};
+    if (UV) x1 = mix(tP, tR, i1);
+    if (flag_lo == keep_lo) {
         cur.a = P; cur.b = G0; cur.c = G1;
         if (UV) { cur.ta = tP; cur.tb = x0; cur.tc = x1; }
         return 1;
@@ -699,104 +703,115 @@ __device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area
     w = ws;
 }
 
+// Pending sibling pieces of the depth-first clip walk, one slot per level 1..5, held in registers: every access
+// uses a compile-time slot index (selected by a switch), so the array never leaves the VGPR file.
 template <bool UV>
-__device__ __forceinline__ void stack_store(float *s_stk, uint32_t slot, const Piece<UV> &pc)
+struct PieceStack {
+    Piece<UV> s0, s1, s2, s3, s4;
+};
+
+// Value-level selects (v_cndmask), not control flow: a branchy form gets folded by the compiler into a select of
+// addresses, which forces the stack into scratch memory.
+template <bool UV>
+__device__ __forceinline__ Piece<UV> sel_piece(bool take_x, const Piece<UV> &x, const Piece<UV> &y)
 {
-    constexpr uint32_t NC = UV ? 15 : 9;
-    float *b = s_stk + (size_t) slot * NC * kBlock + threadIdx.x;
-    b[0 * kBlock] = pc.a.x; b[1 * kBlock] = pc.a.y; b[2 * kBlock] = pc.a.z;
-    b[3 * kBlock] = pc.b.x; b[4 * kBlock] = pc.b.y; b[5 * kBlock] = pc.b.z;
-    b[6 * kBlock] = pc.c.x; b[7 * kBlock] = pc.c.y; b[8 * kBlock] = pc.c.z;
+    Piece<UV> r;
+    r.a = {take_x ? x.a.x : y.a.x, take_x ? x.a.y : y.a.y, take_x ? x.a.z : y.a.z};
+    r.b = {take_x ? x.b.x : y.b.x, take_x ? x.b.y : y.b.y, take_x ? x.b.z : y.b.z};
+    r.c = {take_x ? x.c.x : y.c.x, take_x ? x.c.y : y.c.y, take_x ? x.c.z : y.c.z};
     if (UV) {
-        b[9 * kBlock] = pc.ta.x; b[10 * kBlock] = pc.ta.y; b[11 * kBlock] = pc.tb.x;
-        b[12 * kBlock] = pc.tb.y; b[13 * kBlock] = pc.tc.x; b[14 * kBlock] = pc.tc.y;
+        r.ta = {take_x ? x.ta.x : y.ta.x, take_x ? x.ta.y : y.ta.y};
+        r.tb = {take_x ? x.tb.x : y.tb.x, take_x ? x.tb.y : y.tb.y};
+        r.tc = {take_x ? x.tc.x : y.tc.x, take_x ? x.tc.y : y.tc.y};
     }
+    return r;
 }
 template <bool UV>
-__device__ __forceinline__ void stack_load(const float *s_stk, uint32_t slot, Piece<UV> &pc)
+__device__ __forceinline__ void stack_store(PieceStack<UV> &st, uint32_t slot, const Piece<UV> &pc)
 {
-    constexpr uint32_t NC = UV ? 15 : 9;
-    const float *b = s_stk + (size_t) slot * NC * kBlock + threadIdx.x;
-    pc.a = {b[0 * kBlock], b[1 * kBlock], b[2 * kBlock]};
-    pc.b = {b[3 * kBlock], b[4 * kBlock], b[5 * kBlock]};
-    pc.c = {b[6 * kBlock], b[7 * kBlock], b[8 * kBlock]};
-    if (UV) {
-        pc.ta = {b[9 * kBlock], b[10 * kBlock]};
-        pc.tb = {b[11 * kBlock], b[12 * kBlock]};
-        pc.tc = {b[13 * kBlock], b[14 * kBlock]};
-    }
+    st.s0 = sel_piece<UV>(slot == 0, pc, st.s0);
+    st.s1 = sel_piece<UV>(slot == 1, pc, st.s1);
+    st.s2 = sel_piece<UV>(slot == 2, pc, st.s2);
+    st.s3 = sel_piece<UV>(slot == 3, pc, st.s3);
+    st.s4 = sel_piece<UV>(slot == 4, pc, st.s4);
+}
+template <bool UV>
+__device__ __forceinline__ void stack_load(const PieceStack<UV> &st, uint32_t slot, Piece<UV> &pc)
+{
+    Piece<UV> r = st.s4;
+    r = sel_piece<UV>(slot == 3, st.s3, r);
+    r = sel_piece<UV>(slot == 2, st.s2, r);
+    r = sel_piece<UV>(slot == 1, st.s1, r);
+    r = sel_piece<UV>(slot == 0, st.s0, r);
+    pc = r;
 }
 
-// computeTrianglesUvInVoxel (voxelization.cpp:383-424) for one (leaf, voxel) pair.  The reference clips level
-// by level with two 64-entry buffers; here the same split tree is walked depth first (first emitted piece
-// first), which visits the surviving pieces in the reference's buffer order, so the running mean of
-// voxelization.cpp:414-420 accumulates in the identical sequence.  Under DISCARD every split keeps at most
-// two pieces, so at most one sibling per level 1..5 is pending: five LDS slots per lane.
-template <bool UV>
-__device__ __forceinline__ void clip_voxel(const Leaf &lf, uint32_t px, uint32_t py, uint32_t pz, float *s_stk,
-                                           float &w, float &u, float &v)
+// Conservative triangle / voxel overlap test (separating axes: the triangle's plane and the nine edge x axis
+// directions; the three box axes are implied by the AABB walk).  The box is inflated by kSatMargin, far more than
+// the float32 rounding of the clip (<= a few ulp of the coordinate, 5e-4 at 4096) and than its planarity epsilon
+// (2^-16), so every voxel the exact clip can mark is kept: this only removes work, never results.  All
+// comparisons are written so that a NaN (degenerate triangle) rejects nothing.
+constexpr float kSatMargin = 0.02f;
+
+__device__ __forceinline__ bool sat_axis_separates(float p0, float p1, float rad)
 {
-    Piece<UV> cur, sec;
-    cur.a = {lf.v[0], lf.v[1], lf.v[2]};
-    cur.b = {lf.v[3], lf.v[4], lf.v[5]};
-    cur.c = {lf.v[6], lf.v[7], lf.v[8]};
-    if (UV) {
-        cur.ta = {lf.t[0], lf.t[1]};
-        cur.tb = {lf.t[2], lf.t[3]};
-        cur.tc = {lf.t[4], lf.t[5]};
-    }
-    const float area = lf.area;
-    uint32_t level = 0, pending = 0;
-    bool active = true;
-    w = 0.f;
-    u = 0.f;
-    v = 0.f;
-    for (;;) {
-        if (!active) {
-            if (!pending) break;
-            level = 31u - (uint32_t) __clz((int) pending);
-            pending ^= 1u << level;
-            stack_load<UV>(s_stk, level - 1u, cur);
-        }
-        const bool keep_lo = level >= 3u;
-        const uint32_t axis = keep_lo ? level - 3u : level;
-        const uint32_t pa = axis == 0 ? px : (axis == 1 ? py : pz);
-        const float plane = (float) (pa + (keep_lo ? 1u : 0u));
-        const uint32_t n = split_keep<UV>(cur, sec, axis, plane, keep_lo);
-        active = n != 0;
-        if (n) {
-            if (level == 5u) {
-                accumulate_piece<UV>(cur, area, w, u, v);
-                if (n == 2) accumulate_piece<UV>(sec, area, w, u, v);
-                active = false;
-            }
-            else {
-                if (n == 2) {
-                    stack_store<UV>(s_stk, level, sec);  // slot of level+1
-                    pending |= 1u << (level + 1u);
-                }
-                level += 1u;
-            }
-        }
-    }
+    const float lo = p0 < p1 ? p0 : p1, hi = p0 < p1 ? p1 : p0;
+    return lo > rad || hi < -rad;
 }
 
+__device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, V3 n, float cx, float cy, float cz)
+{
+    const float h = 0.5f + kSatMargin;
+    const V3 c{cx, cy, cz};
+    const V3 a = v0 - c, b = v1 - c, d = v2 - c;
+    // plane of the triangle (n is the normalised leaf normal): |n . a| <= h * (|nx| + |ny| + |nz|)
+    {
+        const float dist = n.x * a.x + n.y * a.y + n.z * a.z;
+        const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z));
+        if (abs_f(dist) > rad) return false;
+    }
+    const V3 e0 = b - a, e1 = d - b, e2 = a - d;
+    // axis = X x e: projections use only the vertices not on edge e (the edge's own vertices project equally)
+#define O2V_SAT_EDGE(E, U, W)                                                                               \
+    if (sat_axis_separates(E.z * U.y - E.y * U.z, E.z * W.y - E.y * W.z, h * (abs_f(E.z) + abs_f(E.y)))) return false; \
+    if (sat_axis_separates(E.x * U.z - E.z * U.x, E.x * W.z - E.z * W.x, h * (abs_f(E.x) + abs_f(E.z)))) return false; \
+    if (sat_axis_separates(E.y * U.x - E.x * U.y, E.y * W.x - E.x * W.y, h * (abs_f(E.y) + abs_f(E.x)))) return false;
+    O2V_SAT_EDGE(e0, a, d)
+    O2V_SAT_EDGE(e1, b, a)
+    O2V_SAT_EDGE(e2, d, b)
+#undef O2V_SAT_EDGE
+    return true;
+}
+
+constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
+constexpr uint32_t kMaxSurvivors = 4096;      // survivor queue entries per sub-batch
+constexpr uint32_t kSplitQuorum = 40;         // lanes that must be waiting for a cut before the split pass runs
+
+// K2.  Persistent workgroups pull batches of tiles.  Per batch:
+//   phase 1  every candidate voxel of the tiles: decode, plane-distance cull (voxelization.cpp:451-458), SAT
+//            pre-test; survivors are queued in LDS (tile slot + index in tile)
+//   phase 2  persistent lanes pop survivors and run computeTrianglesUvInVoxel (voxelization.cpp:383-424) as a
+//            depth-first walk of the split tree: the reference clips level by level with two 64-entry buffers;
+//            visiting the first emitted piece first reproduces its buffer order, so the running mean of
+//            :414-420 accumulates in the identical sequence.  Under DISCARD every split keeps <= 2 pieces, so at
+//            most one sibling per level 1..5 is pending (register stack).  The loop separates the cheap step
+//            "piece passes this plane whole" from the expensive cut, which runs when kSplitQuorum lanes wait
+//            for it (or nothing else can progress), keeping the 64 lanes of the wavefront busy.
 template <bool UV>
 __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                                      Counters *c, uint32_t *grid, HitRec *pool, Params p)
 {
-    extern __shared__ __align__(16) float s_stk[];  // [5][UV ? 15 : 9][kBlock]
-    __shared__ Leaf s_leaf[kTilesPerBatch];
+    __shared__ uint32_t s_leaf[kTilesPerBatch * kLeafStride];
     __shared__ uint32_t s_tleaf[kTilesPerBatch];
     __shared__ uint32_t s_tstart[kTilesPerBatch];
-    __shared__ uint32_t s_prefix[kTilesPerBatch + 1];
-    __shared__ uint8_t s_owner[kTilesPerBatch * kTileSize];
-    __shared__ uint32_t s_batch;
-    __shared__ uint32_t s_hits;
+    __shared__ uint32_t s_tcount[kTilesPerBatch];
+    __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
+    __shared__ uint16_t s_surv[kMaxSurvivors];
+    __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits;
 
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
     const uint32_t n_batches = (n_tiles + kTilesPerBatch - 1) / kTilesPerBatch;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
     if (threadIdx.x == 0) s_hits = 0;
 
@@ -814,79 +829,237 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
             s_tstart[threadIdx.x] = t.start;
         }
         __syncthreads();
-        // stage the leaves of this batch in LDS (24 dwords each)
+        // stage the leaves of this batch in LDS
         for (uint32_t i = threadIdx.x; i < nt * 24u; i += kBlock) {
             const uint32_t k = i / 24u, j = i - k * 24u;
-            reinterpret_cast<uint32_t *>(s_leaf)[i] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
+            s_leaf[k * kLeafStride + j] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0;
-            for (uint32_t k = 0; k < nt; ++k) {
-                const Leaf &lf = s_leaf[k];
-                const uint32_t cnt = (lf.bmin_z_dx >> 16) * (lf.dy_dz & 0xffffu) * (lf.dy_dz >> 16);
-                const uint32_t rem = cnt - s_tstart[k];
-                s_prefix[k] = acc;
-                acc += rem < kTileSize ? rem : kTileSize;
-            }
-            s_prefix[nt] = acc;
+        if (threadIdx.x < nt) {
+            const uint32_t *lf = &s_leaf[threadIdx.x * kLeafStride];
+            const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
+            const uint32_t rem = dx * dy * dz - s_tstart[threadIdx.x];
+            s_tcount[threadIdx.x] = rem < kTileSize ? rem : kTileSize;
+            s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
+            s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
         }
-        __syncthreads();
-        const uint32_t total = s_prefix[nt];
-        for (uint32_t k = 0; k < nt; ++k) {
-            const uint32_t b = s_prefix[k], n = s_prefix[k + 1] - b;
-            if (threadIdx.x < n) s_owner[b + threadIdx.x] = (uint8_t) k;
-        }
-        __syncthreads();
 
-        for (uint32_t cbase = 0; cbase < total; cbase += kBlock) {
-            const uint32_t cidx = cbase + threadIdx.x;
-            float w = 0.f, u = 0.f, v = 0.f;
-            uint64_t cell = 0;
-            uint32_t keyhi = 0, keylo = 0;
-            if (cidx < total) {
-                const uint32_t k = s_owner[cidx];
-                const Leaf &lf = s_leaf[k];
-                const uint32_t j = s_tstart[k] + (cidx - s_prefix[k]);
-                const uint32_t dx = lf.bmin_z_dx >> 16, dy = lf.dy_dz & 0xffffu;
-                const uint32_t row = j / dx;
-                const uint32_t lx = j - row * dx;
-                const uint32_t lz = row / dy;
-                const uint32_t ly = row - lz * dy;
-                const uint32_t x = (lf.bmin_xy & 0xffffu) + lx, y = (lf.bmin_xy >> 16) + ly,
-                               z = (lf.bmin_z_dx & 0xffffu) + lz;
-                // plane distance cull, voxelization.cpp:451-458
-                const V3 center = {(float) x + 0.5f, (float) y + 0.5f, (float) z + 0.5f};
-                const float sd = dot(V3{lf.n[0], lf.n[1], lf.n[2]}, center - V3{lf.v[0], lf.v[1], lf.v[2]});
-                if (!(abs_f(sd) > kPlaneDistanceLimit)) {
-                    clip_voxel<UV>(lf, x, y, z, s_stk, w, u, v);
-                    const uint32_t ox = x >> p.ss_shift, oy = y >> p.ss_shift, oz = z >> p.ss_shift;
-                    cell = ((uint64_t) (oz - p.zo0) * p.G + oy) * p.Gx + ox;
-                    const uint32_t sub = p.ss_shift ? ((x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2)) : 0u;
-                    keyhi = (sub << 29) | lf.tri;
-                    keylo = lf.pathkey;
+        // sub-batches of whole tiles with at most kMaxSurvivors candidates
+        uint32_t t_begin = 0;
+        while (t_begin < nt) {
+            __syncthreads();
+            uint32_t t_end = t_begin, cand = 0;
+            while (t_end < nt && cand + s_tcount[t_end] <= kMaxSurvivors) cand += s_tcount[t_end++];
+            if (threadIdx.x == 0) {
+                s_nsurv = 0;
+                s_next = 0;
+            }
+            __syncthreads();
+
+            // ---- phase 1: one wavefront per tile, lanes over its candidates --------------------------------
+            for (uint32_t k = t_begin + wave; k < t_end; k += kBlock / 64) {
+                const uint32_t *lf = &s_leaf[k * kLeafStride];
+                const uint32_t cnt = s_tcount[k], start = s_tstart[k];
+                const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
+                const float inv_dx = s_inv_dx[k], inv_dy = s_inv_dy[k];
+                const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
+                const uint32_t bx = lf[20] & 0xffffu, by = lf[20] >> 16, bz = lf[21] & 0xffffu;
+                for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    bool keep = false;
+                    if (i < cnt) {
+                        const uint32_t j = start + i;
+                        uint32_t row, lx, lz, ly;
+                        if (j < (1u << 24)) {
+                            // exact quotient from a float estimate (j < 2^24, divisor < 2^16): off by at most one
+                            row = (uint32_t) ((float) j * inv_dx);
+                            int32_t rx = (int32_t) (j - row * dx);
+                            if (rx < 0) { row -= 1; rx += (int32_t) dx; }
+                            else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
+                            lx = (uint32_t) rx;
+                            lz = (uint32_t) ((float) row * inv_dy);
+                            int32_t ry = (int32_t) (row - lz * dy);
+                            if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
+                            else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
+                            ly = (uint32_t) ry;
+                        }
+                        else {
+                            row = j / dx;
+                            lx = j - row * dx;
+                            lz = row / dy;
+                            ly = row - lz * dy;
+                        }
+                        const float cx = (float) (bx + lx) + 0.5f, cy = (float) (by + ly) + 0.5f, cz = (float) (bz + lz) + 0.5f;
+                        // plane distance cull, voxelization.cpp:451-458
+                        const float sd = dot(nrm, V3{cx, cy, cz} - v0);
+                        keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, nrm, cx, cy, cz);
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (m) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&s_nsurv, (uint32_t) __popcll(m));
+                        base = __shfl(base, 0, 64);
+                        if (keep) s_surv[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) (((k - t_begin) << 8) | i);
+                    }
                 }
             }
-            // `not eqExactly(uv.weight, 0.f)` -> insertWeighted (voxelization.cpp:466-468): here the hit is
-            // appended to the cell's list; the ordered combine happens in k_resolve.
-            const bool hit = w != 0.f;
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                const uint32_t cnt = (uint32_t) __popcll(mask);
-                if (chunk_used + cnt > kHitChunk) {
-                    uint32_t base = 0;
-                    if (lane == (uint32_t) (__ffsll((long long) mask) - 1)) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
-                    chunk_base = __shfl(base, __ffsll((long long) mask) - 1, 64);
-                    chunk_used = 0;
+            __syncthreads();
+            const uint32_t n_surv = s_nsurv;
+
+            // ---- phase 2: persistent lanes ------------------------------------------------------------------
+            Piece<UV> cur{}, sec{};
+            PieceStack<UV> stack{};
+            uint32_t level = 0, pending = 0, cls = 0, my_k = 0;
+            bool active = false, has_job = false, need_cut = false;
+            float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
+            float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
+            uint32_t px = 0, py = 0, pz = 0;
+            bool queue_empty = n_surv == 0;
+            for (;;) {
+                // pop a pending sibling, or fetch the next survivor
+                if (!active && !need_cut) {
+                    if (pending) {
+                        level = 31u - (uint32_t) __clz((int) pending);
+                        pending ^= 1u << level;
+                        stack_load<UV>(stack, level - 1u, cur);
+                        active = true;
+                    }
+                    else if (!queue_empty) {
+                        const uint32_t q = atomicAdd(&s_next, 1u);
+                        if (q < n_surv) {
+                            const uint32_t e = s_surv[q];
+                            my_k = t_begin + (e >> 8);
+                            const uint32_t *lf = &s_leaf[my_k * kLeafStride];
+                            const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
+                            const uint32_t j = s_tstart[my_k] + (e & 255u);
+                            uint32_t row, lx, ly, lz;
+                            if (j < (1u << 24)) {
+                                row = (uint32_t) ((float) j * s_inv_dx[my_k]);
+                                int32_t rx = (int32_t) (j - row * dx);
+                                if (rx < 0) { row -= 1; rx += (int32_t) dx; }
+                                else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
+                                lx = (uint32_t) rx;
+                                lz = (uint32_t) ((float) row * s_inv_dy[my_k]);
+                                int32_t ry = (int32_t) (row - lz * dy);
+                                if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
+                                else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
+                                ly = (uint32_t) ry;
+                            }
+                            else {
+                                row = j / dx;
+                                lx = j - row * dx;
+                                lz = row / dy;
+                                ly = row - lz * dy;
+                            }
+                            px = (lf[20] & 0xffffu) + lx;
+                            py = (lf[20] >> 16) + ly;
+                            pz = (lf[21] & 0xffffu) + lz;
+                            fx = (float) px;
+                            fy = (float) py;
+                            fz = (float) pz;
+                            cur.a = {__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                            cur.b = {__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                            cur.c = {__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                            if (UV) {
+                                cur.ta = {__uint_as_float(lf[12]), __uint_as_float(lf[13])};
+                                cur.tb = {__uint_as_float(lf[14]), __uint_as_float(lf[15])};
+                                cur.tc = {__uint_as_float(lf[16]), __uint_as_float(lf[17])};
+                            }
+                            area = __uint_as_float(lf[23]);
+                            level = 0;
+                            w = 0.f;
+                            u = 0.f;
+                            v = 0.f;
+                            active = true;
+                            has_job = true;
+                        }
+                        else {
+                            queue_empty = true;
+                        }
+                    }
                 }
-                const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
-                chunk_used += cnt;
-                if (hit && mine < p.cap_hits) {
-                    const uint32_t prev = atomicExch(&grid[cell], mine + 1u);
-                    pool[mine] = HitRec{prev, keyhi, keylo, w, u, v};
+                // cheap step: classify the current piece against plane `level`; whole triangles move on at once
+                if (active) {
+                    const bool keep_lo = level >= 3u;
+                    const uint32_t axis = keep_lo ? level - 3u : level;
+                    const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
+                    cls = classify_piece(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane);
+                    if ((cls & kClsModeMask) == 0u) {
+                        if (((cls & kClsSideLo) != 0) == keep_lo) {
+                            level += 1u;
+                            if (level == 6u) {
+                                accumulate_piece<UV>(cur, area, w, u, v);
+                                active = false;
+                            }
+                        }
+                        else {
+                            active = false;  // discarded
+                        }
+                    }
+                    else {
+                        need_cut = true;
+                        active = false;
+                    }
                 }
-                if (lane == 0) atomicAdd(&s_hits, cnt);
+                // expensive step: run the cuts when enough lanes wait for one, or nothing else can progress
+                const unsigned long long m_cut = __ballot(need_cut);
+                const unsigned long long m_busy = __ballot(active || (!need_cut && (pending != 0 || !queue_empty)));
+                if (m_cut && ((uint32_t) __popcll(m_cut) >= kSplitQuorum || !m_busy)) {
+                    if (need_cut) {
+                        const bool keep_lo = level >= 3u;
+                        const uint32_t axis = keep_lo ? level - 3u : level;
+                        const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
+                        const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo);
+                        need_cut = false;
+                        if (level == 5u) {
+                            accumulate_piece<UV>(cur, area, w, u, v);
+                            if (n == 2) accumulate_piece<UV>(sec, area, w, u, v);
+                        }
+                        else {
+                            if (n == 2) {
+                                stack_store<UV>(stack, level, sec);  // slot of level + 1
+                                pending |= 1u << (level + 1u);
+                            }
+                            level += 1u;
+                            active = true;
+                        }
+                    }
+                }
+                // a job is finished when nothing of it is in flight: `not eqExactly(uv.weight, 0.f)` ->
+                // insertWeighted (voxelization.cpp:466-468): the hit joins its cell's list; the ordered combine
+                // happens in k_resolve
+                const bool finished = has_job && !active && !need_cut && pending == 0;
+                const bool hit = finished && w != 0.f;
+                if (finished) has_job = false;
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    const uint32_t cnt = (uint32_t) __popcll(mask);
+                    const uint32_t leader = (uint32_t) __ffsll((long long) mask) - 1u;
+                    if (chunk_used + cnt > kHitChunk) {
+                        uint32_t base = 0;
+                        if (lane == leader) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
+                        chunk_base = __shfl(base, (int) leader, 64);
+                        chunk_used = 0;
+                    }
+                    const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+                    chunk_used += cnt;
+                    if (hit && mine < p.cap_hits) {
+                        const uint32_t *lf = &s_leaf[my_k * kLeafStride];
+                        const uint32_t ox = px >> p.ss_shift, oy = py >> p.ss_shift, oz = pz >> p.ss_shift;
+                        const uint64_t cell = ((uint64_t) (oz - p.zo0) * p.G + oy) * p.Gx + ox;
+                        const uint32_t sub = p.ss_shift ? ((px & 1u) | ((py & 1u) << 1) | ((pz & 1u) << 2)) : 0u;
+                        const uint32_t prev = atomicExch(&grid[cell], mine + 1u);
+                        pool[mine] = HitRec{prev, (sub << 29) | lf[18], lf[19], w, u, v};
+                    }
+                    if (lane == leader) atomicAdd(&s_hits, cnt);
+                }
+                // the wavefront leaves when no lane has anything in flight and the queue is drained
+                if (!__ballot(active || need_cut || pending != 0 || !queue_empty)) break;
             }
+            t_begin = t_end;
         }
     }
     __syncthreads();
@@ -1372,7 +1545,6 @@ int upload(o2v_hip_ctx *ctx, T *&dptr, const T *host, uint64_t count)
     return O2V_HIP_OK;
 }
 
-uint32_t lds_bytes_voxelize(bool uv) { return 5u * (uv ? 15u : 9u) * kBlock * (uint32_t) sizeof(float); }
 
 // O2V_DEBUG_SYNC=1: synchronise and log after every launch (locates a faulting or hanging kernel).
 bool debug_sync_enabled()
@@ -1424,14 +1596,14 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
     O2V_CHECK(hipEventRecord(ctx->ev[2], s));
 
     {
-        const uint32_t lds = lds_bytes_voxelize(use_uv);
-        const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? 1u : 2u);
+        // persistent workgroups; residency is VGPR-bound (about 4 waves per SIMD without UVs, 3 with)
+        const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? 3u : 4u);
         if (use_uv) {
-            hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), lds, s, ctx->d_leaves, ctx->d_tiles,
+            hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
         }
         else {
-            hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(kBlock), lds, s, ctx->d_leaves, ctx->d_tiles,
+            hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
         }
         O2V_STAGE("k_voxelize");
@@ -1513,11 +1685,6 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
-    // the clip stacks of k_voxelize<true> need more than the default 64 KiB of dynamic LDS
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_voxelize<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes_voxelize(true));
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_voxelize<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes_voxelize(false));
     *out_ctx = ctx;
     return O2V_HIP_OK;
 }

@@ -13,8 +13,9 @@
 //       k_expand_big           tiles of <= 256 candidate voxels for large leaves
 //   K2  k_voxelize<UV>         AABB walk + plane cull (voxelization.cpp:426-472) + six-plane clip by triangle
 //                              splitting (voxelization.cpp:175-331,383-424); every hit is appended to the hit
-//                              pool and linked into its cell's list with one atomicExch on the dense grid
-//   K5a k_scan                 streams the dense grid once, compacts occupied cells, resets them to empty
+//                              pool and counted in its cell with one atomicAdd on the dense grid (-> rank)
+//   K5a k_scan_flags/_bricks   reads the dirty bricks of the dense grid, compacts occupied cells, turns the
+//                              per-cell counts into offsets (counting sort); k_scatter places the hits
 //   K3  k_resolve              per occupied cell: orders the hits like the reference's sequential loops
 //                              (sub-voxel, triangle index, leaf order), replays insertWeighted
 //                              (voxelization.cpp:56-63,466-468) and moveUvBufferIntoVoxels (:513-526) with
@@ -41,7 +42,7 @@ namespace {
 // ---- device-side records ----------------------------------------------------------------------------------
 
 constexpr uint32_t kTileSize = 256;       // candidate voxels per work tile
-constexpr uint32_t kTilesPerBatch = 64;   // tiles a workgroup stages at once
+constexpr uint32_t kTilesPerBatch = 192;  // tiles a workgroup stages at once
 constexpr uint32_t kBlock = 256;          // threads per workgroup (4 wavefronts)
 constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key holds 15 levels)
 constexpr uint32_t kHitChunk = 256;       // hit-pool slots a wavefront reserves per global atomic
@@ -80,16 +81,27 @@ struct BigLeaf {
     uint32_t leaf, first_tile, ntiles, pad;
 };
 
-struct __attribute__((aligned(8))) HitRec {  // 24 B
-    uint32_t next;   // 1-based index of the next record of the same cell, 0 = end
-    uint32_t keyhi;  // sub-voxel << 29 | triangle index
-    uint32_t keylo;  // leaf order key
-    float w, u, v;   // WeightedUv of this (leaf, voxel) pair (voxelization.cpp:414-423)
+struct __attribute__((aligned(16))) HitRec {  // 32 B: one (leaf, voxel) hit as emitted by k_voxelize
+    uint32_t brick;       // brick of the cell; kHoleBrick marks a pool slot that holds no hit
+    uint32_t local_rank;  // cell inside the brick << 24 | rank of this hit among the hits of its cell
+    uint32_t keyhi;       // sub-voxel << 29 | triangle index
+    uint32_t keylo;       // leaf order key
+    float w, u, v;        // WeightedUv of this (leaf, voxel) pair (voxelization.cpp:414-423)
+    uint32_t pad;
+};
+constexpr uint32_t kHoleBrick = 0xffffffffu;
+constexpr uint32_t kMaxRank = 1u << 24;
+
+struct __attribute__((aligned(8))) SortedRec {  // 24 B: the same hit, placed contiguously with its cell's other hits
+    uint32_t keyhi, keylo;
+    float w, u, v;
+    uint32_t pad;
 };
 
-struct Occ {
-    uint32_t cell_lo, cell_hi;  // linear cell index inside the slab
-    uint32_t head;
+struct __attribute__((aligned(16))) Occ {  // 16 B: one occupied cell
+    uint32_t cell_lo, cell_hi;  // brick * 256 + cell in brick
+    uint32_t offset;            // first SortedRec of the cell
+    uint32_t count;             // number of hits
 };
 
 struct DevTexture {
@@ -101,6 +113,7 @@ struct Counters {
     uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
     uint32_t n_vox, batch_cursor, err_flags, pad0;
     uint32_t n_mid, n_long, n_huge, scratch_used;
+    uint32_t n_dirty, n_sorted, pad4[2];
     uint32_t cursor_mid, cursor_long, cursor_huge, pad3;
     uint32_t n_nodes[kMaxRounds + 1];
     uint32_t pad1[3];
@@ -113,18 +126,20 @@ struct Counters {
 enum : uint32_t {
     kErrLeafTooLarge = 1u,
     kErrDepth = 2u,
+    kErrRank = 4u,
 };
 
 struct Params {
     uint64_t n_tris;
     uint32_t S;            // sample resolution = resolution * supersampling
     uint32_t G;            // output resolution
-    uint32_t Gx;           // row pitch of the dense grid (G rounded up to 4)
+    uint32_t NBx, NBy;     // bricks per grid row / per z layer (brick = 16 x 4 x 4 cells, stored contiguously)
     uint32_t ss_shift;     // 0, or 1 for 2x supersampling
     uint32_t zs0, zs1;     // slab in sample space
     uint32_t zo0;          // slab begin in output space
     uint32_t blend;
     uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
+    uint32_t n_bricks;     // bricks of this slab
     uint32_t bounds_known;
     float bounds[6];
     int32_t unit[9];
@@ -144,6 +159,17 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float(b);
 }
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Dense grid layout: bricks of 16 (x) x 4 (y) x 4 (z) cells, each brick 256 consecutive u32 (1 KiB), bricks ordered
+// x fastest.  A surface marks ~12 cells' worth of brick volume per unit area in this shape (the same as 8^3 bricks)
+// while every brick row is a full 64-byte line; one wavefront reads a brick with a single 16-byte load per lane.
+constexpr uint32_t kBrickX = 16, kBrickY = 4, kBrickZ = 4, kBrickCells = 256;
+
+__device__ __forceinline__ uint64_t cell_index(uint32_t ox, uint32_t oy, uint32_t oz_rel, const Params &p, uint32_t &brick)
+{
+    brick = ((oz_rel >> 2) * p.NBy + (oy >> 2)) * p.NBx + (ox >> 4);
+    return (uint64_t) brick * kBrickCells + (((oz_rel & 3u) * 4u + (oy & 3u)) * 16u + (ox & 15u));
+}
 
 // exclusive scan of one uint32 per thread over a 256-thread block; returns the block total in `total`
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &total)
@@ -784,8 +810,7 @@ __device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, V3 n, float
 }
 
 constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
-constexpr uint32_t kMaxSurvivors = 4096;      // survivor queue entries per sub-batch
-constexpr uint32_t kSplitQuorum = 40;         // lanes that must be waiting for a cut before the split pass runs
+constexpr uint32_t kMaxSurvivors = 8192;      // survivor queue entries (= candidate voxels) per sub-batch
 
 // K2.  Persistent workgroups pull batches of tiles.  Per batch:
 //   phase 1  every candidate voxel of the tiles: decode, plane-distance cull (voxelization.cpp:451-458), SAT
@@ -794,17 +819,21 @@ constexpr uint32_t kSplitQuorum = 40;         // lanes that must be waiting for 
 //            depth-first walk of the split tree: the reference clips level by level with two 64-entry buffers;
 //            visiting the first emitted piece first reproduces its buffer order, so the running mean of
 //            :414-420 accumulates in the identical sequence.  Under DISCARD every split keeps <= 2 pieces, so at
-//            most one sibling per level 1..5 is pending (register stack).  The loop separates the cheap step
-//            "piece passes this plane whole" from the expensive cut, which runs when kSplitQuorum lanes wait
-//            for it (or nothing else can progress), keeping the 64 lanes of the wavefront busy.
+//            most one sibling per level 1..5 is pending (register stack).  Per iteration a lane skips every
+//            plane its piece passes whole (AABB check), classifies it against the first plane it does not, and
+//            cuts if needed; lanes that run out of pieces pop the next survivor, so the wavefront stays full.
 template <bool UV>
 __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
-                                                     Counters *c, uint32_t *grid, HitRec *pool, Params p)
+                                                     Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
+                                                     Params p)
 {
     __shared__ uint32_t s_leaf[kTilesPerBatch * kLeafStride];
     __shared__ uint32_t s_tleaf[kTilesPerBatch];
     __shared__ uint32_t s_tstart[kTilesPerBatch];
     __shared__ uint32_t s_tcount[kTilesPerBatch];
+    __shared__ uint32_t s_tprefix[kTilesPerBatch + 2];
+    __shared__ uint32_t s_scan[kBlock / 64];
+    __shared__ uint32_t s_tend;
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
     __shared__ uint16_t s_surv[kMaxSurvivors];
     __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits;
@@ -835,26 +864,40 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
             s_leaf[k * kLeafStride + j] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
         }
         __syncthreads();
+        uint32_t my_count = 0;
         if (threadIdx.x < nt) {
             const uint32_t *lf = &s_leaf[threadIdx.x * kLeafStride];
             const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
             const uint32_t rem = dx * dy * dz - s_tstart[threadIdx.x];
-            s_tcount[threadIdx.x] = rem < kTileSize ? rem : kTileSize;
+            my_count = rem < kTileSize ? rem : kTileSize;
+            s_tcount[threadIdx.x] = my_count;
             s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
+        }
+        {
+            // exclusive prefix of the tile sizes: s_tprefix[k] = candidates before tile k, s_tprefix[nt] = total
+            uint32_t total;
+            const uint32_t ex = block_exscan(my_count, s_scan, total);
+            if (threadIdx.x <= nt) s_tprefix[threadIdx.x] = threadIdx.x < nt ? ex : total;
         }
 
         // sub-batches of whole tiles with at most kMaxSurvivors candidates
         uint32_t t_begin = 0;
         while (t_begin < nt) {
             __syncthreads();
-            uint32_t t_end = t_begin, cand = 0;
-            while (t_end < nt && cand + s_tcount[t_end] <= kMaxSurvivors) cand += s_tcount[t_end++];
+            const uint32_t base_cand = s_tprefix[t_begin];
+            // the last tile whose end still fits decides t_end (found by the thread that owns it)
+            if (threadIdx.x >= t_begin && threadIdx.x < nt) {
+                const bool fits = s_tprefix[threadIdx.x + 1] - base_cand <= kMaxSurvivors;
+                const bool next_fits = threadIdx.x + 1 < nt && s_tprefix[threadIdx.x + 2] - base_cand <= kMaxSurvivors;
+                if (fits && !next_fits) s_tend = threadIdx.x + 1;
+            }
             if (threadIdx.x == 0) {
                 s_nsurv = 0;
                 s_next = 0;
             }
             __syncthreads();
+            const uint32_t t_end = s_tend;
 
             // ---- phase 1: one wavefront per tile, lanes over its candidates --------------------------------
             for (uint32_t k = t_begin + wave; k < t_end; k += kBlock / 64) {
@@ -912,15 +955,15 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
             // ---- phase 2: persistent lanes ------------------------------------------------------------------
             Piece<UV> cur{}, sec{};
             PieceStack<UV> stack{};
-            uint32_t level = 0, pending = 0, cls = 0, my_k = 0;
-            bool active = false, has_job = false, need_cut = false;
+            uint32_t level = 0, pending = 0, my_k = 0;
+            bool active = false, has_job = false;
             float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
             float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
             uint32_t px = 0, py = 0, pz = 0;
             bool queue_empty = n_surv == 0;
             for (;;) {
                 // pop a pending sibling, or fetch the next survivor
-                if (!active && !need_cut) {
+                if (!active) {
                     if (pending) {
                         level = 31u - (uint32_t) __clz((int) pending);
                         pending ^= 1u << level;
@@ -981,57 +1024,63 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
                         }
                     }
                 }
-                // cheap step: classify the current piece against plane `level`; whole triangles move on at once
                 if (active) {
-                    const bool keep_lo = level >= 3u;
-                    const uint32_t axis = keep_lo ? level - 3u : level;
-                    const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
-                    cls = classify_piece(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane);
-                    if ((cls & kClsModeMask) == 0u) {
-                        if (((cls & kClsSideLo) != 0) == keep_lo) {
-                            level += 1u;
-                            if (level == 6u) {
-                                accumulate_piece<UV>(cur, area, w, u, v);
-                                active = false;
-                            }
-                        }
-                        else {
-                            active = false;  // discarded
-                        }
-                    }
-                    else {
-                        need_cut = true;
+                    // Skip ahead: a piece whose vertices all satisfy v >= plane (lower planes) or v < plane (upper
+                    // planes) is the loSum == 0 / loSum == 3 case of splitTriangle (voxelization.cpp:194-205) and
+                    // passes whole, so every such plane from `level` on is skipped at once.
+                    const V3 mn = tri_min(cur.a, cur.b, cur.c), mx = tri_max(cur.a, cur.b, cur.c);
+                    uint32_t fail = 0;
+                    fail |= (mn.x >= fx) ? 0u : 1u;
+                    fail |= (mn.y >= fy) ? 0u : 2u;
+                    fail |= (mn.z >= fz) ? 0u : 4u;
+                    fail |= (mx.x < fx + 1.0f) ? 0u : 8u;
+                    fail |= (mx.y < fy + 1.0f) ? 0u : 16u;
+                    fail |= (mx.z < fz + 1.0f) ? 0u : 32u;
+                    fail &= ~((1u << level) - 1u);
+                    if (fail == 0) {
+                        accumulate_piece<UV>(cur, area, w, u, v);  // inside all remaining planes
                         active = false;
                     }
-                }
-                // expensive step: run the cuts when enough lanes wait for one, or nothing else can progress
-                const unsigned long long m_cut = __ballot(need_cut);
-                const unsigned long long m_busy = __ballot(active || (!need_cut && (pending != 0 || !queue_empty)));
-                if (m_cut && ((uint32_t) __popcll(m_cut) >= kSplitQuorum || !m_busy)) {
-                    if (need_cut) {
+                    else {
+                        level = (uint32_t) __ffs((int) fail) - 1u;
                         const bool keep_lo = level >= 3u;
                         const uint32_t axis = keep_lo ? level - 3u : level;
                         const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
-                        const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo);
-                        need_cut = false;
-                        if (level == 5u) {
-                            accumulate_piece<UV>(cur, area, w, u, v);
-                            if (n == 2) accumulate_piece<UV>(sec, area, w, u, v);
+                        const uint32_t cls = classify_piece(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane);
+                        if ((cls & kClsModeMask) == 0u) {
+                            // whole triangle to one side (all-lo/all-hi or one of the planar special cases)
+                            if (((cls & kClsSideLo) != 0) == keep_lo) {
+                                level += 1u;
+                                if (level == 6u) {
+                                    accumulate_piece<UV>(cur, area, w, u, v);
+                                    active = false;
+                                }
+                            }
+                            else {
+                                active = false;  // discarded
+                            }
                         }
                         else {
-                            if (n == 2) {
-                                stack_store<UV>(stack, level, sec);  // slot of level + 1
-                                pending |= 1u << (level + 1u);
+                            const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo);
+                            if (level == 5u) {
+                                accumulate_piece<UV>(cur, area, w, u, v);
+                                if (n == 2) accumulate_piece<UV>(sec, area, w, u, v);
+                                active = false;
                             }
-                            level += 1u;
-                            active = true;
+                            else {
+                                if (n == 2) {
+                                    stack_store<UV>(stack, level, sec);  // slot of level + 1
+                                    pending |= 1u << (level + 1u);
+                                }
+                                level += 1u;
+                            }
                         }
                     }
                 }
                 // a job is finished when nothing of it is in flight: `not eqExactly(uv.weight, 0.f)` ->
                 // insertWeighted (voxelization.cpp:466-468): the hit joins its cell's list; the ordered combine
                 // happens in k_resolve
-                const bool finished = has_job && !active && !need_cut && pending == 0;
+                const bool finished = has_job && !active && pending == 0;
                 const bool hit = finished && w != 0.f;
                 if (finished) has_job = false;
                 const unsigned long long mask = __ballot(hit);
@@ -1039,6 +1088,12 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
                     const uint32_t cnt = (uint32_t) __popcll(mask);
                     const uint32_t leader = (uint32_t) __ffsll((long long) mask) - 1u;
                     if (chunk_used + cnt > kHitChunk) {
+                        // abandon the rest of the chunk (marked as holes for the scatter pass) and reserve a new one
+                        const uint32_t hole = chunk_base + chunk_used + lane;
+                        if (chunk_used + lane < kHitChunk && hole < p.cap_hits) pool[hole].brick = kHoleBrick;
+                        if (chunk_used + 64u + lane < kHitChunk && hole + 64u < p.cap_hits) pool[hole + 64u].brick = kHoleBrick;
+                        if (chunk_used + 128u + lane < kHitChunk && hole + 128u < p.cap_hits) pool[hole + 128u].brick = kHoleBrick;
+                        if (chunk_used + 192u + lane < kHitChunk && hole + 192u < p.cap_hits) pool[hole + 192u].brick = kHoleBrick;
                         uint32_t base = 0;
                         if (lane == leader) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
                         chunk_base = __shfl(base, (int) leader, 64);
@@ -1049,85 +1104,167 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
                     if (hit && mine < p.cap_hits) {
                         const uint32_t *lf = &s_leaf[my_k * kLeafStride];
                         const uint32_t ox = px >> p.ss_shift, oy = py >> p.ss_shift, oz = pz >> p.ss_shift;
-                        const uint64_t cell = ((uint64_t) (oz - p.zo0) * p.G + oy) * p.Gx + ox;
+                        uint32_t brick;
+                        const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
                         const uint32_t sub = p.ss_shift ? ((px & 1u) | ((py & 1u) << 1) | ((pz & 1u) << 2)) : 0u;
-                        const uint32_t prev = atomicExch(&grid[cell], mine + 1u);
-                        pool[mine] = HitRec{prev, (sub << 29) | lf[18], lf[19], w, u, v};
+                        // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
+                        const uint32_t rank = atomicAdd(&grid[cell], 1u);
+                        if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
+                        brick_dirty[brick] = 1;  // benign race: every writer stores the same value
+                        pool[mine] = HitRec{brick, (((uint32_t) cell & 255u) << 24) | (rank & (kMaxRank - 1u)),
+                                            (sub << 29) | lf[18], lf[19], w, u, v, 0u};
                     }
                     if (lane == leader) atomicAdd(&s_hits, cnt);
                 }
                 // the wavefront leaves when no lane has anything in flight and the queue is drained
-                if (!__ballot(active || need_cut || pending != 0 || !queue_empty)) break;
+                if (!__ballot(active || pending != 0 || !queue_empty)) break;
             }
             t_begin = t_end;
         }
     }
+    // the unused tail of this wavefront's last chunk holds no hits
+    for (uint32_t k = chunk_used + lane; k < kHitChunk; k += 64)
+        if (chunk_used != kHitChunk && chunk_base + k < p.cap_hits) pool[chunk_base + k].brick = kHoleBrick;
     __syncthreads();
     if (threadIdx.x == 0 && s_hits) atomicAdd(&c->n_hits, (unsigned long long) s_hits);
 }
 
 // ---- K5a: scan + compact + reset ---------------------------------------------------------------------------
+// Two steps.  k_scan_flags streams the one-byte-per-brick dirty map (n_bricks bytes, 4 MiB at 1024^3), lists the
+// dirty bricks and clears their flags.  k_scan_bricks then reads only those bricks (1 KiB each, one 16-byte load
+// per lane), compacts the occupied cells into `occ` through an LDS staging buffer (one global atomic per flush,
+// not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.
 
-constexpr uint32_t kScanUnroll = 4;                              // uint4 loads in flight per thread
-constexpr uint32_t kScanCellsPerIter = kBlock * 4 * kScanUnroll;  // 4096 cells = 16 KiB per block iteration
-constexpr uint32_t kScanFlushAt = 2048;
-constexpr uint32_t kScanCap = kScanFlushAt + kScanCellsPerIter;
-
-__global__ __launch_bounds__(kBlock) void k_scan(uint32_t *grid, uint64_t n_quads, Counters *c, Occ *occ, Params p)
+__global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, Counters *c, uint32_t *dirty_list, Params p)
 {
-    __shared__ uint32_t s_lo[kScanCap], s_hi[kScanCap], s_head[kScanCap];
+    __shared__ uint32_t s_list[kBlock * 16];
     __shared__ uint32_t s_n, s_base;
+    const uint32_t n_groups = (p.n_bricks + 15u) / 16u;  // the flag map is padded to a multiple of 16 bytes
+    uint4 *f4 = reinterpret_cast<uint4 *>(brick_dirty);
+    for (uint32_t g0 = blockIdx.x * kBlock; g0 < n_groups; g0 += gridDim.x * kBlock) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const uint32_t g = g0 + threadIdx.x;
+        if (g < n_groups) {
+            const uint4 f = f4[g];
+            if (f.x | f.y | f.z | f.w) {
+                const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 16; ++k)
+                    if ((w[k >> 2] >> ((k & 3u) * 8u)) & 0xffu) s_list[atomicAdd(&s_n, 1u)] = g * 16u + k;
+                f4[g] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&c->n_dirty, n);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n; i += kBlock) dirty_list[s_base + i] = s_list[i];
+        }
+    }
+}
+
+constexpr uint32_t kScanBricksPerWave = 4;                                   // independent 1 KiB loads in flight per wave
+constexpr uint32_t kScanBricksPerRound = (kBlock / 64) * kScanBricksPerWave;  // 16 bricks = 4096 cells per block round
+constexpr uint32_t kScanFlushAt = 2048;
+constexpr uint32_t kScanCap = kScanFlushAt + kScanBricksPerRound * kBrickCells;
+
+// Writes the staged occupied cells of one workgroup to `occ`, giving every cell the offset of its hits in the sorted
+// record array: one reservation of (cells, hits) per flush, offsets by a block-level prefix sum over the counts.
+// The offset is also stored in the cell itself, where k_scatter reads it.
+__device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi, const uint32_t *s_cnt,
+                                           uint32_t *s_wave, uint32_t *s_base, uint32_t *grid, Counters *c, Occ *occ,
+                                           const Params &p)
+{
+    // thread t owns the entries [t * per, (t + 1) * per)
+    const uint32_t per = (n + kBlock - 1) / kBlock;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += s_cnt[i];
+    uint32_t total;
+    uint32_t run = block_exscan(sum, s_wave, total);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base[0] = atomicAdd(&c->n_vox, n);
+        s_base[1] = atomicAdd(&c->n_sorted, total);
+    }
+    __syncthreads();
+    const uint32_t base_vox = s_base[0];
+    run += s_base[1];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t cnt = s_cnt[i];
+        if (base_vox + i < p.cap_vox) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], run, cnt};
+        grid[((uint64_t) s_hi[i] << 32) | s_lo[i]] = run;
+        run += cnt;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const uint32_t *__restrict__ dirty_list,
+                                                        Counters *c, Occ *occ, Params p)
+{
+    __shared__ uint32_t s_lo[kScanCap], s_hi[kScanCap], s_cnt[kScanCap];
+    __shared__ uint32_t s_n, s_base[2], s_wave[kBlock / 64];
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint64_t quads_per_iter = (uint64_t) kBlock * kScanUnroll;
-    const uint64_t n_iters = (n_quads + quads_per_iter - 1) / quads_per_iter;
-    uint4 *g4 = reinterpret_cast<uint4 *>(grid);
-    for (uint64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
-        const uint64_t q0 = it * quads_per_iter + threadIdx.x;
-        uint4 h[kScanUnroll];
+    const uint32_t n_dirty = c->n_dirty;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_rounds = (n_dirty + kScanBricksPerRound - 1) / kScanBricksPerRound;
+    for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
+        uint32_t brick[kScanBricksPerWave];
+        uint4 h[kScanBricksPerWave];
 #pragma unroll
-        for (uint32_t k = 0; k < kScanUnroll; ++k) {
-            const uint64_t q = q0 + (uint64_t) k * kBlock;
-            h[k] = q < n_quads ? g4[q] : make_uint4(0, 0, 0, 0);
+        for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
+            const uint32_t item = r * kScanBricksPerRound + wave * kScanBricksPerWave + k;
+            brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
         }
 #pragma unroll
-        for (uint32_t k = 0; k < kScanUnroll; ++k) {
+        for (uint32_t k = 0; k < kScanBricksPerWave; ++k)
+            h[k] = brick[k] != 0xffffffffu ? reinterpret_cast<const uint4 *>(grid + (uint64_t) brick[k] * kBrickCells)[lane]
+                                           : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
             if (h[k].x | h[k].y | h[k].z | h[k].w) {
-                const uint64_t q = q0 + (uint64_t) k * kBlock;
                 const uint32_t hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
 #pragma unroll
                 for (uint32_t e = 0; e < 4; ++e) {
                     if (hv[e]) {
-                        const uint64_t cell = q * 4 + e;
+                        const uint64_t cell = (uint64_t) brick[k] * kBrickCells + lane * 4u + e;
                         const uint32_t slot = atomicAdd(&s_n, 1u);
                         s_lo[slot] = (uint32_t) cell;
                         s_hi[slot] = (uint32_t) (cell >> 32);
-                        s_head[slot] = hv[e];
+                        s_cnt[slot] = hv[e];
                     }
                 }
-                g4[q] = make_uint4(0, 0, 0, 0);  // leave the grid clean for the next voxelization
             }
         }
         __syncthreads();
         const uint32_t n = s_n;
         if (n >= kScanFlushAt) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&c->n_vox, n);
-            __syncthreads();
-            const uint32_t base = s_base;
-            for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-                if (base + i < p.cap_vox) occ[base + i] = Occ{s_lo[i], s_hi[i], s_head[i]};
+            scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, grid, c, occ, p);
             __syncthreads();
             if (threadIdx.x == 0) s_n = 0;
         }
         __syncthreads();
     }
     const uint32_t n = s_n;
-    if (n) {
-        if (threadIdx.x == 0) s_base = atomicAdd(&c->n_vox, n);
-        __syncthreads();
-        const uint32_t base = s_base;
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-            if (base + i < p.cap_vox) occ[base + i] = Occ{s_lo[i], s_hi[i], s_head[i]};
+    if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, grid, c, occ, p);
+}
+
+// ---- K5b: scatter --------------------------------------------------------------------------------------------
+// Streams the hit pool once (coalesced 32-byte records, holes skipped) and places every hit at
+// offset(cell) + rank, so that each cell's hits are contiguous for the resolve kernels.
+__global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ pool, const uint32_t *__restrict__ grid,
+                                                    const Counters *c, SortedRec *sorted, Params p)
+{
+    const uint32_t n = c->n_hits_reserved < p.cap_hits ? c->n_hits_reserved : p.cap_hits;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const HitRec r = pool[i];
+        if (r.brick == kHoleBrick) continue;
+        const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
+        const uint32_t pos = grid[cell] + (r.local_rank & (kMaxRank - 1u));
+        if (pos < p.cap_hits) sorted[pos] = SortedRec{r.keyhi, r.keylo, r.w, r.u, r.v, 0u};
     }
 }
 
@@ -1230,11 +1367,13 @@ struct CellFold {
 __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const Params &p)
 {
     const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
-    const uint64_t row = cell / p.Gx;
-    const uint32_t x = (uint32_t) (cell - row * p.Gx);
-    const uint32_t zrel = (uint32_t) (row / p.G);
-    const uint32_t y = (uint32_t) (row - (uint64_t) zrel * p.G);
-    return make_uint4(x, y, zrel + p.zo0, argb);
+    const uint32_t brick = (uint32_t) (cell >> 8), local = (uint32_t) cell & 255u;
+    const uint32_t row = brick / p.NBx;
+    const uint32_t bx = brick - row * p.NBx;
+    const uint32_t bz = row / p.NBy;
+    const uint32_t by = row - bz * p.NBy;
+    const uint32_t x = bx * kBrickX + (local & 15u), y = by * kBrickY + ((local >> 4) & 3u), z = bz * kBrickZ + (local >> 6);
+    return make_uint4(x, y, z + p.zo0, argb);
 }
 
 constexpr uint32_t kShortList = 8;     // lists up to this length are sorted in registers by k_resolve
@@ -1246,27 +1385,33 @@ struct ResolveLists {  // cells k_resolve defers, by list length class (indices 
     uint32_t cap;
 };
 
-// Tier 1: one lane per occupied cell.  Lists of up to 8 hits (the common case) are insertion-sorted in registers
-// while they are walked; longer ones are classified and deferred to the cooperative kernels below.
-__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, const HitRec *__restrict__ pool,
-                                                    Counters *c, Materials m, uint4 *out, ResolveLists lists, Params p)
+// Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
+// from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.  Every
+// cell's counter in the dense grid is reset here, which leaves the grid clean for the next voxelization.
+__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, const SortedRec *__restrict__ sorted,
+                                                    uint32_t *grid, Counters *c, Materials m, uint4 *out,
+                                                    ResolveLists lists, Params p)
 {
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
+        grid[((uint64_t) o.cell_hi << 32) | o.cell_lo] = 0;
+        if (o.count > kShortList) {
+            uint32_t *list = o.count <= kMidList ? lists.mid : (o.count <= kLongList ? lists.lng : lists.huge);
+            uint32_t *ctr = o.count <= kMidList ? &c->n_mid : (o.count <= kLongList ? &c->n_long : &c->n_huge);
+            const uint32_t slot = atomicAdd(ctr, 1u);
+            if (slot < lists.cap) list[slot] = i;
+            continue;
+        }
         uint64_t key[kShortList];
         float w[kShortList], u[kShortList], v[kShortList];
-        uint32_t cnt = 0;
-        uint32_t q = o.head;
 #pragma unroll
         for (uint32_t k = 0; k < kShortList; ++k) {
-            if (q) {
-                const HitRec r = pool[q - 1];
-                q = r.next;
-                uint64_t rk = ((uint64_t) r.keyhi << 32) | r.keylo;
-                float rw = r.w, ru = r.u, rv = r.v;
+            if (k < o.count) {
+                const SortedRec r = sorted[o.offset + k];
+                key[k] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                w[k] = r.w; u[k] = r.u; v[k] = r.v;
                 // insert into the sorted prefix [0, k): bubble the new record down from slot k
-                key[k] = rk; w[k] = rw; u[k] = ru; v[k] = rv;
 #pragma unroll
                 for (uint32_t j = k; j > 0; --j) {
                     if (key[j] < key[j - 1]) {
@@ -1277,26 +1422,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
                         t = v[j]; v[j] = v[j - 1]; v[j - 1] = t;
                     }
                 }
-                cnt = k + 1;
             }
-        }
-        if (q) {
-            // more than kShortList hits: count on (bounded) to pick the cooperative tier
-            uint32_t len = kShortList;
-            while (q && len <= kLongList) {
-                q = pool[q - 1].next;
-                ++len;
-            }
-            uint32_t *list = len <= kMidList ? lists.mid : (len <= kLongList ? lists.lng : lists.huge);
-            uint32_t *ctr = len <= kMidList ? &c->n_mid : (len <= kLongList ? &c->n_long : &c->n_huge);
-            const uint32_t slot = atomicAdd(ctr, 1u);
-            if (slot < lists.cap) list[slot] = i;
-            continue;
         }
         CellFold f;
 #pragma unroll
         for (uint32_t k = 0; k < kShortList; ++k)
-            if (k < cnt) f.add(m, p.blend, (uint32_t) (key[k] >> 32), w[k], u[k], v[k]);
+            if (k < o.count) f.add(m, p.blend, (uint32_t) (key[k] >> 32), w[k], u[k], v[k]);
         out[i] = cell_record(o, f.finish(m, p.blend), p);
     }
 }
@@ -1326,20 +1457,21 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_
     }
 }
 
-// Tiers 2 and 3: THREADS lanes cooperate on one cell (a wavefront for lists up to 256, a workgroup up to 2048).
-// Lane 0 walks the list, everyone fetches keys, the pairs are bitonic-sorted in LDS, the payload is gathered in
-// sorted order, and lane 0 replays the fold (which is inherently sequential: float combine is not associative).
+// Tiers 2 and 3: THREADS lanes cooperate on one cell (a wavefront for up to 256 hits, a workgroup for up to 2048).
+// The cell's records are contiguous: keys are loaded coalesced, (key, idx) pairs are bitonic-sorted in LDS, the
+// payload is gathered in sorted order, and lane 0 replays the fold (which is inherently sequential: the float
+// combine is not associative).
 template <uint32_t THREADS, uint32_t CAP>
 __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
                                                             uint32_t *cursor, const Occ *__restrict__ occ,
-                                                            const HitRec *__restrict__ pool, Materials m, uint4 *out,
+                                                            const SortedRec *__restrict__ sorted, Materials m, uint4 *out,
                                                             uint32_t list_cap, Params p)
 {
     __shared__ uint64_t s_key[CAP];
     __shared__ uint32_t s_idx[CAP];
     __shared__ uint32_t s_hi[CAP];
     __shared__ float s_w[CAP], s_u[CAP], s_v[CAP];
-    __shared__ uint32_t s_item, s_n;
+    __shared__ uint32_t s_item;
     const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
     for (;;) {
         __syncthreads();
@@ -1349,22 +1481,14 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
         if (item >= total) break;
         const uint32_t i = list[item];
         const Occ o = occ[i];
-        if (threadIdx.x == 0) {
-            uint32_t q = o.head, n = 0;
-            while (q && n < CAP) {
-                s_idx[n++] = q - 1;
-                q = pool[q - 1].next;
-            }
-            s_n = n;
-        }
-        __syncthreads();
-        const uint32_t n = s_n;
+        const uint32_t n = o.count < CAP ? o.count : CAP;
         uint32_t n_pow2 = 1;
         while (n_pow2 < n) n_pow2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n_pow2; t += THREADS) {
             if (t < n) {
-                const HitRec &r = pool[s_idx[t]];
+                const SortedRec &r = sorted[o.offset + t];
                 s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                s_idx[t] = t;
             }
             else {
                 s_key[t] = ~0ull;
@@ -1374,7 +1498,7 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
         __syncthreads();
         bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, THREADS);
         for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
-            const HitRec &r = pool[s_idx[t]];
+            const SortedRec &r = sorted[o.offset + s_idx[t]];
             s_hi[t] = r.keyhi;
             s_w[t] = r.w;
             s_u[t] = r.u;
@@ -1389,14 +1513,15 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
     }
 }
 
-// Tier 4: lists longer than 2048 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
+// Tier 4: cells with more than 2048 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
 // pairs in a global scratch area; each cell bump-allocates a power-of-two range (scratch holds 2 * cap_hits pairs).
 __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restrict__ list, Counters *c,
-                                                         const Occ *__restrict__ occ, const HitRec *__restrict__ pool,
+                                                         const Occ *__restrict__ occ, const SortedRec *__restrict__ sorted,
                                                          Materials m, uint4 *out, uint64_t *scratch_key,
-                                                         uint32_t *scratch_idx, uint32_t scratch_cap, uint32_t list_cap, Params p)
+                                                         uint32_t *scratch_idx, uint32_t scratch_cap, uint32_t list_cap,
+                                                         Params p)
 {
-    __shared__ uint32_t s_item, s_n, s_base;
+    __shared__ uint32_t s_item, s_base, s_ok;
     const uint32_t total = c->n_huge < list_cap ? c->n_huge : list_cap;
     for (;;) {
         __syncthreads();
@@ -1406,39 +1531,23 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
         if (item >= total) break;
         const uint32_t i = list[item];
         const Occ o = occ[i];
-        if (threadIdx.x == 0) {
-            uint32_t q = o.head, n = 0;
-            while (q) {
-                q = pool[q - 1].next;
-                ++n;
-            }
-            uint32_t n_pow2 = 1;
-            while (n_pow2 < n) n_pow2 <<= 1;
-            s_n = n;
-            s_base = atomicAdd(&c->scratch_used, n_pow2);
-            if ((uint64_t) s_base + n_pow2 > scratch_cap) {
-                s_n = 0;  // scratch too small: the host sees scratch_used > capacity, grows it and re-runs
-            }
-            else {
-                uint32_t *ix = scratch_idx + s_base;
-                q = o.head;
-                for (uint32_t k = 0; k < n; ++k) {
-                    ix[k] = q - 1;
-                    q = pool[q - 1].next;
-                }
-            }
-        }
-        __syncthreads();
-        const uint32_t n = s_n;
-        if (n == 0) continue;
+        const uint32_t n = o.count;
         uint32_t n_pow2 = 1;
         while (n_pow2 < n) n_pow2 <<= 1;
+        if (threadIdx.x == 0) {
+            s_base = atomicAdd(&c->scratch_used, n_pow2);
+            // scratch too small: the host sees scratch_used > capacity, grows it and re-runs
+            s_ok = (uint64_t) s_base + n_pow2 <= scratch_cap ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_ok) continue;
         uint64_t *key = scratch_key + s_base;
         uint32_t *idx = scratch_idx + s_base;
         for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
             if (t < n) {
-                const HitRec &r = pool[idx[t]];
+                const SortedRec &r = sorted[o.offset + t];
                 key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                idx[t] = t;
             }
             else {
                 key[t] = ~0ull;
@@ -1450,7 +1559,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
         if (threadIdx.x == 0) {
             CellFold f;
             for (uint32_t t = 0; t < n; ++t) {
-                const HitRec r = pool[idx[t]];
+                const SortedRec r = sorted[o.offset + idx[t]];
                 f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
             }
             out[i] = cell_record(o, f.finish(m, p.blend), p);
@@ -1487,6 +1596,7 @@ struct o2v_hip_ctx {
     BigLeaf *d_big = nullptr;
     Node *d_nodes[2] = {nullptr, nullptr};
     HitRec *d_pool = nullptr;
+    SortedRec *d_sorted = nullptr;  // cap_hits records
     Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
     uint32_t *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_huge = nullptr;  // cap_vox each
@@ -1498,6 +1608,9 @@ struct o2v_hip_ctx {
     // dense grid of list heads for this context's slab
     uint32_t *d_grid = nullptr;
     uint64_t grid_cells = 0;      // allocated
+    uint8_t *d_brick_dirty = nullptr;   // one flag per brick (padded to 16 bytes)
+    uint32_t *d_dirty_list = nullptr;   // dirty brick ids of the current run
+    uint64_t brick_cap = 0;
     bool grid_dirty = false;
 
     // results of the last run
@@ -1600,43 +1713,47 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
         const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? 3u : 4u);
         if (use_uv) {
             hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
         }
         else {
             hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_pool, p);
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
         }
         O2V_STAGE("k_voxelize");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
 
     {
-        const uint64_t slab_z = (p.zs1 - p.zs0) >> p.ss_shift;
-        const uint64_t n_quads = slab_z * p.G * (p.Gx / 4);
-        const uint64_t iters = (n_quads + (uint64_t) kBlock * kScanUnroll - 1) / ((uint64_t) kBlock * kScanUnroll);
-        hipLaunchKernelGGL(k_scan, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 8u, std::max<uint64_t>(iters, 1))),
-                           dim3(kBlock), 0, s, ctx->d_grid, n_quads, ctx->d_ctr, ctx->d_occ, p);
-        O2V_STAGE("k_scan");
+        const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
+        hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_brick_dirty, ctx->d_ctr, ctx->d_dirty_list, p);
+        O2V_STAGE("k_scan_flags");
+        hipLaunchKernelGGL(k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
+                           ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, p);
+        O2V_STAGE("k_scan_bricks");
+        hipLaunchKernelGGL(k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
+                           ctx->d_sorted, p);
+        O2V_STAGE("k_scatter");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
 
     {
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
         ResolveLists lists{ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
-        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_pool, ctx->d_ctr, m,
-                           ctx->d_out, lists, p);
+        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_sorted, ctx->d_grid,
+                           ctx->d_ctr, m, ctx->d_out, lists, p);
         O2V_STAGE("k_resolve");
         hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, s,
-                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, ctx->d_pool, m,
+                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, ctx->d_sorted, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
         hipLaunchKernelGGL((k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s,
-                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, ctx->d_pool, m,
+                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, ctx->d_sorted, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
         if (ctx->d_scratch_key) {
             hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus), dim3(kBlock), 0, s, ctx->d_list_huge,
-                               ctx->d_ctr, ctx->d_occ, ctx->d_pool, m, ctx->d_out, ctx->d_scratch_key,
+                               ctx->d_ctr, ctx->d_occ, ctx->d_sorted, m, ctx->d_out, ctx->d_scratch_key,
                                ctx->d_scratch_idx, ctx->cap_scratch, p.cap_vox, p);
             O2V_STAGE("k_resolve_huge");
         }
@@ -1696,8 +1813,9 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
-                    ctx->d_pool,  ctx->d_occ,  ctx->d_out,      ctx->d_grid,
-                    ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx};
+                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid,
+                    ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
+                    ctx->d_brick_dirty, ctx->d_dirty_list};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
     for (uint8_t *q : ctx->d_texpix)
@@ -1798,7 +1916,15 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     p.n_tris = ctx->n_tris;
     p.S = (uint32_t) S64;
     p.G = params->resolution;
-    p.Gx = (p.G + 3u) & ~3u;
+    p.NBx = (p.G + kBrickX - 1) / kBrickX;
+    p.NBy = (p.G + kBrickY - 1) / kBrickY;
+    const uint32_t NBz = (z1 - z0 + kBrickZ - 1) / kBrickZ;
+    const uint64_t n_bricks = (uint64_t) p.NBx * p.NBy * NBz;
+    if (n_bricks >= (1ull << 32) / 2) {
+        ctx->err = "slab has too many bricks for 32-bit brick ids; use more z-slabs";
+        return O2V_HIP_ERR_LIMIT;
+    }
+    p.n_bricks = (uint32_t) n_bricks;
     p.ss_shift = ss == 2 ? 1u : 0u;
     p.zs0 = z0 * ss;
     p.zs1 = z1 * ss;
@@ -1810,20 +1936,28 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     p.has_uv = ctx->d_uvs ? 1u : 0u;
     const bool use_uv = ctx->d_uvs && ctx->any_textured;
 
-    // dense grid for the slab; allocated zeroed, kept clean by k_scan
-    const uint64_t cells = (uint64_t) (z1 - z0) * p.G * p.Gx;
+    // dense grid for the slab (bricked, see cell_index) + one dirty flag per brick; allocated zeroed, kept clean
+    // by k_scan_flags / k_scan_bricks
+    const uint64_t cells = n_bricks * kBrickCells;
     ctx->stats.grid_cells = cells;
-    ctx->stats.grid_bytes = cells * sizeof(uint32_t);
+    ctx->stats.grid_bytes = cells * sizeof(uint32_t) + n_bricks;
     if (cells > ctx->grid_cells || !ctx->d_grid) {
-        if (ctx->d_grid) O2V_CHECK(hipFree(ctx->d_grid));
+        for (void *q : {(void *) ctx->d_grid, (void *) ctx->d_brick_dirty, (void *) ctx->d_dirty_list})
+            if (q) O2V_CHECK(hipFree(q));
         ctx->d_grid = nullptr;
+        ctx->d_brick_dirty = nullptr;
+        ctx->d_dirty_list = nullptr;
         ctx->grid_cells = 0;
         O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_grid), cells * sizeof(uint32_t)));
         ctx->grid_cells = cells;
+        ctx->brick_cap = (n_bricks + 15u) & ~15ull;
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_brick_dirty), ctx->brick_cap));
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list), ctx->brick_cap * sizeof(uint32_t)));
         ctx->grid_dirty = true;
     }
     if (ctx->grid_dirty) {
         O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
+        O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
         ctx->grid_dirty = false;
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
@@ -1840,6 +1974,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     ctx->grid_dirty = true;  // until a pass completes (k_scan leaves it clean)
     for (uint32_t pass = 1; pass <= 12; ++pass) {
         int rc;
+        if (pass > 1) {
+            // a pass that overflowed a buffer may have left counters / offsets in cells it could not list
+            O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
+            O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
+        }
         if ((rc = grow(ctx, ctx->d_leaves, ctx->cap_leaves, want_leaves))) return rc;
         if ((rc = grow(ctx, ctx->d_tiles, ctx->cap_tiles, want_tiles))) return rc;
         if ((rc = grow(ctx, ctx->d_big, ctx->cap_big, want_big))) return rc;
@@ -1847,7 +1986,12 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         if ((rc = grow(ctx, ctx->d_nodes[0], cap_n0, want_nodes))) return rc;
         if ((rc = grow(ctx, ctx->d_nodes[1], cap_n1, want_nodes))) return rc;
         ctx->cap_nodes = cap_n0;
-        if ((rc = grow(ctx, ctx->d_pool, ctx->cap_hits, want_hits))) return rc;
+        {
+            uint32_t cap_p = ctx->cap_hits, cap_s = ctx->cap_hits;
+            if ((rc = grow(ctx, ctx->d_pool, cap_p, want_hits))) return rc;
+            if ((rc = grow(ctx, ctx->d_sorted, cap_s, want_hits))) return rc;
+            ctx->cap_hits = cap_p;
+        }
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
@@ -1875,7 +2019,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         if (h.err_flags) {
             ctx->grid_dirty = false;
             ctx->err = (h.err_flags & kErrLeafTooLarge) ? "a leaf's voxel AABB has 2^32 or more candidate voxels"
-                                                        : "subdivision deeper than 15 levels";
+                       : (h.err_flags & kErrDepth)      ? "subdivision deeper than 15 levels"
+                                                        : "a voxel received 2^24 or more hits";
             return O2V_HIP_ERR_LIMIT;
         }
         uint32_t max_nodes = 0;
@@ -1959,19 +2104,17 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
     O2V_CHECK(hipMemcpy(vox.data(), ctx->d_out, vox.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < ctx->n_vox; ++i) {
         if (vox[i].x != x || vox[i].y != y || vox[i].z != z) continue;
-        uint32_t q = occ[i].head, n = 0;
-        while (q && n < max_records) {
-            HitRec r;
-            O2V_CHECK(hipMemcpy(&r, ctx->d_pool + (q - 1), sizeof(HitRec), hipMemcpyDeviceToHost));
-            uint32_t *o = out + n * 6;
-            o[0] = r.keyhi;
-            o[1] = r.keylo;
-            std::memcpy(&o[2], &r.w, 4);
-            std::memcpy(&o[3], &r.u, 4);
-            std::memcpy(&o[4], &r.v, 4);
-            o[5] = q - 1;
-            q = r.next;
-            ++n;
+        const uint32_t n = occ[i].count < max_records ? occ[i].count : max_records;
+        std::vector<SortedRec> recs(n);
+        if (n) O2V_CHECK(hipMemcpy(recs.data(), ctx->d_sorted + occ[i].offset, n * sizeof(SortedRec), hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < n; ++k) {
+            uint32_t *o = out + k * 6;
+            o[0] = recs[k].keyhi;
+            o[1] = recs[k].keylo;
+            std::memcpy(&o[2], &recs[k].w, 4);
+            std::memcpy(&o[3], &recs[k].u, 4);
+            std::memcpy(&o[4], &recs[k].v, 4);
+            o[5] = occ[i].offset + k;
         }
         *out_count = n;
         break;

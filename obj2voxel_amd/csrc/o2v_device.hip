@@ -114,7 +114,7 @@ struct Counters {
     uint32_t n_vox, batch_cursor, err_flags, pad0;
     uint32_t n_mid, n_long, n_huge, scratch_used;
     uint32_t n_dirty, n_sorted, pad4[2];
-    uint32_t cursor_mid, cursor_long, cursor_huge, pad3;
+    uint32_t cursor_mid, cursor_long, cursor_huge, n_lane;
     uint32_t n_nodes[kMaxRounds + 1];
     uint32_t pad1[3];
     unsigned long long n_candidates, n_hits;
@@ -1376,12 +1376,13 @@ __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const 
     return make_uint4(x, y, z + p.zo0, argb);
 }
 
-constexpr uint32_t kShortList = 8;     // lists up to this length are sorted in registers by k_resolve
+constexpr uint32_t kShortList = 8;     // cells with up to this many hits are sorted in registers by k_resolve
+constexpr uint32_t kLaneList = 32;     // up to this: still one lane per cell, insertion sort in a private LDS column
 constexpr uint32_t kMidList = 256;     // up to this: one wavefront per cell, LDS bitonic sort
 constexpr uint32_t kLongList = 2048;   // up to this: one workgroup per cell, LDS bitonic sort; beyond: global sort
 
-struct ResolveLists {  // cells k_resolve defers, by list length class (indices into occ[])
-    uint32_t *mid, *lng, *huge;
+struct ResolveLists {  // cells k_resolve defers, by hit count class (indices into occ[])
+    uint32_t *lane, *mid, *lng, *huge;
     uint32_t cap;
 };
 
@@ -1397,10 +1398,23 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         const Occ o = occ[i];
         grid[((uint64_t) o.cell_hi << 32) | o.cell_lo] = 0;
         if (o.count > kShortList) {
-            uint32_t *list = o.count <= kMidList ? lists.mid : (o.count <= kLongList ? lists.lng : lists.huge);
-            uint32_t *ctr = o.count <= kMidList ? &c->n_mid : (o.count <= kLongList ? &c->n_long : &c->n_huge);
-            const uint32_t slot = atomicAdd(ctr, 1u);
-            if (slot < lists.cap) list[slot] = i;
+            // deferred to a cooperative tier; one atomic per wavefront and class, not per cell
+            const uint32_t cls = o.count <= kLaneList ? 0u : (o.count <= kMidList ? 1u : (o.count <= kLongList ? 2u : 3u));
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const unsigned long long mk = __ballot(cls == k);
+                if (cls == k) {
+                    uint32_t *list = k == 0 ? lists.lane : (k == 1 ? lists.mid : (k == 2 ? lists.lng : lists.huge));
+                    uint32_t *ctr = k == 0 ? &c->n_lane : (k == 1 ? &c->n_mid : (k == 2 ? &c->n_long : &c->n_huge));
+                    const uint32_t leader = (uint32_t) __ffsll((long long) mk) - 1u;
+                    const uint32_t lane = threadIdx.x & 63u;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(ctr, (uint32_t) __popcll(mk));
+                    base = __shfl(base, (int) leader, 64);
+                    const uint32_t slot = base + (uint32_t) __popcll(mk & ((1ull << lane) - 1ull));
+                    if (slot < lists.cap) list[slot] = i;
+                }
+            }
             continue;
         }
         uint64_t key[kShortList];
@@ -1428,6 +1442,41 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
 #pragma unroll
         for (uint32_t k = 0; k < kShortList; ++k)
             if (k < o.count) f.add(m, p.blend, (uint32_t) (key[k] >> 32), w[k], u[k], v[k]);
+        out[i] = cell_record(o, f.finish(m, p.blend), p);
+    }
+}
+
+// Tier 2: still one lane per cell, for 9..32 hits.  Each lane insertion-sorts (key, record index) in a private LDS
+// column (entry-major layout: lane-contiguous, conflict-free), then replays its cell from the cached records.
+__global__ __launch_bounds__(64) void k_resolve_lane(const uint32_t *__restrict__ list, const Counters *c,
+                                                     const Occ *__restrict__ occ, const SortedRec *__restrict__ sorted,
+                                                     Materials m, uint4 *out, uint32_t list_cap, Params p)
+{
+    __shared__ uint64_t s_key[kLaneList][64];
+    __shared__ uint32_t s_idx[kLaneList][64];
+    const uint32_t total = c->n_lane < list_cap ? c->n_lane : list_cap;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t item = blockIdx.x * 64u + lane; item < total; item += gridDim.x * 64u) {
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count < kLaneList ? o.count : kLaneList;
+        for (uint32_t k = 0; k < n; ++k) {
+            const SortedRec &r = sorted[o.offset + k];
+            const uint64_t key = ((uint64_t) r.keyhi << 32) | r.keylo;
+            uint32_t j = k;
+            while (j > 0 && s_key[j - 1][lane] > key) {
+                s_key[j][lane] = s_key[j - 1][lane];
+                s_idx[j][lane] = s_idx[j - 1][lane];
+                --j;
+            }
+            s_key[j][lane] = key;
+            s_idx[j][lane] = k;
+        }
+        CellFold f;
+        for (uint32_t t = 0; t < n; ++t) {
+            const SortedRec r = sorted[o.offset + s_idx[t][lane]];
+            f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
+        }
         out[i] = cell_record(o, f.finish(m, p.blend), p);
     }
 }
@@ -1505,10 +1554,51 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
             s_v[t] = r.v;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            CellFold f;
-            for (uint32_t t = 0; t < n; ++t) f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
-            out[i] = cell_record(o, f.finish(m, p.blend), p);
+        if (p.blend) {
+            // BLEND: the weighted mean is folded in the reference's order (float mix is not associative)
+            if (threadIdx.x == 0) {
+                CellFold f;
+                for (uint32_t t = 0; t < n; ++t) f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
+                out[i] = cell_record(o, f.finish(m, p.blend), p);
+            }
+        }
+        else {
+            // MAX: `new.w > existing.w ? new : existing` over ascending (sub-voxel, triangle) groups keeps the first
+            // group with the greatest weight, which is a true reduction: every group is folded by the lane at its
+            // first record (leaves of one triangle, in order), then the groups are max-reduced with ties to the
+            // lower position.
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+                if (t == 0 || s_hi[t] != s_hi[t - 1]) {
+                    WUv acc{s_w[t], s_u[t], s_v[t]};
+                    uint32_t j = t + 1;
+                    for (; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                    // weights are non-negative, so their bit patterns order like the values
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            if (THREADS > 64) {
+                __syncthreads();
+                if ((threadIdx.x & 63u) == 0) s_key[threadIdx.x >> 6] = best;  // s_key is free after the sort
+                __syncthreads();
+                best = s_key[0];
+                for (uint32_t wv = 1; wv < THREADS / 64; ++wv) best = s_key[wv] > best ? s_key[wv] : best;
+            }
+            if (threadIdx.x == 0) {
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                // rebuild the winning group's uv (needed for a textured winner) and emit
+                WUv acc{s_w[t], s_u[t], s_v[t]};
+                for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                float cr, cg, cb;
+                color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+            }
         }
     }
 }
@@ -1599,7 +1689,7 @@ struct o2v_hip_ctx {
     SortedRec *d_sorted = nullptr;  // cap_hits records
     Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
-    uint32_t *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_huge = nullptr;  // cap_vox each
+    uint32_t *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_huge = nullptr;  // cap_vox each
     uint64_t *d_scratch_key = nullptr;  // tier-4 resolve scratch, allocated on first need
     uint32_t *d_scratch_idx = nullptr;
     uint32_t cap_scratch = 0;
@@ -1739,10 +1829,13 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
 
     {
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
-        ResolveLists lists{ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
+        ResolveLists lists{ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
         hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_sorted, ctx->d_grid,
                            ctx->d_ctr, m, ctx->d_out, lists, p);
         O2V_STAGE("k_resolve");
+        hipLaunchKernelGGL(k_resolve_lane, dim3((uint32_t) ctx->num_cus * 4u), dim3(64), 0, s, ctx->d_list_lane, ctx->d_ctr,
+                           ctx->d_occ, ctx->d_sorted, m, ctx->d_out, p.cap_vox, p);
+        O2V_STAGE("k_resolve_lane");
         hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, s,
                            ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, ctx->d_sorted, m,
                            ctx->d_out, p.cap_vox, p);
@@ -1814,7 +1907,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
                     ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid,
-                    ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
+                    ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
@@ -1995,7 +2088,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
-        for (uint32_t **lp : {&ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_huge}) {
+        for (uint32_t **lp : {&ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_huge}) {
             uint32_t cap_l = ctx->cap_vox;
             if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;
         }
@@ -2118,6 +2211,24 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
         }
         *out_count = n;
         break;
+    }
+    return O2V_HIP_OK;
+}
+
+// Debugging aid: histogram of hits per occupied cell of the last run; bucket b counts cells with 2^(b-1) < hits <= 2^b
+// (bucket 0: exactly one hit), 32 buckets.
+int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32)
+{
+    if (!ctx || !out32) return O2V_HIP_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < 32; ++i) out32[i] = 0;
+    if (!ctx->n_vox) return O2V_HIP_OK;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    std::vector<Occ> occ(ctx->n_vox);
+    O2V_CHECK(hipMemcpy(occ.data(), ctx->d_occ, occ.size() * sizeof(Occ), hipMemcpyDeviceToHost));
+    for (const Occ &o : occ) {
+        uint32_t b = 0;
+        while ((1u << b) < o.count && b < 31) ++b;
+        out32[b]++;
     }
     return O2V_HIP_OK;
 }

@@ -1259,13 +1259,31 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ p
                                                     const Counters *c, SortedRec *sorted, Params p)
 {
     const uint32_t n = c->n_hits_reserved < p.cap_hits ? c->n_hits_reserved : p.cap_hits;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    // XCD-aware work split (speed only): workgroup b runs on XCD b % 8 and the eight L2s are not coherent, so each
+    // XCD takes one contiguous eighth of the pool.  Pool order is emission order, i.e. spatially coherent, so the
+    // destination lines of one eighth are written (and write-combined) by a single L2 instead of partially by all.
+    constexpr uint32_t kXcds = 8;
+    const uint32_t xcd = blockIdx.x % kXcds, local_block = blockIdx.x / kXcds, blocks_per_xcd = gridDim.x / kXcds;
+    const uint32_t per = ((n + kXcds - 1) / kXcds + kBlock - 1) / kBlock * kBlock;
+    const uint32_t lo = xcd * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t i = lo + local_block * kBlock + threadIdx.x; i < hi; i += blocks_per_xcd * kBlock) {
         const HitRec r = pool[i];
         if (r.brick == kHoleBrick) continue;
         const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
         const uint32_t pos = grid[cell] + (r.local_rank & (kMaxRank - 1u));
         if (pos < p.cap_hits) sorted[pos] = SortedRec{r.keyhi, r.keylo, r.w, r.u, r.v, 0u};
     }
+}
+
+// Zeroes the dirty bricks (whole 1 KiB bricks, one 16-byte store per lane): leaves the dense grid clean for the next
+// voxelization.  Runs after k_scatter has read the per-cell offsets.
+__global__ __launch_bounds__(kBlock) void k_reset_bricks(uint32_t *grid, const uint32_t *__restrict__ dirty_list,
+                                                         const Counters *c)
+{
+    const uint32_t n_dirty = c->n_dirty;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t item = blockIdx.x * (kBlock / 64) + wave; item < n_dirty; item += gridDim.x * (kBlock / 64))
+        reinterpret_cast<uint4 *>(grid + (uint64_t) dirty_list[item] * kBrickCells)[lane] = make_uint4(0, 0, 0, 0);
 }
 
 // ---- K3: resolve ---------------------------------------------------------------------------------------------
@@ -1387,16 +1405,15 @@ struct ResolveLists {  // cells k_resolve defers, by hit count class (indices in
 };
 
 // Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
-// from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.  Every
-// cell's counter in the dense grid is reset here, which leaves the grid clean for the next voxelization.
+// from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
 __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, const SortedRec *__restrict__ sorted,
-                                                    uint32_t *grid, Counters *c, Materials m, uint4 *out,
-                                                    ResolveLists lists, Params p)
+                                                    Counters *c, Materials m, uint4 *out, ResolveLists lists, Params p)
 {
+    __shared__ uint64_t s_key[kShortList][kBlock];
+    __shared__ float s_w[kShortList][kBlock], s_u[kShortList][kBlock], s_v[kShortList][kBlock];
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
-        grid[((uint64_t) o.cell_hi << 32) | o.cell_lo] = 0;
         if (o.count > kShortList) {
             // deferred to a cooperative tier; one atomic per wavefront and class, not per cell
             const uint32_t cls = o.count <= kLaneList ? 0u : (o.count <= kMidList ? 1u : (o.count <= kLongList ? 2u : 3u));
@@ -1417,31 +1434,33 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
             }
             continue;
         }
-        uint64_t key[kShortList];
-        float w[kShortList], u[kShortList], v[kShortList];
+        // all loads are issued before anything is consumed (independent round trips overlap), then the records are
+        // insertion-sorted into this lane's private LDS column and folded by a rolled loop
+        SortedRec r[kShortList];
+#pragma unroll
+        for (uint32_t k = 0; k < kShortList; ++k) r[k] = sorted[o.offset + (k < o.count ? k : 0u)];
 #pragma unroll
         for (uint32_t k = 0; k < kShortList; ++k) {
             if (k < o.count) {
-                const SortedRec r = sorted[o.offset + k];
-                key[k] = ((uint64_t) r.keyhi << 32) | r.keylo;
-                w[k] = r.w; u[k] = r.u; v[k] = r.v;
-                // insert into the sorted prefix [0, k): bubble the new record down from slot k
-#pragma unroll
-                for (uint32_t j = k; j > 0; --j) {
-                    if (key[j] < key[j - 1]) {
-                        uint64_t tk = key[j]; key[j] = key[j - 1]; key[j - 1] = tk;
-                        float t;
-                        t = w[j]; w[j] = w[j - 1]; w[j - 1] = t;
-                        t = u[j]; u[j] = u[j - 1]; u[j - 1] = t;
-                        t = v[j]; v[j] = v[j - 1]; v[j - 1] = t;
-                    }
+                const uint64_t key = ((uint64_t) r[k].keyhi << 32) | r[k].keylo;
+                uint32_t j = k;
+                while (j > 0 && s_key[j - 1][threadIdx.x] > key) {
+                    s_key[j][threadIdx.x] = s_key[j - 1][threadIdx.x];
+                    s_w[j][threadIdx.x] = s_w[j - 1][threadIdx.x];
+                    s_u[j][threadIdx.x] = s_u[j - 1][threadIdx.x];
+                    s_v[j][threadIdx.x] = s_v[j - 1][threadIdx.x];
+                    --j;
                 }
+                s_key[j][threadIdx.x] = key;
+                s_w[j][threadIdx.x] = r[k].w;
+                s_u[j][threadIdx.x] = r[k].u;
+                s_v[j][threadIdx.x] = r[k].v;
             }
         }
         CellFold f;
-#pragma unroll
-        for (uint32_t k = 0; k < kShortList; ++k)
-            if (k < o.count) f.add(m, p.blend, (uint32_t) (key[k] >> 32), w[k], u[k], v[k]);
+        for (uint32_t t = 0; t < o.count; ++t)
+            f.add(m, p.blend, (uint32_t) (s_key[t][threadIdx.x] >> 32), s_w[t][threadIdx.x], s_u[t][threadIdx.x],
+                  s_v[t][threadIdx.x]);
         out[i] = cell_record(o, f.finish(m, p.blend), p);
     }
 }
@@ -1824,14 +1843,17 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
         hipLaunchKernelGGL(k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            ctx->d_sorted, p);
         O2V_STAGE("k_scatter");
+        hipLaunchKernelGGL(k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
+                           ctx->d_dirty_list, ctx->d_ctr);
+        O2V_STAGE("k_reset_bricks");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
 
     {
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
         ResolveLists lists{ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
-        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_sorted, ctx->d_grid,
-                           ctx->d_ctr, m, ctx->d_out, lists, p);
+        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_sorted, ctx->d_ctr, m,
+                           ctx->d_out, lists, p);
         O2V_STAGE("k_resolve");
         hipLaunchKernelGGL(k_resolve_lane, dim3((uint32_t) ctx->num_cus * 4u), dim3(64), 0, s, ctx->d_list_lane, ctx->d_ctr,
                            ctx->d_occ, ctx->d_sorted, m, ctx->d_out, p.cap_vox, p);

@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path on a single-GPU box)")
+    ap.add_argument("--same-device", action="store_true", help="debugging: every rank uses GPU 0")
     ap.add_argument("--resolution", type=int, default=0, help="override (debugging only; invalidates the metric)")
     ap.add_argument("--nv", type=int, default=0, help="override (debugging only; invalidates the metric)")
     args = ap.parse_args()
@@ -59,8 +61,12 @@ def main():
     dist = None
     if n > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = 0 if args.same_device else local_rank
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from obj2voxel_amd import hip, meshes, slab as slabs
 
@@ -73,7 +79,7 @@ def main():
     T = len(verts)
     z0, z1 = slabs.slab_range(rank, n, res)
 
-    dv = hip.DeviceVoxelizer(local_rank if n > 1 else 0)
+    dv = hip.DeviceVoxelizer(local_rank if (n > 1 and not args.same_device) else 0)
     dv.set_triangles(verts)
 
     def barrier():
@@ -100,22 +106,25 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = dv.stats()
 
-    total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed, device="cuda" if dist is not None else None)
+    total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed,
+                                                  device="cuda" if (dist is not None and args.backend == "nccl") else None)
 
     if rank == 0:
         ms_per_step = max_elapsed / args.steps * 1e3
         value = total_voxels / (max_elapsed / args.steps) / 1e6
         stage_avg = {k: stage_sum[k] / args.steps for k in stage_names}
         # dominant kernel and its algorithmic bytes per launch (DESIGN.md section "Kernels and rooflines")
-        L, tiles, H, V, cells = stats["leaves"], stats["tiles"], stats["hits"], stats["voxels"], stats["grid_cells"]
+        L, tiles, H, V = stats["leaves"], stats["tiles"], stats["hits"], stats["voxels"]
+        B, D, slots = stats["bricks"], stats["dirty_bricks"], stats["pool_slots"]
+        # algorithmic bytes per launch of each stage
         alg_bytes = {
-            "expand_ms": 60 * T + 96 * L + 8 * tiles,
-            "voxelize_ms": 96 * L + 8 * tiles + 28 * H,
-            "scan_ms": 4 * cells + 16 * V,
-            "resolve_ms": 12 * V + 24 * H + 16 * V,
+            "expand_ms": 36 * T + 96 * L + 8 * tiles,
+            "voxelize_ms": 96 * L + 8 * tiles + (32 + 4 + 1) * H,
+            "scan_ms": B + 1024 * D + (16 + 4) * V + 32 * slots + (4 + 24) * H + 1024 * D,
+            "resolve_ms": 16 * V + 24 * H + 16 * V,
         }
-        kernel_of = {"expand_ms": "k_expand_roots+k_expand_nodes", "voxelize_ms": "k_voxelize", "scan_ms": "k_scan",
-                     "resolve_ms": "k_resolve"}
+        kernel_of = {"expand_ms": "k_expand_roots+k_expand_nodes", "voxelize_ms": "k_voxelize",
+                     "scan_ms": "k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks", "resolve_ms": "k_resolve*"}
         dom = max(alg_bytes, key=lambda k: stage_avg[k])
         achieved = alg_bytes[dom] / (stage_avg[dom] * 1e-3) / 1e9
         traffic = None
@@ -129,7 +138,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes": alg_bytes[dom], "kernel_ms": round(stage_avg[dom], 4)}
         # the fixed whole-pipeline numerator of SURVEY.md section 8d: 8*G^3 + 16*V + 76*T
-        b_alg = 8 * cells + 16 * V + 76 * T
+        z0_, z1_ = slabs.slab_range(0, n, res)
+        b_alg = 8 * n * (z1_ - z0_) * res * res + 16 * total_voxels + 76 * T
         pipeline = {"b_alg_bytes": b_alg, "device_ms": round(stage_avg["total_ms"], 4),
                     "gbs": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

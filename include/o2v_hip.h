@@ -57,8 +57,8 @@ typedef struct {
 typedef struct {
     float bounds_ms;     /* K0  mesh bounds reduce + transform setup */
     float expand_ms;     /* K1  transform, classify, exact subdivision into leaves and tiles */
-    float voxelize_ms;   /* K2  AABB walk + plane cull + six-plane clip + hit append (dense-grid atomics) */
-    float scan_ms;       /* K5a dense grid scan, compaction of occupied cells, grid reset */
+    float voxelize_ms;   /* K2  AABB walk + plane cull + SAT pre-test + six-plane clip + hit append (dense-grid atomics) */
+    float scan_ms;       /* K5  dirty-brick scan, occupied-cell compaction + offsets, hit scatter, brick reset */
     float resolve_ms;    /* K3  per-cell ordered replay (MAX / BLEND), colour lookup, ARGB pack */
     float total_ms;      /* first event to last event */
     uint32_t passes;     /* 1, or more if a device buffer had to grow and the pipeline was re-run */
@@ -72,8 +72,11 @@ typedef struct {
     uint64_t candidates;  /* (leaf, voxel) pairs examined */
     uint64_t hits;        /* (leaf, voxel) pairs with non-zero weight */
     uint64_t voxels;      /* occupied output voxels */
-    uint64_t grid_cells;  /* dense grid cells owned by this context */
-    uint64_t grid_bytes;  /* bytes of the dense grid allocation */
+    uint64_t grid_cells;  /* dense grid cells owned by this context (bricks of 16x4x4, padded) */
+    uint64_t grid_bytes;  /* bytes of the dense grid allocation incl. the per-brick dirty flags */
+    uint64_t bricks;      /* bricks of the slab */
+    uint64_t dirty_bricks;/* bricks that received at least one hit */
+    uint64_t pool_slots;  /* hit-pool slots reserved (hits + chunk slack) */
 } o2v_hip_stats;
 
 int o2v_hip_device_count(void);

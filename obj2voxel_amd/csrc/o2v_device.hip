@@ -2166,6 +2166,9 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->stats.candidates = h.n_candidates;
             ctx->stats.hits = h.n_hits;
             ctx->stats.voxels = h.n_vox;
+            ctx->stats.bricks = p.n_bricks;
+            ctx->stats.dirty_bricks = h.n_dirty;
+            ctx->stats.pool_slots = h.n_hits_reserved;
             std::memcpy(ctx->xform, h.xform, sizeof(ctx->xform));
             float ms[5];
             for (int i = 0; i < 5; ++i) O2V_CHECK(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));

@@ -1788,7 +1788,7 @@ bool debug_sync_enabled()
     } while (0)
 
 // One pass of the pipeline with the current capacities.  Fills h_ctr; the caller checks for overflow.
-int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
+int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 {
     hipStream_t s = ctx->stream;
     const uint32_t persistent = (uint32_t) ctx->num_cus * 8u;
@@ -1808,7 +1808,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv)
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
                        ctx->d_big, ctx->d_nodes[0], p);
     O2V_STAGE("k_expand_roots");
-    for (uint32_t round = 0; round < kMaxRounds; ++round) {
+    for (uint32_t round = 0; round < n_rounds; ++round) {
         hipLaunchKernelGGL(k_expand_nodes, dim3(persistent), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
         O2V_STAGE("k_expand_nodes");
@@ -2086,7 +2086,12 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     uint64_t want_scratch = ctx->cap_scratch;
     uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
 
-    ctx->grid_dirty = true;  // until a pass completes (k_scan leaves it clean)
+    // Subdivision rounds to launch: every round halves a node's extents and a node becomes a leaf once its voxel
+    // AABB volume is below 512, so ceil(log2(S)) rounds cover the usual case; if a node is still waiting after the
+    // last round the pass is repeated with the full kMaxRounds (nothing is lost, only re-run).
+    uint32_t n_rounds = 4;
+    while ((1u << n_rounds) < p.S && n_rounds < kMaxRounds) ++n_rounds;
+    ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
     for (uint32_t pass = 1; pass <= 12; ++pass) {
         int rc;
         if (pass > 1) {
@@ -2128,7 +2133,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         p.cap_hits = ctx->cap_hits;
         p.cap_vox = ctx->cap_vox;
 
-        if ((rc = run_pass(ctx, p, use_uv))) return rc;
+        if ((rc = run_pass(ctx, p, use_uv, n_rounds))) return rc;
         const Counters &h = *ctx->h_ctr;
         ctx->timings.passes = pass;
         if (h.err_flags) {
@@ -2153,6 +2158,10 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(max_nodes, ctx->cap_nodes, want_nodes);
         need(h.n_hits_reserved, ctx->cap_hits, want_hits);
         need(h.n_vox, ctx->cap_vox, want_vox);
+        if (n_rounds < kMaxRounds && h.n_nodes[n_rounds] != 0) {
+            n_rounds = kMaxRounds;  // unusually deep subdivision
+            again = true;
+        }
         if (!again && h.n_huge && (!ctx->d_scratch_key || h.scratch_used > ctx->cap_scratch)) {
             // some cell holds more than kLongList hits: the global-memory sort tier needs its scratch area
             want_scratch = std::max<uint64_t>(2ull * ctx->cap_hits, (uint64_t) h.scratch_used + 1024);

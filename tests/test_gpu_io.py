@@ -1,0 +1,132 @@
+"""The steps either side of the hot path: file inputs (binary STL, OBJ + MTL +
+PNG) and list-format outputs (VL32, PLY, XYZRGB; file and memory), end to end through the public C API, checked
+against the oracle fed with the same triangles. Formats: reference README.adoc:210-264."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+pytestmark = pytest.mark.gpu
+
+
+def _png_rgb(rgb):
+    h, w, _ = rgb.shape
+    raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def _run_files(a, in_path, out_spec, res, strategy=0):
+    """out_spec: ('file', path) or ('memory', type). Returns (error code, bytes)."""
+    inst = a.obj2voxel_alloc()
+    # the API borrows the path strings until voxelize (reference obj2voxel.cpp:714-720): keep them alive
+    in_bytes, out_bytes = str(in_path).encode(), str(out_spec[1]).encode()
+    a.obj2voxel_set_input_file(inst, in_bytes, None)
+    if out_spec[0] == "file":
+        a.obj2voxel_set_output_file(inst, out_bytes, None)
+    else:
+        a.obj2voxel_set_output_memory(inst, out_bytes)
+    a.obj2voxel_set_resolution(inst, res)
+    a.obj2voxel_set_color_strategy(inst, strategy)
+    err = a.obj2voxel_voxelize(inst)
+    data = b""
+    if out_spec[0] == "memory" and err == 0:
+        size = C.c_size_t(0)
+        ptr = a.obj2voxel_get_output_memory(inst, C.byref(size))
+        data = bytes(np.ctypeslib.as_array(ptr, shape=(size.value,))) if size.value else b""
+    a.obj2voxel_free(inst)
+    if out_spec[0] == "file" and err == 0:
+        data = open(out_spec[1], "rb").read()
+    return err, data
+
+
+def _vl32_to_voxels(data):
+    return np.frombuffer(data, dtype=">u4").astype(np.uint32).reshape(-1, 4)
+
+
+def test_binary_stl_to_vl32_ply_xyzrgb(tmp_path, oracle):
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    v = meshes.uv_sphere(9)
+    stl = tmp_path / "sphere.stl"
+    with open(stl, "wb") as f:
+        f.write(b"binary stl".ljust(80, b" ") + struct.pack("<I", len(v)))
+        for t in v:
+            f.write(struct.pack("<12fH", 0, 0, 0, *t.tolist(), 0))
+    want = meshes.sorted_voxels(oracle.voxelize(v, 72))
+
+    err, data = _run_files(a, stl, ("file", tmp_path / "out.vl32"), 72)
+    assert err == capi.ERR_OK and len(data) == 16 * len(want)
+    assert np.array_equal(meshes.sorted_voxels(_vl32_to_voxels(data)), want)
+
+    err, data = _run_files(a, stl, ("memory", "ply"), 72)
+    assert err == capi.ERR_OK and len(data) == 300 + 16 * len(want)   # README.adoc:236-237
+    header = data[:300].decode()
+    assert header.startswith("ply\nformat binary_big_endian 1.0\nelement vertex ") and header.endswith("end_header\n")
+    assert int(header.split("element vertex ")[1].split("\n")[0]) == len(want)
+    assert np.array_equal(meshes.sorted_voxels(_vl32_to_voxels(data[300:])), want)
+
+    err, data = _run_files(a, stl, ("file", tmp_path / "out.xyzrgb"), 72)
+    assert err == capi.ERR_OK
+    rows = np.array([[int(t) for t in line.split()] for line in data.decode().splitlines()], dtype=np.uint32)
+    argb = 0xFF000000 | (rows[:, 3] << 16) | (rows[:, 4] << 8) | rows[:, 5]
+    got = np.concatenate([rows[:, :3], argb[:, None]], axis=1).astype(np.uint32)
+    assert np.array_equal(meshes.sorted_voxels(got), want)
+
+    err, _ = _run_files(a, stl, ("memory", "qef"), 72)        # palette formats are not built
+    assert err == capi.ERR_OPEN_OUTPUT
+    a.obj2voxel_set_log_level(capi.LOG_INFO)
+
+
+def test_obj_with_materials_and_png_texture(tmp_path, oracle):
+    """OBJ subset the reference consumes through tinyobjloader (src/io.cpp:244-312): v / vt / f, usemtl with Kd
+    (UNTEXTURED) or map_Kd (TEXTURED), faces without material (MATERIALLESS), polygon fan triangulation."""
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    v, uv = meshes.uv_sphere(8, with_uv=True)
+    T = len(v)
+    tex = meshes.checker_texture(32, 4)
+    (tmp_path / "tex.png").write_bytes(_png_rgb(tex))
+    (tmp_path / "m.mtl").write_text("newmtl red\nKd 0.8 0.25 0.125\nnewmtl checker\nKd 1 1 1\nmap_Kd tex.png\n")
+    kind = np.arange(T) % 3          # 0: no material, 1: red, 2: textured
+    lines = ["mtllib m.mtl"]
+    for t in range(T):
+        for k in range(3):
+            lines.append("v %r %r %r" % tuple(float(x) for x in v[t, k * 3:k * 3 + 3]))
+            lines.append("vt %r %r" % tuple(float(x) for x in uv[t, k * 2:k * 2 + 2]))
+    cur = None
+    for t in range(T):
+        want_m = [None, "red", "checker"][kind[t]]
+        if want_m != cur and want_m is not None:
+            lines.append("usemtl " + want_m)
+            cur = want_m
+        i = 3 * t + 1
+        if kind[t] == 0:
+            continue  # material-less faces must come before the first usemtl; emitted below
+        lines.append(f"f {i}/{i} {i + 1}/{i + 1} {i + 2}/{i + 2}" if kind[t] == 2 else f"f {i} {i + 1} {i + 2}")
+    # faces without a material first (OBJ has no "unset material" statement)
+    head = [f"f {3 * t + 1} {3 * t + 2} {3 * t + 3}" for t in range(T) if kind[t] == 0]
+    obj = tmp_path / "mesh.obj"
+    obj.write_text("\n".join(lines[:1 + 6 * T] + head + lines[1 + 6 * T:]) + "\n")
+
+    # the same triangle sequence for the oracle: material-less first, then in file order
+    order = [t for t in range(T) if kind[t] == 0] + [t for t in range(T) if kind[t] != 0]
+    types = np.array([[1, 2, 3][kind[t]] for t in order], np.uint32)
+    colors = np.tile(np.array([0.8, 0.25, 0.125], np.float32), (T, 1))
+    uvs = np.array([uv[t] if kind[t] == 2 else np.zeros(6, np.float32) for t in order], np.float32)
+    argb = np.concatenate([np.full((32, 32, 1), 255, np.uint8), tex], axis=2)
+    want = oracle.voxelize(v[order], 80, uvs=uvs, types=types, colors=colors, texids=np.zeros(T, np.int32),
+                           textures=[(argb, 1)], strategy=1)
+    err, data = _run_files(a, obj, ("memory", "vl32"), 80, strategy=1)
+    a.obj2voxel_set_log_level(capi.LOG_INFO)
+    assert err == capi.ERR_OK
+    assert np.array_equal(meshes.sorted_voxels(_vl32_to_voxels(data)), meshes.sorted_voxels(want))

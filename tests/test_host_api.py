@@ -97,7 +97,8 @@ def test_empty_model_finalizes_sinks_without_a_gpu(a, tmp_path):
         if kind == "memory":
             a.obj2voxel_set_output_memory(inst, b"ply")
         elif kind == "file":
-            a.obj2voxel_set_output_file(inst, str(path).encode(), None)
+            path_bytes = str(path).encode()  # borrowed by the API until voxelize
+            a.obj2voxel_set_output_file(inst, path_bytes, None)
         else:
             a.obj2voxel_set_output_callback(inst, out.callback, None)
         assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
@@ -121,7 +122,8 @@ def test_empty_model_finalizes_sinks_without_a_gpu(a, tmp_path):
 def test_unopenable_files_map_to_error_codes(a, tmp_path):
     from obj2voxel_amd import capi
     inst = a.obj2voxel_alloc()
-    a.obj2voxel_set_input_file(inst, str(tmp_path / "missing.stl").encode(), None)
+    missing = str(tmp_path / "missing.stl").encode()
+    a.obj2voxel_set_input_file(inst, missing, None)
     a.obj2voxel_set_output_memory(inst, b"vl32")
     a.obj2voxel_set_resolution(inst, 8)
     assert a.obj2voxel_voxelize(inst) == capi.ERR_OPEN_INPUT
@@ -129,7 +131,8 @@ def test_unopenable_files_map_to_error_codes(a, tmp_path):
     inst = a.obj2voxel_alloc()
     inp = capi.TriangleInput(np.zeros((0, 9), np.float32))
     a.obj2voxel_set_input_callback(inst, inp.callback, None)
-    a.obj2voxel_set_output_file(inst, str(tmp_path / "no_such_dir" / "x.vl32").encode(), None)
+    bad_out = str(tmp_path / "no_such_dir" / "x.vl32").encode()
+    a.obj2voxel_set_output_file(inst, bad_out, None)
     a.obj2voxel_set_resolution(inst, 8)
     assert a.obj2voxel_voxelize(inst) == capi.ERR_OPEN_OUTPUT
     a.obj2voxel_free(inst)

@@ -178,6 +178,48 @@ std::unique_ptr<VoxelSink> open_output(obj2voxel_instance &inst)
     }
 }
 
+// ---- process-wide device context cache ---------------------------------------------------------------------
+struct CachedContext {
+    o2v_hip_ctx *ctx;
+    int device;
+    bool from_cache;
+};
+std::mutex g_ctx_mutex;
+o2v_hip_ctx *g_cached_ctx = nullptr;  // intentionally never destroyed at exit (HIP may already be torn down)
+int g_cached_device = -1;
+bool g_cached_busy = false;
+
+CachedContext acquire_context(int device)
+{
+    {
+        std::lock_guard<std::mutex> lock{g_ctx_mutex};
+        if (g_cached_ctx && !g_cached_busy && g_cached_device == device) {
+            g_cached_busy = true;
+            return {g_cached_ctx, device, true};
+        }
+    }
+    o2v_hip_ctx *ctx = nullptr;
+    if (o2v_hip_create(device, &ctx) != O2V_HIP_OK) return {nullptr, device, false};
+    return {ctx, device, false};
+}
+
+void release_context(CachedContext c)
+{
+    if (!c.ctx) return;
+    std::lock_guard<std::mutex> lock{g_ctx_mutex};
+    if (c.from_cache) {
+        g_cached_busy = false;
+        return;
+    }
+    if (!g_cached_ctx) {  // first finished voxelization donates its context to the cache
+        g_cached_ctx = c.ctx;
+        g_cached_device = c.device;
+        g_cached_busy = false;
+        return;
+    }
+    o2v_hip_destroy(c.ctx);  // a concurrent voxelization on another thread used a temporary context
+}
+
 // The GPU leg of voxelize_specialized (reference obj2voxel.cpp:467-520): bounds, transform, per-triangle
 // voxelization, colour combine and packing all happen on the device; the host only moves data.
 obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, std::vector<HostTriangle> &tris)
@@ -212,17 +254,19 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, std::vector<HostT
 
     int device = 0;
     if (const char *env = std::getenv("O2V_DEVICE")) device = std::atoi(env);
-    o2v_hip_ctx *ctx = nullptr;
-    int rc = o2v_hip_create(device, &ctx);
-    if (rc != O2V_HIP_OK) {
+    // Instances are single-use (reference obj2voxel.cpp:604-606,635) but the device context is not: one context per
+    // process is kept and reused, so repeated voxelizations do not pay for re-allocating the dense grid.
+    CachedContext cached = acquire_context(device);
+    o2v_hip_ctx *ctx = cached.ctx;
+    if (!ctx) {
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device: the GPU voxelization path cannot run "
                                                "and this library has no CPU fallback");
         return OBJ2VOXEL_ERR_DEVICE;
     }
     struct Guard {
-        o2v_hip_ctx *c;
-        ~Guard() { o2v_hip_destroy(c); }
-    } guard{ctx};
+        CachedContext c;
+        ~Guard() { release_context(c); }
+    } guard{cached};
 
     auto device_error = [&](const char *what) {
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, std::string(what) + ": " + o2v_hip_last_error(ctx));

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the drop-in entry point: obj2voxel_voxelize() with a triangle callback in and a voxel
+callback out (what the reference's CLI and tests call). Includes the callback pulls, H2D of 76 B/triangle, context
+creation + first-touch of the dense grid, the device pipeline, D2H of 16 B/voxel and the sink callbacks.
+This is NOT bench.py's `value` (which is HBM-resident); it is the number DESIGN.md section 6 asks to be noted.
+
+The triangle callback here is a C function inside a tiny helper library (a Python ctypes callback per triangle would
+measure Python, not the library)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+HELPER_SRC = r'''
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+#include "obj2voxel.h"
+typedef struct { const float *verts; size_t n, i; } feed;
+typedef struct { size_t voxels, calls; } count;
+bool feed_next(void *d, obj2voxel_triangle *t) {
+    feed *f = (feed *) d;
+    if (f->i >= f->n) return false;
+    obj2voxel_set_triangle_basic(t, f->verts + 9 * f->i++);
+    return true;
+}
+bool count_write(void *d, uint32_t *v, size_t n) { count *c = (count *) d; (void) v; c->voxels += n; c->calls++; return true; }
+'''
+
+
+def main():
+    import numpy as np
+    from obj2voxel_amd import capi, meshes
+    import obj2voxel_amd
+    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 467
+    res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    tmp = tempfile.mkdtemp()
+    src = os.path.join(tmp, "helper.c")
+    open(src, "w").write(HELPER_SRC)
+    so = os.path.join(tmp, "libhelper.so")
+    libdir = os.path.dirname(obj2voxel_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), src, "-o", so,
+                           "-L", libdir, "-lobj2voxel_amd", "-Wl,-rpath," + libdir])
+    a = capi.api()
+    helper = C.CDLL(so)
+
+    class Feed(C.Structure):
+        _fields_ = [("verts", C.c_void_p), ("n", C.c_size_t), ("i", C.c_size_t)]
+
+    class Count(C.Structure):
+        _fields_ = [("voxels", C.c_size_t), ("calls", C.c_size_t)]
+
+    verts = np.ascontiguousarray(meshes.uv_sphere(nv))
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    a.obj2voxel_set_input_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    a.obj2voxel_set_output_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    times = []
+    for _ in range(reps):
+        feed = Feed(verts.ctypes.data, len(verts), 0)
+        cnt = Count(0, 0)
+        inst = a.obj2voxel_alloc()
+        a.obj2voxel_set_input_callback(inst, C.cast(helper.feed_next, C.c_void_p), C.byref(feed))
+        a.obj2voxel_set_output_callback(inst, C.cast(helper.count_write, C.c_void_p), C.byref(cnt))
+        a.obj2voxel_set_resolution(inst, res)
+        t0 = time.perf_counter()
+        err = a.obj2voxel_voxelize(inst)
+        dt = time.perf_counter() - t0
+        a.obj2voxel_free(inst)
+        assert err == 0, err
+        times.append(dt)
+    best = min(times)
+    print(json.dumps({"entry_point": "obj2voxel_voxelize (callback in, callback out)", "triangles": len(verts),
+                      "resolution": res, "voxels": cnt.voxels, "sink_calls": cnt.calls,
+                      "wall_s": [round(t, 4) for t in times], "best_mvoxels_per_s": round(cnt.voxels / best / 1e6, 2),
+                      "best_mtris_per_s": round(len(verts) / best / 1e6, 2)}))
+
+
+if __name__ == "__main__":
+    main()

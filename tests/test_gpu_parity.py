@@ -226,3 +226,53 @@ def test_long_hit_lists(dv, oracle, strategy):
     for res in (24, 6, 2):            # up to thousands of hits per voxel at the coarse end
         got, want = _run_both(dv, oracle, v, res, **kw)
         _compare(got, want)
+
+
+def test_baseline_config2_spot_512_blend_textured(dv, oracle):
+    """BASELINE.json configs[1]: 'Spot cow at 512^3, weighted-blend, 1xMI355X' with the survey's stand-in
+    (uv-sphere nv=39 -> 5928 triangles, textured). Full size, bit-exact against the oracle."""
+    from obj2voxel_amd import hip
+    v, uv = meshes.uv_sphere(39, with_uv=True)
+    T = len(v)
+    oracle.set_threads(8)
+    try:
+        got, want = _run_both(dv, oracle, v, 512, uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32),
+                              texids=np.zeros(T, np.int32), textures=[(meshes.checker_texture(256, 16), 1)], strategy=1)
+    finally:
+        oracle.set_threads(1)
+    _compare(got, want)
+    assert len(got) > 1_200_000
+
+
+def test_baseline_config4_like_supersampled_room(dv, oracle):
+    """BASELINE.json configs[3] ('Sponza textured at 2048^3 with 2x supersampling') at a size the oracle finishes in
+    seconds: large axis-aligned textured quads + a sphere, 2x supersampling, BLEND. Bit-exact."""
+    from obj2voxel_amd import hip
+    room = meshes.box_room(3)
+    sph, suv = meshes.uv_sphere(24, radius=0.3, center=(0.5, 0.45, 0.55), with_uv=True)
+    v = np.concatenate([room, sph])
+    ruv = np.tile(np.array([0, 0, 1, 0, 1, 1], np.float32), (len(room), 1))
+    uv = np.concatenate([ruv, suv])
+    T = len(v)
+    got, want = _run_both(dv, oracle, v, 160, uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32),
+                          texids=np.zeros(T, np.int32), textures=[(meshes.checker_texture(128, 8), 1)], strategy=1,
+                          supersampling=2)
+    _compare(got, want)
+
+
+def test_full_size_supersampled_2048(dv):
+    """BASELINE.json configs[3] at its full grid (2048^3 output, 4096^3 samples): size-independent properties.
+    A cube's 2x-supersampled result equals the plain one, runs are deterministic and the
+    z-slabs tile the result."""
+    res = 2048
+    dv.set_triangles(meshes.unit_cube())
+    plain = meshes.sorted_voxels(dv.voxelize(res))
+    ss = meshes.sorted_voxels(dv.voxelize(res, supersampling=2))
+    assert len(plain) == 8 + 12 * (res - 2) + 6 * (res - 2) ** 2
+    assert np.array_equal(plain, ss)
+    v = np.concatenate([meshes.box_room(4), meshes.uv_sphere(200, radius=0.3, center=(0.5, 0.5, 0.5))])
+    dv.set_triangles(v)
+    whole = meshes.sorted_voxels(dv.voxelize(res, supersampling=2, strategy=1))
+    parts = [dv.voxelize(res, supersampling=2, strategy=1, zslab=(z, z + 512)) for z in range(0, res, 512)]
+    assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), whole)
+    assert np.array_equal(meshes.sorted_voxels(dv.voxelize(res, supersampling=2, strategy=1)), whole)

@@ -57,3 +57,21 @@ def test_oracle_regression_vectors(oracle):
     for name in CASES:
         vox = meshes.sorted_voxels(run_case(oracle, name))
         assert np.array_equal(vox, data[name]), name
+
+
+def test_baseline_config1_spot_64_max_cpu_path(oracle):
+    """BASELINE.json configs[0]: 'Spot cow (~6k tris) at 64^3, max-blend, CPU reference path (plumbing, no GPU)' with
+    the survey's stand-in mesh (uv-sphere nv=39 -> 5928 triangles): the CPU oracle alone, and its chunk-parallel mode
+    gives the identical result for any thread count."""
+    v = meshes.uv_sphere(39)
+    assert len(v) == 5928
+    T = len(v)
+    kw = dict(types=np.full(T, 2, np.uint32), colors=meshes.triangle_colors(T), strategy=0)
+    one = meshes.sorted_voxels(oracle.voxelize(v, 64, **kw))
+    oracle.set_threads(4)
+    try:
+        four = meshes.sorted_voxels(oracle.voxelize(v, 64, **kw))
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(one, four)
+    assert len(np.unique(one[:, :3], axis=0)) == len(one) > 15000

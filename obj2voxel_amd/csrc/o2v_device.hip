@@ -666,12 +666,16 @@ __device__ __forceinline__ uint32_t split_cut(Piece<UV> &cur, Piece<UV> &sec, ui
 {
     const uint32_t r = (cls >> kClsRotShift) & 3u;
     const bool flag_lo = (cls & kClsFlagLo) != 0;
-    const V3 P = sel3(r, cur.a, cur.b, cur.c), Q = sel3(r, cur.b, cur.c, cur.a), R = sel3(r, cur.c, cur.a, cur.b);
+    // rotate (a, b, c) left by r with two conditional cyclic shifts (18 selects instead of 54)
+    const bool s1 = r >= 1u, s2 = r == 2u;
+    const V3 P1 = s1 ? cur.b : cur.a, Q1 = s1 ? cur.c : cur.b, R1 = s1 ? cur.a : cur.c;
+    const V3 P = s2 ? Q1 : P1, Q = s2 ? R1 : Q1, R = s2 ? P1 : R1;
     V2 tP{}, tQ{}, tR{};
     if (UV) {
-        tP = sel2(r, cur.ta, cur.tb, cur.tc);
-        tQ = sel2(r, cur.tb, cur.tc, cur.ta);
-        tR = sel2(r, cur.tc, cur.ta, cur.tb);
+        const V2 tP1 = s1 ? cur.tb : cur.ta, tQ1 = s1 ? cur.tc : cur.tb, tR1 = s1 ? cur.ta : cur.tc;
+        tP = s2 ? tQ1 : tP1;
+        tQ = s2 ? tR1 : tQ1;
+        tR = s2 ? tP1 : tR1;
     }
     const float cP = comp(P, axis), cQ = comp(Q, axis), cR = comp(R, axis);
     const bool regular = (cls & kClsModeMask) == 2u;
@@ -961,6 +965,45 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
             float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
             uint32_t px = 0, py = 0, pz = 0;
             bool queue_empty = n_surv == 0;
+            // parked result of this lane's last finished hit
+            float d_w = 0.f, d_u = 0.f, d_v = 0.f;
+            uint32_t d_k = 0, d_px = 0, d_py = 0, d_pz = 0;
+            bool d_valid = false;
+            auto flush_results = [&]() {
+                const unsigned long long mask = __ballot(d_valid);
+                if (!mask) return;
+                const uint32_t cnt = (uint32_t) __popcll(mask);
+                const uint32_t leader = (uint32_t) __ffsll((long long) mask) - 1u;
+                if (chunk_used + cnt > kHitChunk) {
+                    // abandon the rest of the chunk (marked as holes for the scatter pass) and reserve a new one
+                    const uint32_t hole = chunk_base + chunk_used + lane;
+                    if (chunk_used + lane < kHitChunk && hole < p.cap_hits) pool[hole].brick = kHoleBrick;
+                    if (chunk_used + 64u + lane < kHitChunk && hole + 64u < p.cap_hits) pool[hole + 64u].brick = kHoleBrick;
+                    if (chunk_used + 128u + lane < kHitChunk && hole + 128u < p.cap_hits) pool[hole + 128u].brick = kHoleBrick;
+                    if (chunk_used + 192u + lane < kHitChunk && hole + 192u < p.cap_hits) pool[hole + 192u].brick = kHoleBrick;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
+                    chunk_base = __shfl(base, (int) leader, 64);
+                    chunk_used = 0;
+                }
+                const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+                chunk_used += cnt;
+                if (d_valid && mine < p.cap_hits) {
+                    const uint32_t *lf = &s_leaf[d_k * kLeafStride];
+                    const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
+                    uint32_t brick;
+                    const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                    const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
+                    // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
+                    const uint32_t rank = atomicAdd(&grid[cell], 1u);
+                    if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
+                    brick_dirty[brick] = 1;  // benign race: every writer stores the same value
+                    pool[mine] = HitRec{brick, (((uint32_t) cell & 255u) << 24) | (rank & (kMaxRank - 1u)),
+                                        (sub << 29) | lf[18], lf[19], d_w, d_u, d_v, 0u};
+                }
+                if (lane == leader) atomicAdd(&s_hits, cnt);
+                d_valid = false;
+            };
             for (;;) {
                 // pop a pending sibling, or fetch the next survivor
                 if (!active) {
@@ -1077,47 +1120,24 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
                         }
                     }
                 }
-                // a job is finished when nothing of it is in flight: `not eqExactly(uv.weight, 0.f)` ->
-                // insertWeighted (voxelization.cpp:466-468): the hit joins its cell's list; the ordered combine
-                // happens in k_resolve
+                // A job is finished when nothing of it is in flight.  `not eqExactly(uv.weight, 0.f)` -> insertWeighted
+                // (voxelization.cpp:466-468): the hit is appended to the pool and counted in its cell; the ordered
+                // combine happens in the resolve kernels.  A finished hit is parked in the lane's result registers and
+                // the append section runs only when half the wavefront holds one (or a lane needs its slot again, or
+                // the wavefront leaves), not in every iteration.
                 const bool finished = has_job && !active && pending == 0;
-                const bool hit = finished && w != 0.f;
+                const bool fin_hit = finished && w != 0.f;
                 if (finished) has_job = false;
-                const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    const uint32_t cnt = (uint32_t) __popcll(mask);
-                    const uint32_t leader = (uint32_t) __ffsll((long long) mask) - 1u;
-                    if (chunk_used + cnt > kHitChunk) {
-                        // abandon the rest of the chunk (marked as holes for the scatter pass) and reserve a new one
-                        const uint32_t hole = chunk_base + chunk_used + lane;
-                        if (chunk_used + lane < kHitChunk && hole < p.cap_hits) pool[hole].brick = kHoleBrick;
-                        if (chunk_used + 64u + lane < kHitChunk && hole + 64u < p.cap_hits) pool[hole + 64u].brick = kHoleBrick;
-                        if (chunk_used + 128u + lane < kHitChunk && hole + 128u < p.cap_hits) pool[hole + 128u].brick = kHoleBrick;
-                        if (chunk_used + 192u + lane < kHitChunk && hole + 192u < p.cap_hits) pool[hole + 192u].brick = kHoleBrick;
-                        uint32_t base = 0;
-                        if (lane == leader) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
-                        chunk_base = __shfl(base, (int) leader, 64);
-                        chunk_used = 0;
-                    }
-                    const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
-                    chunk_used += cnt;
-                    if (hit && mine < p.cap_hits) {
-                        const uint32_t *lf = &s_leaf[my_k * kLeafStride];
-                        const uint32_t ox = px >> p.ss_shift, oy = py >> p.ss_shift, oz = pz >> p.ss_shift;
-                        uint32_t brick;
-                        const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
-                        const uint32_t sub = p.ss_shift ? ((px & 1u) | ((py & 1u) << 1) | ((pz & 1u) << 2)) : 0u;
-                        // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
-                        const uint32_t rank = atomicAdd(&grid[cell], 1u);
-                        if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
-                        brick_dirty[brick] = 1;  // benign race: every writer stores the same value
-                        pool[mine] = HitRec{brick, (((uint32_t) cell & 255u) << 24) | (rank & (kMaxRank - 1u)),
-                                            (sub << 29) | lf[18], lf[19], w, u, v, 0u};
-                    }
-                    if (lane == leader) atomicAdd(&s_hits, cnt);
+                if (__ballot(fin_hit && d_valid)) flush_results();
+                if (fin_hit) {
+                    d_w = w; d_u = u; d_v = v;
+                    d_k = my_k; d_px = px; d_py = py; d_pz = pz;
+                    d_valid = true;
                 }
-                // the wavefront leaves when no lane has anything in flight and the queue is drained
-                if (!__ballot(active || pending != 0 || !queue_empty)) break;
+                const bool leaving = !__ballot(active || pending != 0 || !queue_empty);
+                const unsigned long long dm = __ballot(d_valid);
+                if (dm && ((uint32_t) __popcll(dm) >= 32u || leaving)) flush_results();
+                if (leaving) break;
             }
             t_begin = t_end;
         }

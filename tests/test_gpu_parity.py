@@ -276,3 +276,20 @@ def test_full_size_supersampled_2048(dv):
     parts = [dv.voxelize(res, supersampling=2, strategy=1, zslab=(z, z + 512)) for z in range(0, res, 512)]
     assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), whole)
     assert np.array_equal(meshes.sorted_voxels(dv.voxelize(res, supersampling=2, strategy=1)), whole)
+
+
+def test_4096_grid_in_eight_slabs(dv):
+    """BASELINE.json configs[4] layout: a 4096^3 grid split into 8 z-slabs (34 GB of dense grid each), here run one
+    after the other on a single GPU. The slab counts of the unit cube must add up to the reference's closed form
+    (test/main.cpp:120-126) and every voxel must lie in its slab."""
+    res, n = 4096, 8
+    dv.set_triangles(meshes.unit_cube())
+    total = 0
+    for r in range(n):
+        z0, z1 = r * res // n, (r + 1) * res // n
+        vox = dv.voxelize(res, zslab=(z0, z1))
+        assert ((vox[:, 2] >= z0) & (vox[:, 2] < z1)).all()
+        total += len(vox)
+    assert total == 8 + 12 * (res - 2) + 6 * (res - 2) ** 2
+    st = dv.stats()
+    assert st["grid_bytes"] > 34e9

@@ -130,3 +130,31 @@ def test_obj_with_materials_and_png_texture(tmp_path, oracle):
     a.obj2voxel_set_log_level(capi.LOG_INFO)
     assert err == capi.ERR_OK
     assert np.array_equal(meshes.sorted_voxels(_vl32_to_voxels(data)), meshes.sorted_voxels(want))
+
+
+def test_cli_front_end(tmp_path, oracle):
+    """The command line front end (reference src/main.cpp:115-202 call sequence, :224-262 axis permutation) on a
+    binary STL: -r, -s blend, -p zYx (axes permuted, y flipped), -u, -j 2; output compared with the oracle."""
+    import os
+    import subprocess
+    import obj2voxel_amd
+    cli = os.path.join(os.path.dirname(obj2voxel_amd.LIB_PATH), "obj2voxel-amd")
+    assert os.path.exists(cli), "build with __graft_entry__.build()"
+    v = meshes.uv_sphere(8, radius=0.8, center=(0.1, 0.0, -0.2))
+    v[:, 1::3] *= 0.6  # not a cube-filling shape, so the permutation is visible
+    stl = tmp_path / "in.stl"
+    with open(stl, "wb") as f:
+        f.write(b"binary stl".ljust(80, b" ") + struct.pack("<I", len(v)))
+        for t in v:
+            f.write(struct.pack("<12fH", 0, 0, 0, *t.tolist(), 0))
+    out = tmp_path / "out.vl32"
+    r = subprocess.run([cli, str(stl), str(out), "-r", "48", "-s", "blend", "-p", "zYx", "-u", "-j", "2"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = _vl32_to_voxels(out.read_bytes())
+    # -p zYx: row i of the unit transform selects axis perm[i]; capital = flipped (main.cpp:224-262)
+    unit = [0, 0, 1, 0, -1, 0, 1, 0, 0]
+    want = oracle.voxelize(v, 48, strategy=1, supersampling=2, unit_transform=unit)
+    assert np.array_equal(meshes.sorted_voxels(got), meshes.sorted_voxels(want))
+    bad = subprocess.run([cli, str(stl), str(out)], capture_output=True, text=True)
+    assert bad.returncode == 1  # resolution is required

@@ -59,9 +59,12 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
         n = world
     dist = None
+    dev_index = 0
     if n > 1:
         import torch.distributed as dist
-        dev_index = 0 if args.same_device else local_rank
+        # one process per GPU; if the launcher narrowed each rank's visibility to a single device, that device is 0
+        visible = torch.cuda.device_count()
+        dev_index = 0 if (args.same_device or local_rank >= visible) else local_rank
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
@@ -79,7 +82,7 @@ def main():
     T = len(verts)
     z0, z1 = slabs.slab_range(rank, n, res)
 
-    dv = hip.DeviceVoxelizer(local_rank if (n > 1 and not args.same_device) else 0)
+    dv = hip.DeviceVoxelizer(dev_index if n > 1 else 0)
     dv.set_triangles(verts)
 
     def barrier():

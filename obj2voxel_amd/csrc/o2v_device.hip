@@ -470,6 +470,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
                 }
             }
         }
+        // a block whose triangles all miss this GPU's slab has nothing to reserve (the common case on the other
+        // ranks of a multi-GPU run, where every rank filters the whole triangle list)
+        if (!__syncthreads_or((int) (as_leaf || as_node))) continue;
         BlockSlots slot = reserve_slots(e, c, 0, s_wave, s_base);
         if (as_leaf) {
             if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, (uint32_t) (base + threadIdx.x), 0u, area, pl);

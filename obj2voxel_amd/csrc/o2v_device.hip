@@ -841,6 +841,7 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
     __shared__ uint32_t s_tprefix[kTilesPerBatch + 2];
     __shared__ uint32_t s_scan[kBlock / 64];
     __shared__ uint32_t s_tend;
+    __shared__ uint32_t s_chunk_tile[kMaxSurvivors / 64 + 1];
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
     __shared__ uint16_t s_surv[kMaxSurvivors];
     __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits;
@@ -906,54 +907,63 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
             __syncthreads();
             const uint32_t t_end = s_tend;
 
-            // ---- phase 1: one wavefront per tile, lanes over its candidates --------------------------------
-            for (uint32_t k = t_begin + wave; k < t_end; k += kBlock / 64) {
-                const uint32_t *lf = &s_leaf[k * kLeafStride];
-                const uint32_t cnt = s_tcount[k], start = s_tstart[k];
-                const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
-                const float inv_dx = s_inv_dx[k], inv_dy = s_inv_dy[k];
-                const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
-                const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
-                const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
-                const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
-                const uint32_t bx = lf[20] & 0xffffu, by = lf[20] >> 16, bz = lf[21] & 0xffffu;
-                for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    bool keep = false;
-                    if (i < cnt) {
-                        const uint32_t j = start + i;
-                        uint32_t row, lx, lz, ly;
-                        if (j < (1u << 24)) {
-                            // exact quotient from a float estimate (j < 2^24, divisor < 2^16): off by at most one
-                            row = (uint32_t) ((float) j * inv_dx);
-                            int32_t rx = (int32_t) (j - row * dx);
-                            if (rx < 0) { row -= 1; rx += (int32_t) dx; }
-                            else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
-                            lx = (uint32_t) rx;
-                            lz = (uint32_t) ((float) row * inv_dy);
-                            int32_t ry = (int32_t) (row - lz * dy);
-                            if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
-                            else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
-                            ly = (uint32_t) ry;
-                        }
-                        else {
-                            row = j / dx;
-                            lx = j - row * dx;
-                            lz = row / dy;
-                            ly = row - lz * dy;
-                        }
-                        const float cx = (float) (bx + lx) + 0.5f, cy = (float) (by + ly) + 0.5f, cz = (float) (bz + lz) + 0.5f;
-                        // plane distance cull, voxelization.cpp:451-458
-                        const float sd = dot(nrm, V3{cx, cy, cz} - v0);
-                        keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, nrm, cx, cy, cz);
+            // ---- phase 1: the sub-batch's candidates flattened over the lanes ------------------------------
+            // Candidate g (in sub-batch order) belongs to the tile k with s_tprefix[k] <= g < s_tprefix[k + 1].  A small
+            // table gives every 64-candidate chunk the tile its first candidate falls in; a lane then walks forward a
+            // few tiles at most, so the 64 lanes stay busy however small the tiles are.
+            const uint32_t n_cand = s_tprefix[t_end] - base_cand;
+            if (threadIdx.x >= t_begin && threadIdx.x < t_end) {
+                const uint32_t lo = s_tprefix[threadIdx.x] - base_cand, hi = s_tprefix[threadIdx.x + 1] - base_cand;
+                if (hi > lo)
+                    for (uint32_t ch = (lo + 63u) / 64u; ch * 64u < hi; ++ch) s_chunk_tile[ch] = threadIdx.x;
+            }
+            __syncthreads();
+            for (uint32_t g0 = wave * 64u; g0 < n_cand; g0 += kBlock) {
+                const uint32_t g = g0 + lane;
+                bool keep = false;
+                uint32_t k = s_chunk_tile[g0 / 64u], i = 0;
+                if (g < n_cand) {
+                    while (s_tprefix[k + 1] - base_cand <= g) ++k;
+                    i = g - (s_tprefix[k] - base_cand);
+                    const uint32_t *lf = &s_leaf[k * kLeafStride];
+                    const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
+                    const uint32_t j = s_tstart[k] + i;
+                    uint32_t row, lx, lz, ly;
+                    if (j < (1u << 24)) {
+                        // exact quotient from a float estimate (j < 2^24, divisor < 2^16): off by at most one
+                        row = (uint32_t) ((float) j * s_inv_dx[k]);
+                        int32_t rx = (int32_t) (j - row * dx);
+                        if (rx < 0) { row -= 1; rx += (int32_t) dx; }
+                        else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
+                        lx = (uint32_t) rx;
+                        lz = (uint32_t) ((float) row * s_inv_dy[k]);
+                        int32_t ry = (int32_t) (row - lz * dy);
+                        if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
+                        else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
+                        ly = (uint32_t) ry;
                     }
-                    const unsigned long long m = __ballot(keep);
-                    if (m) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&s_nsurv, (uint32_t) __popcll(m));
-                        base = __shfl(base, 0, 64);
-                        if (keep) s_surv[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) (((k - t_begin) << 8) | i);
+                    else {
+                        row = j / dx;
+                        lx = j - row * dx;
+                        lz = row / dy;
+                        ly = row - lz * dy;
                     }
+                    const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                    const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                    const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                    const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
+                    const float cx = (float) ((lf[20] & 0xffffu) + lx) + 0.5f, cy = (float) ((lf[20] >> 16) + ly) + 0.5f,
+                                cz = (float) ((lf[21] & 0xffffu) + lz) + 0.5f;
+                    // plane distance cull, voxelization.cpp:451-458
+                    const float sd = dot(nrm, V3{cx, cy, cz} - v0);
+                    keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, nrm, cx, cy, cz);
+                }
+                const unsigned long long m = __ballot(keep);
+                if (m) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nsurv, (uint32_t) __popcll(m));
+                    base = __shfl(base, 0, 64);
+                    if (keep) s_surv[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) (((k - t_begin) << 8) | i);
                 }
             }
             __syncthreads();

@@ -2,8 +2,8 @@
 //
 // Replaces, for one GPU's z-slab of the grid, the reference's chunk loop (src/obj2voxel.cpp:467-520) and
 // Voxelizer::voxelize (src/voxelization.cpp:480-526).  Written for CDNA4: 64-wide wavefronts, LDS-staged leaf
-// geometry, LDS-resident clip stacks, 32-bit atomics on a dense HBM grid of list heads.  No MFMA: the path is
-// float32 VALU + HBM/atomic traffic.
+// geometry and work queues, register-resident clip stacks, 32-bit atomics on a dense (bricked) HBM grid of per-cell
+// counters.  No MFMA: the path is float32 VALU + HBM/atomic traffic.
 //
 // Stages (all on one HIP stream, no host round trips between them):
 //   K0  k_bounds / k_setup     mesh bounds (obj2voxel.cpp:180-200) and mesh transform (obj2voxel.cpp:370-402)
@@ -158,7 +158,6 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
     return __uint_as_float(b);
 }
-__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
 // Dense grid layout: bricks of 16 (x) x 4 (y) x 4 (z) cells, each brick 256 consecutive u32 (1 KiB), bricks ordered
 // x fastest.  A surface marks ~12 cells' worth of brick volume per unit area in this shape (the same as 8^3 bricks)
@@ -623,9 +622,6 @@ struct Piece {  // TexturedTriangle (triangle.hpp:113-144); the uv members are d
     V2 ta, tb, tc;
 };
 
-__device__ __forceinline__ V3 sel3(uint32_t r, V3 x0, V3 x1, V3 x2) { return r == 0 ? x0 : (r == 1 ? x1 : x2); }
-__device__ __forceinline__ V2 sel2(uint32_t r, V2 x0, V2 x1, V2 x2) { return r == 0 ? x0 : (r == 1 ? x1 : x2); }
-
 // Classification of one piece against one axis plane: SplittingValues + the case switch of splitTriangle
 // (voxelization.cpp:110-153,190-232).  Packed so that it can be carried in one register between the cheap
 // classification pass and the expensive split pass of the clip loop.
@@ -782,8 +778,11 @@ __device__ __forceinline__ void stack_load(const PieceStack<UV> &st, uint32_t sl
 // Conservative triangle / voxel overlap test (separating axes: the triangle's plane and the nine edge x axis
 // directions; the three box axes are implied by the AABB walk).  The box is inflated by kSatMargin, far more than
 // the float32 rounding of the clip (<= a few ulp of the coordinate, 5e-4 at 4096) and than its planarity epsilon
-// (2^-16), so every voxel the exact clip can mark is kept: this only removes work, never results.  All
-// comparisons are written so that a NaN (degenerate triangle) rejects nothing.
+// (2^-16), so every voxel the exact clip can mark is kept: this only removes work, never results.  The test's own
+// rounding is covered too: everything is evaluated in the voxel-centred frame, the plane axis uses the unnormalised
+// normal e0 x e1 with an explicit error bound (for a sliver, whose normal direction is numerically meaningless, the
+// bound exceeds the radius and the plane axis simply never separates), and all comparisons are written so that a
+// NaN rejects nothing.
 constexpr float kSatMargin = 0.02f;
 
 __device__ __forceinline__ bool sat_axis_separates(float p0, float p1, float rad)
@@ -792,18 +791,23 @@ __device__ __forceinline__ bool sat_axis_separates(float p0, float p1, float rad
     return lo > rad || hi < -rad;
 }
 
-__device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, V3 n, float cx, float cy, float cz)
+__device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, float cx, float cy, float cz)
 {
     const float h = 0.5f + kSatMargin;
     const V3 c{cx, cy, cz};
     const V3 a = v0 - c, b = v1 - c, d = v2 - c;
-    // plane of the triangle (n is the normalised leaf normal): |n . a| <= h * (|nx| + |ny| + |nz|)
+    const V3 e0 = b - a, e1 = d - b, e2 = a - d;
     {
+        // plane axis: |n . a| <= h * |n|_1, n = e0 x e1.  Each component of n carries an absolute rounding error of a
+        // few ulp of |e0|_1 |e1|_1 (cancellation), which the bound below over-estimates by more than 10x.
+        const V3 n = cross(e0, e1);
         const float dist = n.x * a.x + n.y * a.y + n.z * a.z;
         const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z));
-        if (abs_f(dist) > rad) return false;
+        const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
+        const float la = abs_f(a.x) + abs_f(a.y) + abs_f(a.z);
+        const float err = 1e-5f * l0 * l1 * (la + 1.0f);
+        if (abs_f(dist) > rad + err) return false;
     }
-    const V3 e0 = b - a, e1 = d - b, e2 = a - d;
     // axis = X x e: projections use only the vertices not on edge e (the edge's own vertices project equally)
 #define O2V_SAT_EDGE(E, U, W)                                                                               \
     if (sat_axis_separates(E.z * U.y - E.y * U.z, E.z * W.y - E.y * W.z, h * (abs_f(E.z) + abs_f(E.y)))) return false; \
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
                                 cz = (float) ((lf[21] & 0xffffu) + lz) + 0.5f;
                     // plane distance cull, voxelization.cpp:451-458
                     const float sd = dot(nrm, V3{cx, cy, cz} - v0);
-                    keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, nrm, cx, cy, cz);
+                    keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, cx, cy, cz);
                 }
                 const unsigned long long m = __ballot(keep);
                 if (m) {

@@ -24,7 +24,6 @@ constexpr uint32_t kSubdivisionVolumeLimit = 512;
 constexpr float kDiagonalityLimit = 0.5f;
 constexpr float kEpsilon = 1.0f / (1 << 16);
 constexpr float kPlaneDistanceLimit = 2.0f;  // voxelization.cpp:435
-constexpr uint32_t kChunkSize = 64;
 
 // triangle.hpp:21-29
 enum TriangleType : uint32_t { kTriNone = 0, kTriMaterialless = 1, kTriUntextured = 2, kTriTextured = 3 };
@@ -67,7 +66,6 @@ O2V_HD V3 normalize(V3 a)
     float l = length(a);
     return {a.x / l, a.y / l, a.z / l};
 }
-O2V_HD float mix1(float a, float b, float s, float t) { return s * a + t * b; }
 O2V_HD V3 mix(V3 a, V3 b, float t)
 {
     float s = 1 - t;

@@ -1,0 +1,106 @@
+"""Seeded randomised parity: random triangle soups (tiny, huge, degenerate, axis-aligned, duplicated), random
+resolution / strategy / supersampling / unit transform / user bounds / z-slab / materials, device vs. oracle,
+bit-exact. Deterministic (fixed seeds) so a failure is reproducible by its case number."""
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+pytestmark = pytest.mark.gpu
+
+PERMS = [[1, 0, 0, 0, 1, 0, 0, 0, 1], [0, 1, 0, 0, 0, 1, 1, 0, 0], [0, 0, -1, 0, 1, 0, 1, 0, 0],
+         [-1, 0, 0, 0, -1, 0, 0, 0, -1], [0, -1, 0, 1, 0, 0, 0, 0, 1]]
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.integers(1, 220))
+    kind = rng.integers(0, 5, size=T)
+    c = rng.random((T, 1, 3))
+    v = np.empty((T, 3, 3))
+    for i in range(T):
+        if kind[i] == 0:      # small
+            v[i] = c[i] + 0.08 * (rng.random((3, 3)) - 0.5)
+        elif kind[i] == 1:    # large, arbitrary orientation (subdivision)
+            v[i] = rng.random((3, 3))
+        elif kind[i] == 2:    # axis aligned plane piece
+            v[i] = rng.random((3, 3))
+            v[i][:, rng.integers(0, 3)] = np.round(rng.random() * 8) / 8
+        elif kind[i] == 3:    # degenerate: repeated or collinear vertices
+            a, b = rng.random(3), rng.random(3)
+            v[i] = [a, b, a if rng.random() < 0.5 else (a + b) / 2]
+        else:                 # sub-voxel sliver
+            v[i] = c[i] + 1e-3 * (rng.random((3, 3)) - 0.5)
+    v = np.clip(v, 0, 1).astype(np.float32).reshape(T, 9)
+    if rng.random() < 0.3:
+        v = np.concatenate([v, v[: max(1, T // 4)]])  # exact duplicates (ties)
+        T = len(v)
+    res = int(rng.choice([7, 16, 33, 48, 64, 65, 90, 128]))
+    kw = dict(strategy=int(rng.integers(0, 2)), supersampling=int(rng.choice([1, 1, 2])))
+    if rng.random() < 0.4:
+        kw["unit_transform"] = PERMS[int(rng.integers(0, len(PERMS)))]
+    if rng.random() < 0.25:
+        kw["bounds"] = [-0.1, -0.2, -0.05, 1.3, 1.1, 1.2]
+    if rng.random() < 0.3:
+        z0 = int(rng.integers(0, res - 1))
+        kw["zslab"] = (z0, int(rng.integers(z0 + 1, res + 1)))
+    types = rng.integers(1, 4, size=T).astype(np.uint32)
+    mat = dict(types=types, colors=rng.random((T, 3)).astype(np.float32),
+               uvs=(rng.random((T, 6)) * 2.5 - 0.7).astype(np.float32), texids=rng.integers(0, 2, size=T).astype(np.int32))
+    tex_a = (rng.integers(0, 256, size=(int(rng.integers(1, 40)), int(rng.integers(1, 40)), 3))).astype(np.uint8)
+    tex_b = (rng.integers(0, 256, size=(16, 8, 4))).astype(np.uint8)
+    textures = [(tex_a, int(rng.integers(0, 2))), (tex_b, int(rng.integers(0, 2)))]
+    return v, res, kw, mat, textures
+
+
+@pytest.fixture(scope="module")
+def dv():
+    from obj2voxel_amd import hip
+    d = hip.DeviceVoxelizer(0)
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_case(dv, oracle, seed):
+    v, res, kw, mat, textures = _case(seed)
+    dv.set_textures(textures)
+    dv.set_triangles(v, **mat)
+    got = meshes.sorted_voxels(dv.voxelize(res, **kw))
+    want = meshes.sorted_voxels(oracle.voxelize(v, res, textures=textures, **mat, **kw))
+    assert got.shape == want.shape, (seed, got.shape, want.shape)
+    assert np.array_equal(got[:, :3], want[:, :3]), seed
+    assert np.array_equal(got[:, 3], want[:, 3]), seed
+
+
+def _planar_case(seed):
+    """Vertices on (or within a few 2^-16 of) voxel boundary planes: with bounds [-0.25, S-0.75] the mesh transform
+    (obj2voxel.cpp:370-402) is x -> x + 0.5 up to rounding, so model coordinates k - 0.5 land on integer planes and
+    the splitter's planar / one-planar / parallel cases (voxelization.cpp:190-232) and its 2^-16 epsilon are hit."""
+    rng = np.random.default_rng(5000 + seed)
+    S = int(rng.choice([8, 12, 16, 24]))
+    T = int(rng.integers(1, 60))
+    # keep every vertex inside the user bounds: outside them the reference is undefined (negative float -> u32
+    # casts, voxels in the padding of the last 64^3 chunk), see DESIGN.md section 7
+    k = rng.integers(1, S, size=(T, 3, 3)).astype(np.float64)
+    noise = rng.choice([0.0, 0.0, 1e-6, -1e-6, 1.4e-5, -1.4e-5, 1.7e-5, -1.7e-5, 3e-4, 0.25, 0.5], size=(T, 3, 3))
+    v = (k - 0.5 + noise).astype(np.float32).reshape(T, 9)
+    # a few triangles lying exactly in a voxel boundary plane
+    for i in range(0, T, 5):
+        a = int(rng.integers(0, 3))
+        v[i, a::3] = v[i, a]
+    bounds = [-0.25] * 3 + [S - 0.75] * 3
+    kw = dict(strategy=int(rng.integers(0, 2)), bounds=bounds)
+    types = np.full(T, 2, np.uint32)
+    mat = dict(types=types, colors=rng.random((T, 3)).astype(np.float32))
+    return v, S, kw, mat
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_planar_stress_case(dv, oracle, seed):
+    v, res, kw, mat = _planar_case(seed)
+    dv.set_triangles(v, **mat)
+    got = meshes.sorted_voxels(dv.voxelize(res, **kw))
+    want = meshes.sorted_voxels(oracle.voxelize(v, res, **mat, **kw))
+    assert got.shape == want.shape, (seed, got.shape, want.shape)
+    assert np.array_equal(got, want), seed

@@ -2120,8 +2120,18 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     uint64_t want_big = std::max<uint64_t>(ctx->cap_big, 1u << 16);
     uint64_t want_nodes = std::max<uint64_t>(ctx->cap_nodes, 1u << 18);
     uint64_t want_hits = std::max<uint64_t>(ctx->cap_hits, std::min<uint64_t>(16 * ctx->n_tris + (4u << 20), 1ull << 31));
+    if (const char *tiny = std::getenv("O2V_TEST_TINY_BUFFERS"); tiny && tiny[0] == '1') {
+        // test hook: start with minimal buffers so that every overflow -> grow -> re-run path is exercised
+        want_leaves = std::max<uint64_t>(ctx->cap_leaves, 64);
+        want_tiles = std::max<uint64_t>(ctx->cap_tiles, 64);
+        want_big = std::max<uint64_t>(ctx->cap_big, 4);
+        want_nodes = std::max<uint64_t>(ctx->cap_nodes, 16);
+        want_hits = std::max<uint64_t>(ctx->cap_hits, 512);
+    }
     uint64_t want_scratch = ctx->cap_scratch;
     uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
+    if (const char *tiny = std::getenv("O2V_TEST_TINY_BUFFERS"); tiny && tiny[0] == '1')
+        want_vox = std::max<uint64_t>(ctx->cap_vox, 256);
 
     // Subdivision rounds to launch: every round halves a node's extents and a node becomes a leaf once its voxel
     // AABB volume is below 512, so ceil(log2(S)) rounds cover the usual case; if a node is still waiting after the

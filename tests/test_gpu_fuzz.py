@@ -104,3 +104,23 @@ def test_planar_stress_case(dv, oracle, seed):
     want = meshes.sorted_voxels(oracle.voxelize(v, res, **mat, **kw))
     assert got.shape == want.shape, (seed, got.shape, want.shape)
     assert np.array_equal(got, want), seed
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_dense_cells_case(dv, oracle, seed):
+    """Thousands of small triangles in a 2..6-voxel grid: every resolve tier (register, LDS column, wavefront,
+    workgroup, global sort), with textures, BLEND / MAX, supersampling, several leaves per triangle."""
+    rng = np.random.default_rng(9000 + seed)
+    T = int(rng.integers(300, 7000))
+    c = rng.random((T, 1, 3))
+    v = np.clip(c + rng.choice([0.02, 0.2, 0.6]) * (rng.random((T, 3, 3)) - 0.5), 0, 1).astype(np.float32).reshape(T, 9)
+    res = int(rng.integers(2, 7))
+    kw = dict(strategy=int(seed % 2), supersampling=int(rng.choice([1, 2])))
+    mat = dict(types=rng.integers(1, 4, size=T).astype(np.uint32), colors=rng.random((T, 3)).astype(np.float32),
+               uvs=rng.random((T, 6)).astype(np.float32), texids=np.zeros(T, np.int32))
+    textures = [(rng.integers(0, 256, size=(32, 32, 3)).astype(np.uint8), 1)]
+    dv.set_textures(textures)
+    dv.set_triangles(v, **mat)
+    got = meshes.sorted_voxels(dv.voxelize(res, **kw))
+    want = meshes.sorted_voxels(oracle.voxelize(v, res, textures=textures, **mat, **kw))
+    assert np.array_equal(got, want), seed

@@ -293,3 +293,35 @@ def test_4096_grid_in_eight_slabs(dv):
     assert total == 8 + 12 * (res - 2) + 6 * (res - 2) ** 2
     st = dv.stats()
     assert st["grid_bytes"] > 34e9
+
+
+def test_buffer_overflow_regrow_paths(oracle, monkeypatch):
+    """Every device buffer (leaves, tiles, big-leaf list, subdivision queue, hit pool, occupied cells, sort scratch)
+    starts tiny (test hook O2V_TEST_TINY_BUFFERS): the pipeline must detect each overflow, grow and re-run until the
+    result is complete - and bit-identical to the oracle."""
+    from obj2voxel_amd import hip
+    monkeypatch.setenv("O2V_TEST_TINY_BUFFERS", "1")
+    d = hip.DeviceVoxelizer(0)
+    try:
+        v = np.concatenate([meshes.uv_sphere(7), meshes.box_room(1) * 0.9 + 0.05])   # subdivision + big aligned leaves
+        T = len(v)
+        kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=1)
+        d.set_triangles(v, **kw_mat(kw))
+        got = d.voxelize(200, strategy=1)
+        assert d.timings()["passes"] > 1
+        _compare(got, oracle.voxelize(v, 200, **kw))
+        again = d.voxelize(200, strategy=1)          # capacities persist: one pass now
+        assert d.timings()["passes"] == 1
+        _compare(again, got)
+        # thousands of hits in one cell with tiny buffers: the global-sort tier's scratch is allocated on demand
+        dense = meshes.uv_sphere(40)
+        Td = len(dense)
+        kd = dict(types=np.full(Td, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(Td), strategy=1)
+        d.set_triangles(dense, **kw_mat(kd))
+        _compare(d.voxelize(2, strategy=1), oracle.voxelize(dense, 2, **kd))
+    finally:
+        d.close()
+
+
+def kw_mat(kw):
+    return {k: v for k, v in kw.items() if k in ("types", "colors", "uvs", "texids")}

@@ -833,8 +833,10 @@ constexpr uint32_t kMaxSurvivors = 8192;      // survivor queue entries (= candi
 //            most one sibling per level 1..5 is pending (register stack).  Per iteration a lane skips every
 //            plane its piece passes whole (AABB check), classifies it against the first plane it does not, and
 //            cuts if needed; lanes that run out of pieces pop the next survivor, so the wavefront stays full.
+// Register budget: 4 waves per SIMD without uv arithmetic, 3 with it (the allocator spills a handful of cold values;
+// measured faster than running one wave fewer on the bench mesh and on the large textured workloads).
 template <bool UV>
-__global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+__global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                                      Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
                                                      Params p)
 {
@@ -984,7 +986,7 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
             bool queue_empty = n_surv == 0;
             // parked result of this lane's last finished hit
             float d_w = 0.f, d_u = 0.f, d_v = 0.f;
-            uint32_t d_k = 0, d_px = 0, d_py = 0, d_pz = 0;
+            uint32_t d_xy = 0, d_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
             bool d_valid = false;
             auto flush_results = [&]() {
                 const unsigned long long mask = __ballot(d_valid);
@@ -1006,7 +1008,8 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
                 const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
                 chunk_used += cnt;
                 if (d_valid && mine < p.cap_hits) {
-                    const uint32_t *lf = &s_leaf[d_k * kLeafStride];
+                    const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
+                    const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
                     const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
                     uint32_t brick;
                     const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
@@ -1148,7 +1151,8 @@ __global__ __launch_bounds__(kBlock) void k_voxelize(const Leaf *__restrict__ le
                 if (__ballot(fin_hit && d_valid)) flush_results();
                 if (fin_hit) {
                     d_w = w; d_u = u; d_v = v;
-                    d_k = my_k; d_px = px; d_py = py; d_pz = pz;
+                    d_xy = px | (py << 16);
+                    d_zk = pz | (my_k << 16);
                     d_valid = true;
                 }
                 const bool leaving = !__ballot(active || pending != 0 || !queue_empty);

@@ -98,6 +98,22 @@ struct __attribute__((aligned(8))) SortedRec {  // 24 B: the same hit, placed co
     uint32_t pad;
 };
 
+// The sorted array is read through a view: 6 dwords per record in general, 4 (keyhi, keylo, w, pad: one 16-byte access)
+// when the mesh has no textured triangle, because then u and v are never used and the scatter's cost scales with the
+// bytes it writes.
+struct SortedView {
+    const uint32_t *base;
+    uint32_t stride;  // dwords per record: 6 or 4
+    __device__ __forceinline__ SortedRec load(uint32_t i) const
+    {
+        if (stride == 4u) {
+            const uint4 q = reinterpret_cast<const uint4 *>(base)[i];
+            return SortedRec{q.x, q.y, __uint_as_float(q.z), 0.f, 0.f, 0u};
+        }
+        return reinterpret_cast<const SortedRec *>(base)[i];
+    }
+};
+
 struct __attribute__((aligned(16))) Occ {  // 16 B: one occupied cell
     uint32_t cell_lo, cell_hi;  // brick * 256 + cell in brick
     uint32_t offset;            // first SortedRec of the cell
@@ -1297,7 +1313,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
 // Streams the hit pool once (coalesced 32-byte records, holes skipped) and places every hit at
 // offset(cell) + rank, so that each cell's hits are contiguous for the resolve kernels.
 __global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ pool, const uint32_t *__restrict__ grid,
-                                                    const Counters *c, SortedRec *sorted, Params p)
+                                                    const Counters *c, uint32_t *sorted, uint32_t stride, Params p)
 {
     const uint32_t n = c->n_hits_reserved < p.cap_hits ? c->n_hits_reserved : p.cap_hits;
     // XCD-aware work split (speed only): workgroup b runs on XCD b % 8 and the eight L2s are not coherent, so each
@@ -1312,7 +1328,10 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ p
         if (r.brick == kHoleBrick) continue;
         const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
         const uint32_t pos = grid[cell] + (r.local_rank & (kMaxRank - 1u));
-        if (pos < p.cap_hits) sorted[pos] = SortedRec{r.keyhi, r.keylo, r.w, r.u, r.v, 0u};
+        if (pos < p.cap_hits) {
+            if (stride == 4u) reinterpret_cast<uint4 *>(sorted)[pos] = make_uint4(r.keyhi, r.keylo, __float_as_uint(r.w), 0u);
+            else reinterpret_cast<SortedRec *>(sorted)[pos] = SortedRec{r.keyhi, r.keylo, r.w, r.u, r.v, 0u};
+        }
     }
 }
 
@@ -1447,7 +1466,7 @@ struct ResolveLists {  // cells k_resolve defers, by hit count class (indices in
 
 // Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
 // from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
-__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, const SortedRec *__restrict__ sorted,
+__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted,
                                                     Counters *c, Materials m, uint4 *out, ResolveLists lists, Params p)
 {
     __shared__ uint64_t s_key[kShortList][kBlock];
@@ -1479,7 +1498,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         // insertion-sorted into this lane's private LDS column and folded by a rolled loop
         SortedRec r[kShortList];
 #pragma unroll
-        for (uint32_t k = 0; k < kShortList; ++k) r[k] = sorted[o.offset + (k < o.count ? k : 0u)];
+        for (uint32_t k = 0; k < kShortList; ++k) r[k] = sorted.load(o.offset + (k < o.count ? k : 0u));
 #pragma unroll
         for (uint32_t k = 0; k < kShortList; ++k) {
             if (k < o.count) {
@@ -1509,7 +1528,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
 // Tier 2: still one lane per cell, for 9..32 hits.  Each lane insertion-sorts (key, record index) in a private LDS
 // column (entry-major layout: lane-contiguous, conflict-free), then replays its cell from the cached records.
 __global__ __launch_bounds__(64) void k_resolve_lane(const uint32_t *__restrict__ list, const Counters *c,
-                                                     const Occ *__restrict__ occ, const SortedRec *__restrict__ sorted,
+                                                     const Occ *__restrict__ occ, SortedView sorted,
                                                      Materials m, uint4 *out, uint32_t list_cap, Params p)
 {
     __shared__ uint64_t s_key[kLaneList][64];
@@ -1521,7 +1540,7 @@ __global__ __launch_bounds__(64) void k_resolve_lane(const uint32_t *__restrict_
         const Occ o = occ[i];
         const uint32_t n = o.count < kLaneList ? o.count : kLaneList;
         for (uint32_t k = 0; k < n; ++k) {
-            const SortedRec &r = sorted[o.offset + k];
+            const SortedRec r = sorted.load(o.offset + k);
             const uint64_t key = ((uint64_t) r.keyhi << 32) | r.keylo;
             uint32_t j = k;
             while (j > 0 && s_key[j - 1][lane] > key) {
@@ -1534,7 +1553,7 @@ __global__ __launch_bounds__(64) void k_resolve_lane(const uint32_t *__restrict_
         }
         CellFold f;
         for (uint32_t t = 0; t < n; ++t) {
-            const SortedRec r = sorted[o.offset + s_idx[t][lane]];
+            const SortedRec r = sorted.load(o.offset + s_idx[t][lane]);
             f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
         }
         out[i] = cell_record(o, f.finish(m, p.blend), p);
@@ -1573,7 +1592,7 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_
 template <uint32_t THREADS, uint32_t CAP>
 __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
                                                             uint32_t *cursor, const Occ *__restrict__ occ,
-                                                            const SortedRec *__restrict__ sorted, Materials m, uint4 *out,
+                                                            SortedView sorted, Materials m, uint4 *out,
                                                             uint32_t list_cap, Params p)
 {
     __shared__ uint64_t s_key[CAP];
@@ -1595,7 +1614,7 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
         while (n_pow2 < n) n_pow2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n_pow2; t += THREADS) {
             if (t < n) {
-                const SortedRec &r = sorted[o.offset + t];
+                const SortedRec r = sorted.load(o.offset + t);
                 s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
                 s_idx[t] = t;
             }
@@ -1607,7 +1626,7 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
         __syncthreads();
         bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, THREADS);
         for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
-            const SortedRec &r = sorted[o.offset + s_idx[t]];
+            const SortedRec r = sorted.load(o.offset + s_idx[t]);
             s_hi[t] = r.keyhi;
             s_w[t] = r.w;
             s_u[t] = r.u;
@@ -1666,7 +1685,7 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
 // Tier 4: cells with more than 2048 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
 // pairs in a global scratch area; each cell bump-allocates a power-of-two range (scratch holds 2 * cap_hits pairs).
 __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restrict__ list, Counters *c,
-                                                         const Occ *__restrict__ occ, const SortedRec *__restrict__ sorted,
+                                                         const Occ *__restrict__ occ, SortedView sorted,
                                                          Materials m, uint4 *out, uint64_t *scratch_key,
                                                          uint32_t *scratch_idx, uint32_t scratch_cap, uint32_t list_cap,
                                                          Params p)
@@ -1695,7 +1714,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
         uint32_t *idx = scratch_idx + s_base;
         for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
             if (t < n) {
-                const SortedRec &r = sorted[o.offset + t];
+                const SortedRec r = sorted.load(o.offset + t);
                 key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
                 idx[t] = t;
             }
@@ -1709,7 +1728,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
         if (threadIdx.x == 0) {
             CellFold f;
             for (uint32_t t = 0; t < n; ++t) {
-                const SortedRec r = sorted[o.offset + idx[t]];
+                const SortedRec r = sorted.load(o.offset + idx[t]);
                 f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
             }
             out[i] = cell_record(o, f.finish(m, p.blend), p);
@@ -1746,7 +1765,8 @@ struct o2v_hip_ctx {
     BigLeaf *d_big = nullptr;
     Node *d_nodes[2] = {nullptr, nullptr};
     HitRec *d_pool = nullptr;
-    SortedRec *d_sorted = nullptr;  // cap_hits records
+    SortedRec *d_sorted = nullptr;  // cap_hits records (read through SortedView: 24 or 16 bytes per record)
+    uint32_t sorted_stride = 6;
     Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
     uint32_t *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_huge = nullptr;  // cap_vox each
@@ -1882,7 +1902,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                            ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, p);
         O2V_STAGE("k_scan_bricks");
         hipLaunchKernelGGL(k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
-                           ctx->d_sorted, p);
+                           reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
         O2V_STAGE("k_scatter");
         hipLaunchKernelGGL(k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr);
@@ -1892,24 +1912,25 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 
     {
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
+        const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
         ResolveLists lists{ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
-        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, ctx->d_sorted, ctx->d_ctr, m,
+        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
                            ctx->d_out, lists, p);
         O2V_STAGE("k_resolve");
         hipLaunchKernelGGL(k_resolve_lane, dim3((uint32_t) ctx->num_cus * 4u), dim3(64), 0, s, ctx->d_list_lane, ctx->d_ctr,
-                           ctx->d_occ, ctx->d_sorted, m, ctx->d_out, p.cap_vox, p);
+                           ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_lane");
         hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, s,
-                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, ctx->d_sorted, m,
+                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
         hipLaunchKernelGGL((k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s,
-                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, ctx->d_sorted, m,
+                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
         if (ctx->d_scratch_key) {
             hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus), dim3(kBlock), 0, s, ctx->d_list_huge,
-                               ctx->d_ctr, ctx->d_occ, ctx->d_sorted, m, ctx->d_out, ctx->d_scratch_key,
+                               ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, ctx->d_scratch_key,
                                ctx->d_scratch_idx, ctx->cap_scratch, p.cap_vox, p);
             O2V_STAGE("k_resolve_huge");
         }
@@ -2091,6 +2112,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];
     p.has_uv = ctx->d_uvs ? 1u : 0u;
     const bool use_uv = ctx->d_uvs && ctx->any_textured;
+    ctx->sorted_stride = use_uv ? 6u : 4u;
 
     // dense grid for the slab (bricked, see cell_index) + one dirty flag per brick; allocated zeroed, kept clean
     // by k_scan_flags / k_scan_bricks
@@ -2283,15 +2305,18 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
     for (uint64_t i = 0; i < ctx->n_vox; ++i) {
         if (vox[i].x != x || vox[i].y != y || vox[i].z != z) continue;
         const uint32_t n = occ[i].count < max_records ? occ[i].count : max_records;
-        std::vector<SortedRec> recs(n);
-        if (n) O2V_CHECK(hipMemcpy(recs.data(), ctx->d_sorted + occ[i].offset, n * sizeof(SortedRec), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> raw((size_t) n * ctx->sorted_stride);
+        if (n)
+            O2V_CHECK(hipMemcpy(raw.data(), reinterpret_cast<const uint32_t *>(ctx->d_sorted) + (size_t) occ[i].offset * ctx->sorted_stride,
+                                raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t *r = &raw[(size_t) k * ctx->sorted_stride];
             uint32_t *o = out + k * 6;
-            o[0] = recs[k].keyhi;
-            o[1] = recs[k].keylo;
-            std::memcpy(&o[2], &recs[k].w, 4);
-            std::memcpy(&o[3], &recs[k].u, 4);
-            std::memcpy(&o[4], &recs[k].v, 4);
+            o[0] = r[0];
+            o[1] = r[1];
+            o[2] = r[2];
+            o[3] = ctx->sorted_stride == 6 ? r[3] : 0u;
+            o[4] = ctx->sorted_stride == 6 ? r[4] : 0u;
             o[5] = occ[i].offset + k;
         }
         *out_count = n;

@@ -393,16 +393,35 @@ struct BlockSlots {
     uint32_t leaf, tile, big, node;
 };
 
-// One reservation per counter per workgroup (a per-lane atomic on one address would serialise at ~88/us).
+// One reservation per counter per workgroup (a per-lane atomic on one address would serialise at ~88/us).  The four
+// per-lane counts are packed into one 64-bit value (tiles: 31 bits; leaves, big leaves, nodes: 11 bits each, a lane
+// emits at most 4 of each, so a block at most 1024) so that a single block scan yields all four offsets.
 __device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, uint32_t node_round, uint32_t *s_wave,
                                                     uint32_t *s_base)
 {
-    uint32_t tot_leaf, tot_tile, tot_big, tot_node;
-    BlockSlots off;
-    off.leaf = block_exscan(e.n_leaf, s_wave, tot_leaf);
-    off.tile = block_exscan(e.n_tile, s_wave, tot_tile);
-    off.big = block_exscan(e.n_big, s_wave, tot_big);
-    off.node = block_exscan(e.n_node, s_wave, tot_node);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mine = (unsigned long long) e.n_tile | ((unsigned long long) e.n_leaf << 31) |
+                                    ((unsigned long long) e.n_big << 42) | ((unsigned long long) e.n_node << 53);
+    unsigned long long inc = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    unsigned long long *s_wave64 = reinterpret_cast<unsigned long long *>(s_wave);  // [kBlock / 64], 8-byte aligned
+    __syncthreads();
+    if (lane == 63) s_wave64[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const unsigned long long v = s_wave64[w];
+        if (w < wave) base += v;
+        tot += v;
+    }
+    const unsigned long long ex = base + inc - mine;
+    const uint32_t tot_tile = (uint32_t) tot & 0x7fffffffu, tot_leaf = (uint32_t) (tot >> 31) & 2047u,
+                   tot_big = (uint32_t) (tot >> 42) & 2047u, tot_node = (uint32_t) (tot >> 53) & 2047u;
     __syncthreads();
     if (threadIdx.x == 0) {
         s_base[0] = tot_leaf ? atomicAdd(&c->n_leaves, tot_leaf) : 0u;
@@ -411,10 +430,11 @@ __device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, 
         s_base[3] = tot_node ? atomicAdd(&c->n_nodes[node_round], tot_node) : 0u;
     }
     __syncthreads();
-    off.leaf += s_base[0];
-    off.tile += s_base[1];
-    off.big += s_base[2];
-    off.node += s_base[3];
+    BlockSlots off;
+    off.tile = ((uint32_t) ex & 0x7fffffffu) + s_base[1];
+    off.leaf = ((uint32_t) (ex >> 31) & 2047u) + s_base[0];
+    off.big = ((uint32_t) (ex >> 42) & 2047u) + s_base[2];
+    off.node = ((uint32_t) (ex >> 53) & 2047u) + s_base[3];
     return off;
 }
 
@@ -424,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
                                                          Counters *c, Leaf *leaves, Tile *tiles, BigLeaf *big,
                                                          Node *nodes_out, Params p)
 {
-    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ __align__(8) uint32_t s_wave[2 * (kBlock / 64)];
     __shared__ uint32_t s_base[4];
     __shared__ float s_v[kBlock * 9];
     __shared__ float s_t[kBlock * 6];
@@ -521,7 +541,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_nodes(const Node *__restrict_
                                                          Leaf *leaves, Tile *tiles, BigLeaf *big, Node *nodes_out,
                                                          Params p)
 {
-    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ __align__(8) uint32_t s_wave[2 * (kBlock / 64)];
     __shared__ uint32_t s_base[4];
     __shared__ unsigned long long s_cand;
     const uint32_t n_in = c->n_nodes[round] < p.cap_nodes ? c->n_nodes[round] : p.cap_nodes;

@@ -1486,11 +1486,13 @@ struct ResolveLists {  // cells k_resolve defers, by hit count class (indices in
 
 // Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
 // from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
-__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted,
+template <uint32_t STRIDE>
+__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn,
                                                     Counters *c, Materials m, uint4 *out, ResolveLists lists, Params p)
 {
     __shared__ uint64_t s_key[kShortList][kBlock];
     __shared__ float s_w[kShortList][kBlock], s_u[kShortList][kBlock], s_v[kShortList][kBlock];
+    const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads below stay branch-free
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
@@ -1934,8 +1936,12 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
         const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
         ResolveLists lists{ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
-        hipLaunchKernelGGL(k_resolve, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
-                           ctx->d_out, lists, p);
+        if (use_uv)
+            hipLaunchKernelGGL(k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+                               ctx->d_out, lists, p);
+        else
+            hipLaunchKernelGGL(k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+                               ctx->d_out, lists, p);
         O2V_STAGE("k_resolve");
         hipLaunchKernelGGL(k_resolve_lane, dim3((uint32_t) ctx->num_cus * 4u), dim3(64), 0, s, ctx->d_list_lane, ctx->d_ctr,
                            ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);

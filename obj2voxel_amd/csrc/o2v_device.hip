@@ -129,7 +129,7 @@ struct Counters {
     uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
     uint32_t n_vox, batch_cursor, err_flags, pad0;
     uint32_t n_mid, n_long, n_huge, scratch_used;
-    uint32_t n_dirty, n_sorted, pad4[2];
+    uint32_t n_dirty, n_sorted, n_bigl, cursor_big;
     uint32_t cursor_mid, cursor_long, cursor_huge, n_lane;
     uint32_t n_nodes[kMaxRounds + 1];
     uint32_t pad1[3];
@@ -1477,10 +1477,12 @@ __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const 
 constexpr uint32_t kShortList = 8;     // cells with up to this many hits are sorted in registers by k_resolve
 constexpr uint32_t kLaneList = 32;     // up to this: still one lane per cell, insertion sort in a private LDS column
 constexpr uint32_t kMidList = 256;     // up to this: one wavefront per cell, LDS bitonic sort
-constexpr uint32_t kLongList = 2048;   // up to this: one workgroup per cell, LDS bitonic sort; beyond: global sort
+constexpr uint32_t kLongList = 2048;   // up to this: one workgroup per cell, LDS bitonic sort
+constexpr uint32_t kBigList = 8192;    // up to this: one workgroup per cell, keys + indices in 96 KiB of dynamic LDS;
+                                       // beyond: global-memory sort
 
 struct ResolveLists {  // cells k_resolve defers, by hit count class (indices into occ[])
-    uint32_t *lane, *mid, *lng, *huge;
+    uint32_t *lane, *mid, *lng, *big, *huge;
     uint32_t cap;
 };
 
@@ -1498,13 +1500,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         const Occ o = occ[i];
         if (o.count > kShortList) {
             // deferred to a cooperative tier; one atomic per wavefront and class, not per cell
-            const uint32_t cls = o.count <= kLaneList ? 0u : (o.count <= kMidList ? 1u : (o.count <= kLongList ? 2u : 3u));
+            const uint32_t cls = o.count <= kLaneList ? 0u : (o.count <= kMidList ? 1u : (o.count <= kLongList ? 2u : (o.count <= kBigList ? 3u : 4u)));
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
+            for (uint32_t k = 0; k < 5; ++k) {
                 const unsigned long long mk = __ballot(cls == k);
                 if (cls == k) {
-                    uint32_t *list = k == 0 ? lists.lane : (k == 1 ? lists.mid : (k == 2 ? lists.lng : lists.huge));
-                    uint32_t *ctr = k == 0 ? &c->n_lane : (k == 1 ? &c->n_mid : (k == 2 ? &c->n_long : &c->n_huge));
+                    uint32_t *list = k == 0 ? lists.lane : (k == 1 ? lists.mid : (k == 2 ? lists.lng : (k == 3 ? lists.big : lists.huge)));
+                    uint32_t *ctr = k == 0 ? &c->n_lane : (k == 1 ? &c->n_mid : (k == 2 ? &c->n_long : (k == 3 ? &c->n_bigl : &c->n_huge)));
                     const uint32_t leader = (uint32_t) __ffsll((long long) mk) - 1u;
                     const uint32_t lane = threadIdx.x & 63u;
                     uint32_t base = 0;
@@ -1704,7 +1706,107 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
     }
 }
 
-// Tier 4: cells with more than 2048 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
+// Tier 3b: cells with 2049..8192 hits (the poles of a finely tessellated sphere at high resolution).  One workgroup
+// per cell; (key, idx) pairs are bitonic-sorted in dynamic LDS (96 KiB), the payload stays in global memory: MAX
+// folds the groups in parallel straight from it, BLEND stages it in sorted order, 1024 records at a time, for the
+// sequential replay.
+constexpr uint32_t kBigStage = 1024;
+__global__ __launch_bounds__(kBlock) void k_resolve_big(const uint32_t *__restrict__ list, Counters *c,
+                                                        const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                        uint4 *out, uint32_t list_cap, Params p)
+{
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    uint64_t *s_key = reinterpret_cast<uint64_t *>(s_dyn);                                  // [kBigList]
+    uint32_t *s_idx = reinterpret_cast<uint32_t *>(s_dyn + (size_t) kBigList * 8);           // [kBigList]
+    __shared__ uint32_t s_hi[kBigStage];
+    __shared__ float s_w[kBigStage], s_u[kBigStage], s_v[kBigStage];
+    __shared__ unsigned long long s_best[kBlock / 64];
+    __shared__ uint32_t s_item;
+    const uint32_t total = c->n_bigl < list_cap ? c->n_bigl : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(&c->cursor_big, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count < kBigList ? o.count : kBigList;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
+            if (t < n) {
+                const SortedRec r = sorted.load(o.offset + t);
+                s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                s_idx[t] = t;
+            }
+            else {
+                s_key[t] = ~0ull;
+                s_idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, kBlock);
+        if (p.blend) {
+            CellFold f;  // only thread 0's copy is used
+            for (uint32_t base = 0; base < n; base += kBigStage) {
+                const uint32_t m_here = n - base < kBigStage ? n - base : kBigStage;
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < m_here; t += kBlock) {
+                    const SortedRec r = sorted.load(o.offset + s_idx[base + t]);
+                    s_hi[t] = r.keyhi;
+                    s_w[t] = r.w;
+                    s_u[t] = r.u;
+                    s_v[t] = r.v;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    for (uint32_t t = 0; t < m_here; ++t) f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
+            }
+            if (threadIdx.x == 0) out[i] = cell_record(o, f.finish(m, p.blend), p);
+        }
+        else {
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += kBlock) {
+                const uint32_t hi = (uint32_t) (s_key[t] >> 32);
+                if (t == 0 || (uint32_t) (s_key[t - 1] >> 32) != hi) {
+                    SortedRec r = sorted.load(o.offset + s_idx[t]);
+                    WUv acc{r.w, r.u, r.v};
+                    for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
+                        r = sorted.load(o.offset + s_idx[j]);
+                        acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                    }
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBlock / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                const uint32_t hi = (uint32_t) (s_key[t] >> 32);
+                SortedRec r = sorted.load(o.offset + s_idx[t]);
+                WUv acc{r.w, r.u, r.v};
+                for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
+                    r = sorted.load(o.offset + s_idx[j]);
+                    acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                }
+                float cr, cg, cb;
+                color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+            }
+        }
+    }
+}
+
+// Tier 4: cells with more than 8192 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
 // pairs in a global scratch area; each cell bump-allocates a power-of-two range (scratch holds 2 * cap_hits pairs).
 __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restrict__ list, Counters *c,
                                                          const Occ *__restrict__ occ, SortedView sorted,
@@ -1713,6 +1815,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
                                                          Params p)
 {
     __shared__ uint32_t s_item, s_base, s_ok;
+    __shared__ unsigned long long s_best[kBlock / 64];
     const uint32_t total = c->n_huge < list_cap ? c->n_huge : list_cap;
     for (;;) {
         __syncthreads();
@@ -1747,13 +1850,55 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
         }
         __syncthreads();
         bitonic_sort(key, idx, n_pow2, threadIdx.x, kBlock);
-        if (threadIdx.x == 0) {
-            CellFold f;
-            for (uint32_t t = 0; t < n; ++t) {
-                const SortedRec r = sorted.load(o.offset + idx[t]);
-                f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
+        if (p.blend) {
+            // BLEND: sequential by nature (see k_resolve_sorted)
+            if (threadIdx.x == 0) {
+                CellFold f;
+                for (uint32_t t = 0; t < n; ++t) {
+                    const SortedRec r = sorted.load(o.offset + idx[t]);
+                    f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
+                }
+                out[i] = cell_record(o, f.finish(m, p.blend), p);
             }
-            out[i] = cell_record(o, f.finish(m, p.blend), p);
+        }
+        else {
+            // MAX: fold every (sub-voxel, triangle) group at its first record, max-reduce with ties to the earlier group
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += kBlock) {
+                const uint32_t hi = (uint32_t) (key[t] >> 32);
+                if (t == 0 || (uint32_t) (key[t - 1] >> 32) != hi) {
+                    SortedRec r = sorted.load(o.offset + idx[t]);
+                    WUv acc{r.w, r.u, r.v};
+                    for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
+                        r = sorted.load(o.offset + idx[j]);
+                        acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                    }
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBlock / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                const uint32_t hi = (uint32_t) (key[t] >> 32);
+                SortedRec r = sorted.load(o.offset + idx[t]);
+                WUv acc{r.w, r.u, r.v};
+                for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
+                    r = sorted.load(o.offset + idx[j]);
+                    acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                }
+                float cr, cg, cb;
+                color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+            }
         }
     }
 }
@@ -1791,7 +1936,8 @@ struct o2v_hip_ctx {
     uint32_t sorted_stride = 6;
     Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
-    uint32_t *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_huge = nullptr;  // cap_vox each
+    uint32_t *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_big = nullptr,
+             *d_list_huge = nullptr;  // cap_vox each
     uint64_t *d_scratch_key = nullptr;  // tier-4 resolve scratch, allocated on first need
     uint32_t *d_scratch_idx = nullptr;
     uint32_t cap_scratch = 0;
@@ -1935,7 +2081,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     {
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
         const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
-        ResolveLists lists{ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, p.cap_vox};
+        ResolveLists lists{ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
         if (use_uv)
             hipLaunchKernelGGL(k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
                                ctx->d_out, lists, p);
@@ -1943,10 +2089,10 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             hipLaunchKernelGGL(k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
                                ctx->d_out, lists, p);
         O2V_STAGE("k_resolve");
-        hipLaunchKernelGGL(k_resolve_lane, dim3((uint32_t) ctx->num_cus * 4u), dim3(64), 0, s, ctx->d_list_lane, ctx->d_ctr,
+        hipLaunchKernelGGL(k_resolve_lane, dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, s, ctx->d_list_lane, ctx->d_ctr,
                            ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_lane");
-        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, s,
+        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 32u), dim3(64), 0, s,
                            ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
@@ -1954,6 +2100,9 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                            ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
+        hipLaunchKernelGGL(k_resolve_big, dim3((uint32_t) ctx->num_cus), dim3(kBlock), kBigList * 12u, s, ctx->d_list_big,
+                           ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_STAGE("k_resolve_big");
         if (ctx->d_scratch_key) {
             hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus), dim3(kBlock), 0, s, ctx->d_list_huge,
                                ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, ctx->d_scratch_key,
@@ -2005,6 +2154,9 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
+    // k_resolve_big sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int) (kBigList * 12u));
     *out_ctx = ctx;
     return O2V_HIP_OK;
 }
@@ -2017,7 +2169,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
                     ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid,
-                    ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
+                    ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
@@ -2214,7 +2366,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
-        for (uint32_t **lp : {&ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_huge}) {
+        for (uint32_t **lp : {&ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
             uint32_t cap_l = ctx->cap_vox;
             if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;
         }

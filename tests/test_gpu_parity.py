@@ -228,6 +228,22 @@ def test_long_hit_lists(dv, oracle, strategy):
         _compare(got, want)
 
 
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_big_and_huge_hit_lists(dv, oracle, strategy):
+    """39 600 triangles into 8 cells (~5-10 k hits each: the dynamic-LDS tier, 2049..8192 hits) and into a single
+    cell (> 8192 hits: the global-memory sort)."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(100)
+    T = len(v)
+    kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=strategy)
+    for res in (3, 2, 1):
+        got, want = _run_both(dv, oracle, v, res, **kw)
+        _compare(got, want)
+        st = dv.stats()
+        assert st["hits"] >= T
+    assert st["voxels"] == 1 and st["hits"] > 8192
+
+
 def test_baseline_config2_spot_512_blend_textured(dv, oracle):
     """BASELINE.json configs[1]: 'Spot cow at 512^3, weighted-blend, 1xMI355X' with the survey's stand-in
     (uv-sphere nv=39 -> 5928 triangles, textured). Full size, bit-exact against the oracle."""

@@ -12,8 +12,10 @@ One step = one pass of the whole device pipeline (bounds -> transform -> exact s
 -> grid scan -> ordered resolve) over triangles already resident in HBM, leaving the (x, y, z, argb) records
 in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the grid is split into N z-slabs,
 every rank voxelizes its slab from the replicated triangle list (triangles are binned to slabs on the device
-by AABB; no data-path collective is needed: SURVEY.md section 8e).  Scaling is weak: the job grows with N so
-that triangles and output voxels per GPU stay fixed (resolution 1024*sqrt(N), nv = 467*sqrt(N)).
+by AABB; no data-path collective is needed: SURVEY.md section 8e).  The slab cuts are work-balanced: each step
+every rank runs o2v_hip_plan_slabs (a z-histogram of predicted hits over the replicated triangles) and takes its
+own slab, so the plan's cost is inside the timed region.  Scaling is weak: the job grows with N so that triangles
+and output voxels per GPU stay fixed on average (resolution 1024*sqrt(N), nv = 467*sqrt(N)).
 """
 import argparse
 import json
@@ -43,6 +45,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path on a single-GPU box)")
     ap.add_argument("--same-device", action="store_true", help="debugging: every rank uses GPU 0")
+    ap.add_argument("--equal-slabs", action="store_true", help="N > 1: equal-height z-slabs instead of the work-balanced plan")
     ap.add_argument("--resolution", type=int, default=0, help="override (debugging only; invalidates the metric)")
     ap.add_argument("--nv", type=int, default=0, help="override (debugging only; invalidates the metric)")
     args = ap.parse_args()
@@ -91,7 +94,14 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        return dv.voxelize(res, zslab=(z0, z1) if n > 1 else (0, 0), read=False)
+        if n == 1:
+            return dv.voxelize(res, read=False)
+        if args.equal_slabs:
+            return dv.voxelize(res, zslab=(z0, z1), read=False)
+        # every rank derives the same work-balanced cuts from the replicated triangles (o2v_hip_plan_slabs, part of the
+        # timed step: a new mesh needs a new plan), then voxelizes its own slab; the plan's bounds save a second pass
+        cuts, bnd = dv.plan_slabs(res, n)
+        return dv.voxelize(res, zslab=(cuts[rank], cuts[rank + 1]), bounds=bnd, read=False)
 
     for _ in range(args.warmup):
         step()
@@ -141,8 +151,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes": alg_bytes[dom], "kernel_ms": round(stage_avg[dom], 4)}
         # the fixed whole-pipeline numerator of SURVEY.md section 8d: 8*G^3 + 16*V + 76*T
-        z0_, z1_ = slabs.slab_range(0, n, res)
-        b_alg = 8 * n * (z1_ - z0_) * res * res + 16 * total_voxels + 76 * T
+        b_alg = 8 * res * res * res + 16 * total_voxels + 76 * T
         pipeline = {"b_alg_bytes": b_alg, "device_ms": round(stage_avg["total_ms"], 4),
                     "gbs": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -94,6 +94,19 @@ int o2v_hip_set_textures(o2v_hip_ctx *ctx, const o2v_hip_texture *textures, uint
 /* Runs the whole device pipeline and waits for it.  out_voxel_count receives the number of occupied voxels. */
 int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *out_voxel_count);
 
+/* Work-balanced z-slabs for a multi-GPU job (one process per GPU, every process holding the same triangles):
+ * writes n_slabs+1 ascending output-z cuts to out_z (out_z[0] = 0, out_z[n_slabs] = resolution); slab k is
+ * [out_z[k], out_z[k+1]) and goes into o2v_hip_params::z_begin/z_end of rank k.  The cuts equalise the predicted
+ * number of (triangle, voxel) hits per slab, which the pipeline's time is proportional to; they are a pure
+ * function of the triangles and the parameters, so every rank computes the same ones without communicating.
+ * The reference balances its worker pool dynamically over 64^3 chunks (src/obj2voxel.cpp:482-497); slabs are
+ * static, hence the up-front plan.  out_bounds (optional, 6 floats: min xyz, max xyz) receives the mesh bounds
+ * found on the way (reference findMeshBounds, src/obj2voxel.cpp:180-200): passing them back as
+ * o2v_hip_params::bounds with bounds_known = 1 saves the voxelize call its own bounds pass.  z_begin/z_end of
+ * `params` are ignored. */
+int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t n_slabs, uint32_t *out_z,
+                       float *out_bounds);
+
 /* Copies voxels [first, first+count) of the last result to host memory as (x, y, z, argb) uint32 quadruples,
  * the layout of the reference's voxel callback (include/obj2voxel.h:35,200-209).  Order is unspecified. */
 int o2v_hip_read_voxels(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count);

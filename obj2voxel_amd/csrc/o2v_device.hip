@@ -127,12 +127,12 @@ struct DevTexture {
 
 struct Counters {
     uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
-    uint32_t n_vox, batch_cursor, err_flags, pad0;
+    uint32_t n_vox, batch_cursor, err_flags, n_lane16;
     uint32_t n_mid, n_long, n_huge, scratch_used;
     uint32_t n_dirty, n_sorted, n_bigl, cursor_big;
     uint32_t cursor_mid, cursor_long, cursor_huge, n_lane;
     uint32_t n_nodes[kMaxRounds + 1];
-    uint32_t pad1[3];
+    uint32_t n_w64, pad1[2];
     unsigned long long n_candidates, n_hits;
     uint32_t bounds_enc[6];
     uint32_t pad2[2];
@@ -297,6 +297,53 @@ __global__ void k_setup(Counters *c, Params p)
     c->xform[9] = a.t.x;
     c->xform[10] = a.t.y;
     c->xform[11] = a.t.z;
+}
+
+// ---- slab planning: where to cut the grid so that N GPUs get equal work ------------------------------------
+//
+// Pipeline time is proportional to the number of (triangle, voxel) hits (measured: 0.23 ms per million on every
+// slab of the weak-scaling job), and the hits of one triangle are predicted to ~0.1 % per slab by the Steiner-type
+// count  A_x + A_y + A_z + (L1 perimeter) / 2 + 1  (projected areas and edge lengths in voxel units).  k_zhist
+// spreads that estimate over the triangle's z layers into <= 2048 bins (fixed point, integer atomics: the result
+// does not depend on the order of the adds, so every rank derives the same cuts).
+constexpr uint32_t kPlanBins = 2048;
+__global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ verts, const Counters *__restrict__ c,
+                                                   unsigned long long *hist, Params p, uint32_t bin_h)
+{
+    __shared__ unsigned long long s_hist[kPlanBins];
+    __shared__ float s_v[kBlock * 9];
+    for (uint32_t t = threadIdx.x; t < kPlanBins; t += kBlock) s_hist[t] = 0;
+    Affine a;
+    for (int i = 0; i < 3; ++i) a.m[i] = {c->xform[i * 3], c->xform[i * 3 + 1], c->xform[i * 3 + 2]};
+    a.t = {c->xform[9], c->xform[10], c->xform[11]};
+    for (uint64_t base = (uint64_t) blockIdx.x * kBlock; base < p.n_tris; base += (uint64_t) gridDim.x * kBlock) {
+        __syncthreads();
+        const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
+        for (uint32_t k = threadIdx.x; k < n_here * 9; k += kBlock) s_v[k] = verts[base * 9 + k];
+        __syncthreads();
+        if (threadIdx.x >= n_here) continue;
+        const float *q = &s_v[threadIdx.x * 9];
+        const V3 v0 = affine_apply(a, V3{q[0], q[1], q[2]}), v1 = affine_apply(a, V3{q[3], q[4], q[5]}),
+                 v2 = affine_apply(a, V3{q[6], q[7], q[8]});
+        const V3 n = tri_normal(v0, v1, v2), e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
+        float est = (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) * 0.5f +
+                    (abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z) + abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z) + abs_f(e2.x) +
+                     abs_f(e2.y) + abs_f(e2.z)) * 0.5f + 1.0f;
+        if (!(est < 1e12f)) est = 1e12f;  // also catches NaN
+        const float zlo = fmin2(v0.z, fmin2(v1.z, v2.z)), zhi = fmax2(v0.z, fmax2(v1.z, v2.z));
+        if (!(zhi >= 0.f) || !(zlo < (float) p.S)) continue;
+        const uint32_t l0 = zlo > 0.f ? (uint32_t) zlo : 0u;
+        const uint32_t l1 = zhi < (float) (p.S - 1) ? (uint32_t) zhi : p.S - 1;
+        const float per_layer = est * 16.0f / (float) (l1 - l0 + 1);
+        for (uint32_t b = l0 / bin_h; b <= l1 / bin_h; ++b) {
+            const uint32_t lo = b * bin_h > l0 ? b * bin_h : l0;
+            const uint32_t hi = (b + 1) * bin_h - 1 < l1 ? (b + 1) * bin_h - 1 : l1;
+            atomicAdd(&s_hist[b], (unsigned long long) (per_layer * (float) (hi - lo + 1) + 0.5f));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < kPlanBins; t += kBlock)
+        if (s_hist[t]) atomicAdd(&hist[t], s_hist[t]);
 }
 
 // ---- K1: leaves --------------------------------------------------------------------------------------------
@@ -1248,12 +1295,50 @@ constexpr uint32_t kScanBricksPerRound = (kBlock / 64) * kScanBricksPerWave;  //
 constexpr uint32_t kScanFlushAt = 2048;
 constexpr uint32_t kScanCap = kScanFlushAt + kScanBricksPerRound * kBrickCells;
 
+constexpr uint32_t kShortList = 8;     // cells with up to this many hits are sorted in registers by k_resolve
+constexpr uint32_t kLane16List = 16;   // up to this: 16 lanes per cell, bitonic sort in registers (k_resolve_wave<16>)
+constexpr uint32_t kLaneList = 32;     // up to this: 32 lanes per cell (k_resolve_wave<32>)
+constexpr uint32_t kWaveList = 64;     // up to this: one wavefront per cell (k_resolve_wave<64>)
+constexpr uint32_t kMidList = 256;     // up to this: one wavefront per cell, LDS bitonic sort
+constexpr uint32_t kLongList = 2048;   // up to this: one workgroup per cell, LDS bitonic sort
+constexpr uint32_t kBigList = 8192;    // up to this: one workgroup per cell, keys + indices in 96 KiB of dynamic LDS;
+                                       // beyond: global-memory sort
+
+struct ResolveLists {  // cells k_resolve defers, by hit count class (indices into occ[])
+    uint32_t *lane16, *lane, *w64, *mid, *lng, *big, *huge;
+    uint32_t cap;
+};
+
+// Cells with more than kShortList hits are resolved by the cooperative tiers; k_scan_bricks files them by hit count
+// while it builds occ[] (one global atomic per class and flush), so that every resolve tier can start at once.
+constexpr uint32_t kResolveClasses = 7;
+__device__ __forceinline__ uint32_t resolve_class(uint32_t cnt)
+{
+    return cnt <= kLane16List ? 0u
+           : cnt <= kLaneList ? 1u
+           : cnt <= kWaveList ? 2u
+           : cnt <= kMidList  ? 3u
+           : cnt <= kLongList ? 4u
+           : cnt <= kBigList  ? 5u
+                              : 6u;
+}
+__device__ __forceinline__ uint32_t *class_list(const ResolveLists &l, uint32_t k)
+{
+    return k == 0 ? l.lane16 : k == 1 ? l.lane : k == 2 ? l.w64 : k == 3 ? l.mid : k == 4 ? l.lng : k == 5 ? l.big : l.huge;
+}
+__device__ __forceinline__ uint32_t *class_counter(Counters *c, uint32_t k)
+{
+    return k == 0 ? &c->n_lane16 : k == 1 ? &c->n_lane : k == 2 ? &c->n_w64 : k == 3 ? &c->n_mid : k == 4 ? &c->n_long
+           : k == 5 ? &c->n_bigl : &c->n_huge;
+}
+
 // Writes the staged occupied cells of one workgroup to `occ`, giving every cell the offset of its hits in the sorted
 // record array: one reservation of (cells, hits) per flush, offsets by a block-level prefix sum over the counts.
 // The offset is also stored in the cell itself, where k_scatter reads it.
-__device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi, const uint32_t *s_cnt,
-                                           uint32_t *s_wave, uint32_t *s_base, uint32_t *grid, Counters *c, Occ *occ,
-                                           const Params &p)
+__device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi, uint32_t *s_cnt,
+                                           uint32_t *s_wave, uint32_t *s_base, uint32_t *s_cls /*[7], zero*/,
+                                           uint32_t *s_cls_base /*[7]*/, uint32_t *grid, Counters *c, Occ *occ,
+                                           const ResolveLists &lists, const Params &p)
 {
     // thread t owns the entries [t * per, (t + 1) * per)
     const uint32_t per = (n + kBlock - 1) / kBlock;
@@ -1272,18 +1357,39 @@ __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, con
     run += s_base[1];
     for (uint32_t i = lo; i < hi; ++i) {
         const uint32_t cnt = s_cnt[i];
-        if (base_vox + i < p.cap_vox) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], run, cnt};
+        const bool listed = base_vox + i < p.cap_vox;
+        if (listed) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], run, cnt};
         grid[((uint64_t) s_hi[i] << 32) | s_lo[i]] = run;
+        if (cnt > kShortList && listed) {
+            // rank within its class among this flush's cells; the count is not needed again, the slot keeps the tag
+            const uint32_t cls = resolve_class(cnt);
+            s_cnt[i] = 0x80000000u | (cls << 24) | atomicAdd(&s_cls[cls], 1u);
+        }
         run += cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < kResolveClasses) {
+        const uint32_t n_cls = s_cls[threadIdx.x];
+        s_cls[threadIdx.x] = 0;
+        if (n_cls) s_cls_base[threadIdx.x] = atomicAdd(class_counter(c, threadIdx.x), n_cls);
+    }
+    __syncthreads();
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t tag = s_cnt[i];
+        if (tag & 0x80000000u) {
+            const uint32_t cls = (tag >> 24) & 7u, slot = s_cls_base[cls] + (tag & 0xffffffu);
+            if (slot < lists.cap) class_list(lists, cls)[slot] = base_vox + i;
+        }
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const uint32_t *__restrict__ dirty_list,
-                                                        Counters *c, Occ *occ, Params p)
+                                                        Counters *c, Occ *occ, ResolveLists lists, Params p)
 {
     __shared__ uint32_t s_lo[kScanCap], s_hi[kScanCap], s_cnt[kScanCap];
-    __shared__ uint32_t s_n, s_base[2], s_wave[kBlock / 64];
+    __shared__ uint32_t s_n, s_base[2], s_wave[kBlock / 64], s_cls[kResolveClasses], s_cls_base[kResolveClasses];
     if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x < kResolveClasses) s_cls[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t n_dirty = c->n_dirty;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1319,14 +1425,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
         __syncthreads();
         const uint32_t n = s_n;
         if (n >= kScanFlushAt) {
-            scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, grid, c, occ, p);
+            scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
             __syncthreads();
             if (threadIdx.x == 0) s_n = 0;
         }
         __syncthreads();
     }
     const uint32_t n = s_n;
-    if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, grid, c, occ, p);
+    if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
 }
 
 // ---- K5b: scatter --------------------------------------------------------------------------------------------
@@ -1474,23 +1580,12 @@ __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const 
     return make_uint4(x, y, z + p.zo0, argb);
 }
 
-constexpr uint32_t kShortList = 8;     // cells with up to this many hits are sorted in registers by k_resolve
-constexpr uint32_t kLaneList = 32;     // up to this: still one lane per cell, insertion sort in a private LDS column
-constexpr uint32_t kMidList = 256;     // up to this: one wavefront per cell, LDS bitonic sort
-constexpr uint32_t kLongList = 2048;   // up to this: one workgroup per cell, LDS bitonic sort
-constexpr uint32_t kBigList = 8192;    // up to this: one workgroup per cell, keys + indices in 96 KiB of dynamic LDS;
-                                       // beyond: global-memory sort
-
-struct ResolveLists {  // cells k_resolve defers, by hit count class (indices into occ[])
-    uint32_t *lane, *mid, *lng, *big, *huge;
-    uint32_t cap;
-};
 
 // Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
 // from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
 template <uint32_t STRIDE>
 __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn,
-                                                    Counters *c, Materials m, uint4 *out, ResolveLists lists, Params p)
+                                                    const Counters *c, Materials m, uint4 *out, Params p)
 {
     __shared__ uint64_t s_key[kShortList][kBlock];
     __shared__ float s_w[kShortList][kBlock], s_u[kShortList][kBlock], s_v[kShortList][kBlock];
@@ -1498,26 +1593,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
-        if (o.count > kShortList) {
-            // deferred to a cooperative tier; one atomic per wavefront and class, not per cell
-            const uint32_t cls = o.count <= kLaneList ? 0u : (o.count <= kMidList ? 1u : (o.count <= kLongList ? 2u : (o.count <= kBigList ? 3u : 4u)));
-#pragma unroll
-            for (uint32_t k = 0; k < 5; ++k) {
-                const unsigned long long mk = __ballot(cls == k);
-                if (cls == k) {
-                    uint32_t *list = k == 0 ? lists.lane : (k == 1 ? lists.mid : (k == 2 ? lists.lng : (k == 3 ? lists.big : lists.huge)));
-                    uint32_t *ctr = k == 0 ? &c->n_lane : (k == 1 ? &c->n_mid : (k == 2 ? &c->n_long : (k == 3 ? &c->n_bigl : &c->n_huge)));
-                    const uint32_t leader = (uint32_t) __ffsll((long long) mk) - 1u;
-                    const uint32_t lane = threadIdx.x & 63u;
-                    uint32_t base = 0;
-                    if (lane == leader) base = atomicAdd(ctr, (uint32_t) __popcll(mk));
-                    base = __shfl(base, (int) leader, 64);
-                    const uint32_t slot = base + (uint32_t) __popcll(mk & ((1ull << lane) - 1ull));
-                    if (slot < lists.cap) list[slot] = i;
-                }
-            }
-            continue;
-        }
+        if (o.count > kShortList) continue;  // filed for a cooperative tier by k_scan_bricks
         // all loads are issued before anything is consumed (independent round trips overlap), then the records are
         // insertion-sorted into this lane's private LDS column and folded by a rolled loop
         SortedRec r[kShortList];
@@ -1549,42 +1625,70 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
     }
 }
 
-// Tier 2: still one lane per cell, for 9..32 hits.  Each lane insertion-sorts (key, record index) in a private LDS
-// column (entry-major layout: lane-contiguous, conflict-free), then replays its cell from the cached records.
-__global__ __launch_bounds__(64) void k_resolve_lane(const uint32_t *__restrict__ list, const Counters *c,
-                                                     const Occ *__restrict__ occ, SortedView sorted,
-                                                     Materials m, uint4 *out, uint32_t list_cap, Params p)
+// Tier 2: cells with 9..64 hits, W = 16, 32 or 64 lanes per cell (64 / W cells per wavefront).  Every lane loads one
+// record; the (key, position) pairs are bitonic-sorted across the W lanes with cross-lane moves only (no LDS, no
+// barrier); the payload is gathered to its sorted lane and the cell is folded in order, every lane of the group
+// running the same fold on broadcast values.
+template <uint32_t W>
+__global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                         const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                         uint4 *out, uint32_t list_cap, Params p)
 {
-    __shared__ uint64_t s_key[kLaneList][64];
-    __shared__ uint32_t s_idx[kLaneList][64];
-    const uint32_t total = c->n_lane < list_cap ? c->n_lane : list_cap;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t item = blockIdx.x * 64u + lane; item < total; item += gridDim.x * 64u) {
-        const uint32_t i = list[item];
-        const Occ o = occ[i];
-        const uint32_t n = o.count < kLaneList ? o.count : kLaneList;
-        for (uint32_t k = 0; k < n; ++k) {
-            const SortedRec r = sorted.load(o.offset + k);
-            const uint64_t key = ((uint64_t) r.keyhi << 32) | r.keylo;
-            uint32_t j = k;
-            while (j > 0 && s_key[j - 1][lane] > key) {
-                s_key[j][lane] = s_key[j - 1][lane];
-                s_idx[j][lane] = s_idx[j - 1][lane];
-                --j;
+    constexpr uint32_t kPerWave = 64u / W;
+    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane / W, sl = lane % W, base_lane = sub * W;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64u);
+    for (uint32_t item0 = wave * kPerWave; item0 < total; item0 += n_waves * kPerWave) {  // wave-uniform
+        const uint32_t item = item0 + sub;
+        const bool valid = item < total;
+        uint32_t i = 0;
+        Occ o{};
+        if (valid) {
+            i = list[item];
+            o = occ[i];
+        }
+        const uint32_t n = valid ? (o.count < W ? o.count : W) : 0u;
+        uint64_t key = ~0ull;
+        uint32_t hi = 0, idx = sl;
+        float w = 0.f, u = 0.f, v = 0.f;
+        if (sl < n) {
+            const SortedRec r = sorted.load(o.offset + sl);
+            key = ((uint64_t) r.keyhi << 32) | r.keylo;
+            hi = r.keyhi;
+            w = r.w;
+            u = r.u;
+            v = r.v;
+        }
+#pragma unroll
+        for (uint32_t k = 2; k <= W; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint64_t okey = __shfl_xor(key, (int) j, 64);
+                const uint32_t oidx = __shfl_xor(idx, (int) j, 64);
+                const bool keep_min = ((sl & k) == 0) == ((sl & j) == 0);
+                if (keep_min ? okey < key : okey > key) {
+                    key = okey;
+                    idx = oidx;
+                }
             }
-            s_key[j][lane] = key;
-            s_idx[j][lane] = k;
         }
+        const int src = (int) (base_lane + idx);
+        hi = __shfl(hi, src, 64);
+        w = __shfl(w, src, 64);
+        u = __shfl(u, src, 64);
+        v = __shfl(v, src, 64);
         CellFold f;
-        for (uint32_t t = 0; t < n; ++t) {
-            const SortedRec r = sorted.load(o.offset + s_idx[t][lane]);
-            f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
+        for (uint32_t t = 0; t < W; ++t) {
+            if (!__any(t < n)) break;
+            const int from = (int) (base_lane + t);
+            const uint32_t hh = __shfl(hi, from, 64);
+            const float ww = __shfl(w, from, 64), uu = __shfl(u, from, 64), vv = __shfl(v, from, 64);
+            if (t < n) f.add(m, p.blend, hh, ww, uu, vv);
         }
-        out[i] = cell_record(o, f.finish(m, p.blend), p);
+        if (n != 0 && sl == 0) out[i] = cell_record(o, f.finish(m, p.blend), p);
     }
 }
 
-// In-place ascending bitonic sort of (key, idx) pairs; n_pow2 >= n entries, the padding holds key = ~0.
 template <typename KeyPtr, typename IdxPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_pow2, uint32_t tid, uint32_t nthreads)
 {
@@ -1710,8 +1814,8 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
 // per cell; (key, idx) pairs are bitonic-sorted in dynamic LDS (96 KiB), the payload stays in global memory: MAX
 // folds the groups in parallel straight from it, BLEND stages it in sorted order, 1024 records at a time, for the
 // sequential replay.
-constexpr uint32_t kBigStage = 1024;
-__global__ __launch_bounds__(kBlock) void k_resolve_big(const uint32_t *__restrict__ list, Counters *c,
+constexpr uint32_t kBigStage = 1024, kBigThreads = 1024;
+__global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__restrict__ list, Counters *c,
                                                         const Occ *__restrict__ occ, SortedView sorted, Materials m,
                                                         uint4 *out, uint32_t list_cap, Params p)
 {
@@ -1720,7 +1824,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_big(const uint32_t *__restri
     uint32_t *s_idx = reinterpret_cast<uint32_t *>(s_dyn + (size_t) kBigList * 8);           // [kBigList]
     __shared__ uint32_t s_hi[kBigStage];
     __shared__ float s_w[kBigStage], s_u[kBigStage], s_v[kBigStage];
-    __shared__ unsigned long long s_best[kBlock / 64];
+    __shared__ unsigned long long s_best[kBigThreads / 64];
     __shared__ uint32_t s_item;
     const uint32_t total = c->n_bigl < list_cap ? c->n_bigl : list_cap;
     for (;;) {
@@ -1734,7 +1838,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_big(const uint32_t *__restri
         const uint32_t n = o.count < kBigList ? o.count : kBigList;
         uint32_t n_pow2 = 1;
         while (n_pow2 < n) n_pow2 <<= 1;
-        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBigThreads) {
             if (t < n) {
                 const SortedRec r = sorted.load(o.offset + t);
                 s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
@@ -1746,13 +1850,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve_big(const uint32_t *__restri
             }
         }
         __syncthreads();
-        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, kBlock);
+        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, kBigThreads);
         if (p.blend) {
             CellFold f;  // only thread 0's copy is used
             for (uint32_t base = 0; base < n; base += kBigStage) {
                 const uint32_t m_here = n - base < kBigStage ? n - base : kBigStage;
                 __syncthreads();
-                for (uint32_t t = threadIdx.x; t < m_here; t += kBlock) {
+                for (uint32_t t = threadIdx.x; t < m_here; t += kBigThreads) {
                     const SortedRec r = sorted.load(o.offset + s_idx[base + t]);
                     s_hi[t] = r.keyhi;
                     s_w[t] = r.w;
@@ -1767,7 +1871,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_big(const uint32_t *__restri
         }
         else {
             unsigned long long best = 0;
-            for (uint32_t t = threadIdx.x; t < n; t += kBlock) {
+            for (uint32_t t = threadIdx.x; t < n; t += kBigThreads) {
                 const uint32_t hi = (uint32_t) (s_key[t] >> 32);
                 if (t == 0 || (uint32_t) (s_key[t - 1] >> 32) != hi) {
                     SortedRec r = sorted.load(o.offset + s_idx[t]);
@@ -1789,7 +1893,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_big(const uint32_t *__restri
             if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
             __syncthreads();
             if (threadIdx.x == 0) {
-                for (uint32_t wv = 1; wv < kBlock / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
+                for (uint32_t wv = 1; wv < kBigThreads / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
                 const uint32_t t = 0xffffffffu - (uint32_t) best;
                 const uint32_t hi = (uint32_t) (s_key[t] >> 32);
                 SortedRec r = sorted.load(o.offset + s_idx[t]);
@@ -1927,6 +2031,9 @@ struct o2v_hip_ctx {
     // work buffers (grown on demand)
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;  // pinned
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the cooperative resolve tiers run beside tier 1
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    unsigned long long *d_zhist = nullptr, *h_zhist = nullptr;  // kPlanBins each (h_: pinned), o2v_hip_plan_slabs
     Leaf *d_leaves = nullptr;
     Tile *d_tiles = nullptr;
     BigLeaf *d_big = nullptr;
@@ -1936,7 +2043,7 @@ struct o2v_hip_ctx {
     uint32_t sorted_stride = 6;
     Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
-    uint32_t *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_big = nullptr,
+    uint32_t *d_list_lane16 = nullptr, *d_list_w64 = nullptr, *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_big = nullptr,
              *d_list_huge = nullptr;  // cap_vox each
     uint64_t *d_scratch_key = nullptr;  // tier-4 resolve scratch, allocated on first need
     uint32_t *d_scratch_idx = nullptr;
@@ -2016,6 +2123,14 @@ bool debug_sync_enabled()
         }                                                                        \
     } while (0)
 
+float ord2f_host(uint32_t o)
+{
+    const uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
 // One pass of the pipeline with the current capacities.  Fills h_ctr; the caller checks for overflow.
 int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 {
@@ -2066,8 +2181,10 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_brick_dirty, ctx->d_ctr, ctx->d_dirty_list, p);
         O2V_STAGE("k_scan_flags");
+        const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
+                                 ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
         hipLaunchKernelGGL(k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
-                           ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, p);
+                           ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, lists, p);
         O2V_STAGE("k_scan_bricks");
         hipLaunchKernelGGL(k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
@@ -2081,34 +2198,55 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     {
         Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
         const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
-        ResolveLists lists{ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
+        // The tiers work on disjoint cells and were filed by k_scan_bricks, so they run side by side: tier 1 on the
+        // main stream, the cooperative tiers (short, latency-bound launches) on three auxiliary streams.
+        const bool fork = !debug_sync_enabled();
+        hipStream_t sw = s, sm = s, sl = s;
+        if (fork) {
+            sw = ctx->aux[0];
+            sm = ctx->aux[1];
+            sl = ctx->aux[2];
+            O2V_CHECK(hipEventRecord(ctx->ev_fork, s));
+            for (hipStream_t a : ctx->aux) O2V_CHECK(hipStreamWaitEvent(a, ctx->ev_fork, 0));
+        }
         if (use_uv)
             hipLaunchKernelGGL(k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
-                               ctx->d_out, lists, p);
+                               ctx->d_out, p);
         else
             hipLaunchKernelGGL(k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
-                               ctx->d_out, lists, p);
+                               ctx->d_out, p);
         O2V_STAGE("k_resolve");
-        hipLaunchKernelGGL(k_resolve_lane, dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, s, ctx->d_list_lane, ctx->d_ctr,
-                           ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_STAGE("k_resolve_lane");
-        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 32u), dim3(64), 0, s,
+        hipLaunchKernelGGL(k_resolve_wave<16>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
+                           &ctx->d_ctr->n_lane16, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_STAGE("k_resolve_wave<16>");
+        hipLaunchKernelGGL(k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_lane,
+                           &ctx->d_ctr->n_lane, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_STAGE("k_resolve_wave<32>");
+        hipLaunchKernelGGL(k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_w64,
+                           &ctx->d_ctr->n_w64, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_STAGE("k_resolve_wave<64>");
+        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, sm,
                            ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
-        hipLaunchKernelGGL((k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL((k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sl,
                            ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
-        hipLaunchKernelGGL(k_resolve_big, dim3((uint32_t) ctx->num_cus), dim3(kBlock), kBigList * 12u, s, ctx->d_list_big,
+        hipLaunchKernelGGL(k_resolve_big, dim3((uint32_t) ctx->num_cus), dim3(kBigThreads), kBigList * 12u, sl, ctx->d_list_big,
                            ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_big");
         if (ctx->d_scratch_key) {
-            hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus), dim3(kBlock), 0, s, ctx->d_list_huge,
+            hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus), dim3(kBlock), 0, sl, ctx->d_list_huge,
                                ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, ctx->d_scratch_key,
                                ctx->d_scratch_idx, ctx->cap_scratch, p.cap_vox, p);
             O2V_STAGE("k_resolve_huge");
         }
+        if (fork)
+            for (int j = 0; j < 3; ++j) {
+                O2V_CHECK(hipEventRecord(ctx->ev_join[j], ctx->aux[j]));
+                O2V_CHECK(hipStreamWaitEvent(s, ctx->ev_join[j], 0));
+            }
     }
     O2V_CHECK(hipEventRecord(ctx->ev[5], s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -2149,6 +2287,14 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
             delete ctx;
             return O2V_HIP_ERR_HIP;
         }
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int j = 0; j < 3 && ok; ++j)
+        ok = hipStreamCreateWithFlags(&ctx->aux[j], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        delete ctx;
+        return O2V_HIP_ERR_HIP;
+    }
     if (hipMalloc(reinterpret_cast<void **>(&ctx->d_ctr), sizeof(Counters)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&ctx->h_ctr), sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
         delete ctx;
@@ -2169,15 +2315,22 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
                     ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid,
-                    ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
+                    ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
     for (uint8_t *q : ctx->d_texpix)
         if (q) (void) hipFree(q);
     if (ctx->h_ctr) (void) hipHostFree(ctx->h_ctr);
+    if (ctx->d_zhist) (void) hipFree(ctx->d_zhist);
+    if (ctx->h_zhist) (void) hipHostFree(ctx->h_zhist);
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
+    if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
+    for (int j = 0; j < 3; ++j) {
+        if (ctx->ev_join[j]) (void) hipEventDestroy(ctx->ev_join[j]);
+        if (ctx->aux[j]) (void) hipStreamDestroy(ctx->aux[j]);
+    }
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -2366,7 +2519,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
-        for (uint32_t **lp : {&ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
+        for (uint32_t **lp : {&ctx->d_list_lane16, &ctx->d_list_w64, &ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
             uint32_t cap_l = ctx->cap_vox;
             if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;
         }
@@ -2444,6 +2597,77 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     }
     ctx->err = "device buffers did not converge after 12 passes";
     return O2V_HIP_ERR_LIMIT;
+}
+
+int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t n_slabs, uint32_t *out_z,
+                       float *out_bounds)
+{
+    if (!ctx || !params || !out_z || n_slabs == 0) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const uint32_t ss = params->supersampling ? params->supersampling : 1u;
+    const uint32_t G = params->resolution;
+    if (G == 0 || ss > 2 || (uint64_t) G * ss > 65535u || n_slabs > G) {
+        ctx->err = "plan_slabs: resolution must be non-zero and below 65536 samples, 1 <= n_slabs <= resolution";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
+    for (uint32_t k = 0; k <= n_slabs; ++k) out_z[k] = (uint32_t) ((uint64_t) G * k / n_slabs);  // equal heights
+    if (out_bounds)
+        for (int i = 0; i < 6; ++i) out_bounds[i] = params->bounds_known ? params->bounds[i] : 0.f;
+    if (ctx->n_tris == 0) return O2V_HIP_OK;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->d_zhist) {
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zhist), kPlanBins * sizeof(unsigned long long)));
+        O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_zhist), kPlanBins * sizeof(unsigned long long),
+                                hipHostMallocDefault));
+    }
+    Params p{};
+    p.n_tris = ctx->n_tris;
+    p.S = G * ss;
+    p.G = G;
+    p.bounds_known = params->bounds_known;
+    for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
+    for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];
+    // sample layers per bin: a whole number of output layers, at most kPlanBins bins
+    const uint32_t bin_out = (G + kPlanBins - 1) / kPlanBins;
+    const uint32_t n_bins = (G + bin_out - 1) / bin_out;
+
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    if (!p.bounds_known)
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
+    O2V_CHECK(hipMemsetAsync(ctx->d_zhist, 0, kPlanBins * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_zhist, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 6u, (p.n_tris + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, ctx->d_verts, ctx->d_ctr, ctx->d_zhist, p, bin_out * ss);
+    O2V_STAGE("k_zhist");
+    O2V_CHECK(hipMemcpyAsync(ctx->h_zhist, ctx->d_zhist, n_bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    O2V_CHECK(hipStreamSynchronize(s));
+    O2V_CHECK(hipGetLastError());
+    if (out_bounds && !params->bounds_known)
+        for (int i = 0; i < 6; ++i) out_bounds[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
+
+    unsigned __int128 total = 0;
+    for (uint32_t b = 0; b < n_bins; ++b) total += ctx->h_zhist[b];
+    if (total == 0) return O2V_HIP_OK;
+    unsigned __int128 before = 0;
+    uint32_t k = 1;
+    for (uint32_t b = 0; b < n_bins && k < n_slabs; ++b) {
+        const unsigned __int128 after = before + ctx->h_zhist[b];
+        while (k < n_slabs && after * n_slabs >= total * k) {
+            // the k-th cut falls inside bin b: take whichever end of the bin is closer to the target
+            const unsigned __int128 target_n = total * k;  // compare in units of 1/n_slabs
+            const bool take_start = (target_n - before * n_slabs) < (after * n_slabs - target_n);
+            out_z[k] = std::min<uint32_t>(G, (take_start ? b : b + 1) * bin_out);
+            ++k;
+        }
+        before = after;
+    }
+    for (; k < n_slabs; ++k) out_z[k] = G;
+    // every slab keeps at least one layer
+    for (uint32_t j = 1; j < n_slabs; ++j) out_z[j] = std::max(out_z[j], out_z[j - 1] + 1);
+    for (uint32_t j = n_slabs - 1; j >= 1; --j) out_z[j] = std::min(out_z[j], out_z[j + 1] - 1);
+    return O2V_HIP_OK;
 }
 
 int o2v_hip_read_voxels(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count)

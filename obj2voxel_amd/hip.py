@@ -54,6 +54,7 @@ def _bind():
     L.o2v_hip_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.o2v_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.o2v_hip_get_transform.argtypes = [C.c_void_p, C.c_void_p]
+    L.o2v_hip_plan_slabs.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -114,8 +115,8 @@ class DeviceVoxelizer:
         self._check(self._L.o2v_hip_set_textures(self._ctx, C.cast(arr, C.c_void_p), len(textures)),
                     "o2v_hip_set_textures")
 
-    def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
-                 zslab=(0, 0), read=True):
+    @staticmethod
+    def _params(resolution, supersampling, strategy, unit_transform, bounds, zslab):
         p = _Params()
         p.resolution, p.supersampling, p.strategy = resolution, supersampling, strategy
         ut = (1, 0, 0, 0, 1, 0, 0, 0, 1) if unit_transform is None else tuple(int(x) for x in np.ravel(unit_transform))
@@ -124,6 +125,20 @@ class DeviceVoxelizer:
             p.bounds_known = 1
             p.bounds = (C.c_float * 6)(*[float(x) for x in np.ravel(bounds)])
         p.z_begin, p.z_end = zslab
+        return p
+
+    def plan_slabs(self, resolution, n_slabs, *, supersampling=1, unit_transform=None, bounds=None):
+        """o2v_hip_plan_slabs: (cuts, bounds) -- n_slabs+1 ascending z cuts that equalise the predicted work per slab,
+        and the mesh bounds (float32 [6]) to hand back to voxelize(bounds=...)."""
+        p = self._params(resolution, supersampling, 0, unit_transform, bounds, (0, 0))
+        cuts = np.zeros(n_slabs + 1, dtype=np.uint32)
+        bnd = np.zeros(6, dtype=np.float32)
+        self._check(self._L.o2v_hip_plan_slabs(self._ctx, C.byref(p), n_slabs, _ptr(cuts), _ptr(bnd)), "o2v_hip_plan_slabs")
+        return [int(z) for z in cuts], bnd
+
+    def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
+                 zslab=(0, 0), read=True):
+        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, zslab)
         n = C.c_uint64(0)
         self._check(self._L.o2v_hip_voxelize(self._ctx, C.byref(p), C.byref(n)), "o2v_hip_voxelize")
         self.count = n.value

@@ -162,6 +162,59 @@ def test_slabs_union_equals_whole(dv, oracle):
     _compare(np.concatenate(parts), full)
 
 
+@pytest.mark.parametrize("n_slabs", [2, 3, 8])
+def test_planned_slabs_union_equals_whole_and_balance(dv, oracle, n_slabs):
+    """o2v_hip_plan_slabs: the work-balanced cuts partition [0, res); the union of the planned slabs equals the whole
+    result bit for bit (and the oracle's); the slabs' hit counts are balanced to a few per cent on a mesh whose
+    equal-height slabs are not (a sphere with its poles on the y axis and a dense patch of extra triangles)."""
+    from obj2voxel_amd import hip
+    res = 192
+    sphere = meshes.uv_sphere(90)
+    patch = meshes.uv_sphere(60, radius=0.08, center=(0.0, 0.0, 0.7))  # a dense blob near the top of z
+    v = np.concatenate([np.reshape(sphere, (-1, 9)), np.reshape(patch, (-1, 9))])
+    T = len(v)
+    kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=1)
+    got, want = _run_both(dv, oracle, v, res, **kw)
+    _compare(got, want)
+    whole_hits = dv.stats()["hits"]
+    cuts, bnd = dv.plan_slabs(res, n_slabs)
+    assert cuts[0] == 0 and cuts[-1] == res and all(a < b for a, b in zip(cuts, cuts[1:]))
+    assert np.array_equal(bnd, np.concatenate([v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)]).astype(np.float32))
+    parts, hits = [], []
+    for k in range(n_slabs):
+        parts.append(dv.voxelize(res, strategy=1, zslab=(cuts[k], cuts[k + 1]), bounds=bnd))
+        hits.append(dv.stats()["hits"])
+    assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), meshes.sorted_voxels(got))
+    assert sum(hits) == whole_hits
+    assert max(hits) < 1.08 * whole_hits / n_slabs, (cuts, hits)
+    equal = []
+    for k in range(n_slabs):
+        z0, z1 = k * res // n_slabs, (k + 1) * res // n_slabs
+        dv.voxelize(res, strategy=1, zslab=(z0, z1), read=False)
+        equal.append(dv.stats()["hits"])
+    assert max(equal) > max(hits)
+
+
+def test_planned_slabs_edge_cases(dv):
+    """Empty mesh -> equal heights; one layer per slab; supersampling; a single triangle (all work in one layer)."""
+    from obj2voxel_amd import hip
+    dv.set_triangles(np.zeros((0, 9), np.float32))
+    cuts, _ = dv.plan_slabs(64, 4)
+    assert cuts == [0, 16, 32, 48, 64]
+    dv.set_triangles(meshes.uv_sphere(12))
+    cuts, _ = dv.plan_slabs(16, 16)
+    assert cuts == list(range(17))
+    cuts, _ = dv.plan_slabs(100, 4, supersampling=2)
+    assert cuts[0] == 0 and cuts[-1] == 100 and all(a < b for a, b in zip(cuts, cuts[1:]))
+    assert abs(cuts[2] - 50) <= 1                      # the sphere is symmetric in z
+    flat = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 0, 1, 1, 0, 1, 0, 1, 1]], np.float32)  # two z-flat triangles
+    dv.set_triangles(flat)
+    cuts, _ = dv.plan_slabs(64, 4)
+    assert cuts[0] == 0 and cuts[-1] == 64 and all(a < b for a, b in zip(cuts, cuts[1:]))
+    with pytest.raises(hip.DeviceError):
+        dv.plan_slabs(8, 9)                             # more slabs than layers
+
+
 def test_context_reuse_is_idempotent(dv, oracle):
     v = meshes.uv_sphere(9)
     a, want = _run_both(dv, oracle, v, 80)

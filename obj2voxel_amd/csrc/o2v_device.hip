@@ -164,6 +164,21 @@ struct Params {
 
 // ---- small device helpers ---------------------------------------------------------------------------------
 
+// A pass that ran out of hit-pool or cell-list space has cell offsets that point past the sorted records: the
+// resolve kernels skip such a pass (the host grows the buffers and runs it again).
+// A pass whose subdivision ran out of leaf / tile / queue space is discarded by the host as well; k_voxelize skips it
+// (a tile may name a leaf that was never written).
+__device__ __forceinline__ bool expand_overflowed(const Counters *c, const Params &p)
+{
+    bool over = c->n_leaves > p.cap_leaves || c->n_tiles > p.cap_tiles || c->n_big > p.cap_big;
+    for (uint32_t r = 0; r <= kMaxRounds; ++r) over |= c->n_nodes[r] > p.cap_nodes;
+    return over;
+}
+__device__ __forceinline__ bool pass_overflowed(const Counters *c, const Params &p)
+{
+    return c->n_hits_reserved > p.cap_hits || c->n_sorted > p.cap_hits || c->n_vox > p.cap_vox;
+}
+
 __device__ __forceinline__ uint32_t f2ord(float f)
 {
     uint32_t b = __float_as_uint(f);
@@ -935,6 +950,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     __shared__ uint16_t s_surv[kMaxSurvivors];
     __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits;
 
+    if (expand_overflowed(c, p)) return;
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
     const uint32_t n_batches = (n_tiles + kTilesPerBatch - 1) / kTilesPerBatch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1590,6 +1606,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
     __shared__ uint64_t s_key[kShortList][kBlock];
     __shared__ float s_w[kShortList][kBlock], s_u[kShortList][kBlock], s_v[kShortList][kBlock];
     const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads below stay branch-free
+    if (pass_overflowed(c, p)) return;
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
@@ -1631,10 +1648,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
 // running the same fold on broadcast values.
 template <uint32_t W>
 __global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restrict__ list, const uint32_t *n_list,
-                                                         const Occ *__restrict__ occ, SortedView sorted, Materials m,
-                                                         uint4 *out, uint32_t list_cap, Params p)
+                                                         const Counters *c, const Occ *__restrict__ occ,
+                                                         SortedView sorted, Materials m, uint4 *out, uint32_t list_cap,
+                                                         Params p)
 {
     constexpr uint32_t kPerWave = 64u / W;
+    if (pass_overflowed(c, p)) return;
     const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
     const uint32_t lane = threadIdx.x & 63u, sub = lane / W, sl = lane % W, base_lane = sub * W;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64u);
@@ -1719,10 +1738,11 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_
 // combine is not associative).
 template <uint32_t THREADS, uint32_t CAP>
 __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
-                                                            uint32_t *cursor, const Occ *__restrict__ occ,
-                                                            SortedView sorted, Materials m, uint4 *out,
-                                                            uint32_t list_cap, Params p)
+                                                            uint32_t *cursor, const Counters *c,
+                                                            const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                            uint4 *out, uint32_t list_cap, Params p)
 {
+    if (pass_overflowed(c, p)) return;
     __shared__ uint64_t s_key[CAP];
     __shared__ uint32_t s_idx[CAP];
     __shared__ uint32_t s_hi[CAP];
@@ -1826,6 +1846,7 @@ __global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__r
     __shared__ float s_w[kBigStage], s_u[kBigStage], s_v[kBigStage];
     __shared__ unsigned long long s_best[kBigThreads / 64];
     __shared__ uint32_t s_item;
+    if (pass_overflowed(c, p)) return;
     const uint32_t total = c->n_bigl < list_cap ? c->n_bigl : list_cap;
     for (;;) {
         __syncthreads();
@@ -1920,6 +1941,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
 {
     __shared__ uint32_t s_item, s_base, s_ok;
     __shared__ unsigned long long s_best[kBlock / 64];
+    if (pass_overflowed(c, p)) return;
     const uint32_t total = c->n_huge < list_cap ? c->n_huge : list_cap;
     for (;;) {
         __syncthreads();
@@ -2104,21 +2126,23 @@ int upload(o2v_hip_ctx *ctx, T *&dptr, const T *host, uint64_t count)
 }
 
 
-// O2V_DEBUG_SYNC=1: synchronise and log after every launch (locates a faulting or hanging kernel).
-bool debug_sync_enabled()
+// O2V_DEBUG_SYNC=1: synchronise and log after every launch (locates a faulting or hanging kernel); the resolve tiers
+// then run on one stream.  O2V_DEBUG_SYNC=2: the same, but the tiers keep their own streams (device-wide sync).
+int debug_sync_level()
 {
-    static const bool on = [] {
+    static const int level = [] {
         const char *e = std::getenv("O2V_DEBUG_SYNC");
-        return e && e[0] == '1';
+        return e && (e[0] == '1' || e[0] == '2') ? e[0] - '0' : 0;
     }();
-    return on;
+    return level;
 }
+bool debug_sync_enabled() { return debug_sync_level() != 0; }
 #define O2V_STAGE(name)                                                          \
     do {                                                                         \
         if (debug_sync_enabled()) {                                              \
             std::fprintf(stderr, "[o2v] launched %s ...", name);                 \
             std::fflush(stderr);                                                 \
-            hipError_t e_ = hipStreamSynchronize(s);                             \
+            hipError_t e_ = debug_sync_level() == 2 ? hipDeviceSynchronize() : hipStreamSynchronize(s); \
             std::fprintf(stderr, " %s\n", hipGetErrorString(e_));                \
         }                                                                        \
     } while (0)
@@ -2200,7 +2224,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
         // The tiers work on disjoint cells and were filed by k_scan_bricks, so they run side by side: tier 1 on the
         // main stream, the cooperative tiers (short, latency-bound launches) on three auxiliary streams.
-        const bool fork = !debug_sync_enabled();
+        const bool fork = debug_sync_level() != 1;
         hipStream_t sw = s, sm = s, sl = s;
         if (fork) {
             sw = ctx->aux[0];
@@ -2217,20 +2241,20 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                                ctx->d_out, p);
         O2V_STAGE("k_resolve");
         hipLaunchKernelGGL(k_resolve_wave<16>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
-                           &ctx->d_ctr->n_lane16, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+                           &ctx->d_ctr->n_lane16, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<16>");
         hipLaunchKernelGGL(k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_lane,
-                           &ctx->d_ctr->n_lane, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+                           &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<32>");
         hipLaunchKernelGGL(k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_w64,
-                           &ctx->d_ctr->n_w64, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+                           &ctx->d_ctr->n_w64, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<64>");
         hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, sm,
-                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_occ, sorted_view, m,
+                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
         hipLaunchKernelGGL((k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sl,
-                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_occ, sorted_view, m,
+                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
         hipLaunchKernelGGL(k_resolve_big, dim3((uint32_t) ctx->num_cus), dim3(kBigThreads), kBigList * 12u, sl, ctx->d_list_big,

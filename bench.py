@@ -130,11 +130,12 @@ def main():
         L, tiles, H, V = stats["leaves"], stats["tiles"], stats["hits"], stats["voxels"]
         B, D, slots = stats["bricks"], stats["dirty_bricks"], stats["pool_slots"]
         # algorithmic bytes per launch of each stage
+        REC = 16  # sorted record: 16 bytes for a mesh without textured triangles (this workload), else 24
         alg_bytes = {
             "expand_ms": 36 * T + 96 * L + 8 * tiles,
             "voxelize_ms": 96 * L + 8 * tiles + (32 + 4 + 1) * H,
-            "scan_ms": B + 1024 * D + (16 + 4) * V + 32 * slots + (4 + 24) * H + 1024 * D,
-            "resolve_ms": 16 * V + 24 * H + 16 * V,
+            "scan_ms": B + 1024 * D + (16 + 4) * V + 32 * slots + (4 + REC) * H + 1024 * D,
+            "resolve_ms": 16 * V + REC * H + 16 * V,
         }
         kernel_of = {"expand_ms": "k_expand_roots+k_expand_nodes", "voxelize_ms": "k_voxelize",
                      "scan_ms": "k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks", "resolve_ms": "k_resolve*"}

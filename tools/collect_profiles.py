@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs under gpurun_out/ (prof_final, pmcf_FETCH_SIZE, pmcf_WRITE_SIZE, pmcf_sq, bench_final.json)
+"""Turns the rocprofv3 outputs that tools/profile_all.sh leaves under gpurun_out/ (prof_final, pmcf_FETCH_SIZE, pmcf_WRITE_SIZE, pmcf_sq, bench_final.json)
 into the committed summaries under profiles/<round>/ and profiles/traffic.json (read by bench.py)."""
 import collections
 import csv
@@ -12,7 +12,19 @@ import sys
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = os.path.join("profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
-shutil.copy("gpurun_out/prof_final/f_kernel_stats.csv", os.path.join(out_dir, "kernel_stats.csv"))
+import glob
+
+
+def find(pattern):
+    hits = sorted(glob.glob(pattern, recursive=True))
+    if not hits:
+        raise SystemExit("missing " + pattern)
+    return hits[0]
+
+
+shutil.copy(find("gpurun_out/prof_final/**/f_kernel_stats.csv"), os.path.join(out_dir, "kernel_stats.csv"))
+if os.path.exists("gpurun_out/predict_scaling_8.jsonl"):
+    shutil.copy("gpurun_out/predict_scaling_8.jsonl", os.path.join(out_dir, "predict_scaling_8.jsonl"))
 shutil.copy("gpurun_out/bench_final.json", os.path.join(out_dir, "bench_line.json"))
 
 
@@ -24,7 +36,7 @@ def kname(s):
 res = {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f"gpurun_out/pmcf_{cname}/p_counter_collection.csv")):
+    for r in csv.DictReader(open(find(f"gpurun_out/pmcf_{cname}/**/p_counter_collection.csv"))):
         k = kname(r["Kernel_Name"])
         if k and r["Counter_Name"] == cname:
             acc[k].append(float(r["Counter_Value"]))
@@ -48,13 +60,13 @@ json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 json.dump(out, open(os.path.join(out_dir, "pmc_hbm_traffic.json"), "w"), indent=1)
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open("gpurun_out/pmcf_sq/p_counter_collection.csv")):
+for r in csv.DictReader(open(find("gpurun_out/pmcf_sq/**/p_counter_collection.csv"))):
     k = kname(r["Kernel_Name"])
     if k:
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 sq = {"_comment": "rocprofv3 --pmc pass (8 SQ counters, --kernel-trace only), bench workload, averages per launch. "
                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)."}
-for k in ("k_voxelize<false>", "k_scatter", "k_resolve", "k_scan_bricks"):
+for k in ("k_voxelize<false>", "k_scatter", "k_resolve<4u>", "k_scan_bricks"):
     d = {c: round(sum(v) / len(v)) for c, v in acc[k].items()}
     if d.get("SQ_INSTS_VALU"):
         d["derived"] = {"valu_active_fraction_per_wave": round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 3),

@@ -1,5 +1,6 @@
 // o2v_io.cpp -- triangle sources (binary STL, Wavefront OBJ + MTL, PNG textures) and voxel sinks
-// (VL32, PLY, XYZRGB; file or memory).  Formats as documented in the reference's README.adoc:210-264.
+// (VL32, PLY, XYZRGB streamed; QEF, VOX buffered; file or memory).  Formats as documented in the reference's
+// README.adoc:210-264 and, for the two palette formats, in their publishers' specifications.
 #include "o2v_io.hpp"
 
 #include <zlib.h>
@@ -12,6 +13,7 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <utility>
 
 namespace o2v {
 
@@ -536,27 +538,344 @@ struct ListSink final : VoxelSink {
     const std::vector<uint8_t> *memory() const override { return is_memory ? &out.mem : nullptr; }
 };
 
-std::unique_ptr<VoxelSink> make_list_sink(FileFormat format, const char *path)
+// ---- palette formats -----------------------------------------------------------------
+// QEF and VOX index a colour table, so every voxel is buffered (16 bytes each, as README.adoc:274-275 says of the
+// reference) and the file is written in finalize(), like the reference's VoxelioVoxelSink does for paletted writers
+// (src/io.cpp:575-633).  The encoders themselves live in the absent voxel-io module; what is written here follows the
+// published formats (Qubicle Exchange Format 0.2; MagicaVoxel .vox version 150) and is not byte-pinned to voxel-io.
+
+// Colour table of at most `limit` entries for `colors` (distinct ARGB values, ascending) with voxel counts `weight`:
+// median cut in RGB - the box with the largest weighted extent is split at the weighted median of its longest axis;
+// every box is represented by its weighted mean.  map[i] receives the table index of colors[i].
+void reduce_palette(const std::vector<uint32_t> &colors, const std::vector<uint64_t> &weight, size_t limit,
+                    std::vector<uint32_t> &table, std::vector<uint32_t> &map)
 {
-    if (format != FileFormat::VL32 && format != FileFormat::PLY && format != FileFormat::XYZRGB) {
-        log_message(LOG_ERROR, "This build writes VL32, PLY and XYZRGB; palette formats (QEF, VOX) are not implemented");
+    const size_t n = colors.size();
+    map.assign(n, 0);
+    table.clear();
+    if (n <= limit) {
+        table = colors;
+        for (size_t i = 0; i < n; ++i) map[i] = (uint32_t) i;
+        return;
+    }
+    struct Box {
+        size_t begin, end;  // range in `order`
+        uint64_t score;
+        int axis;
+    };
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t) i;
+    auto channel = [&](uint32_t idx, int axis) { return (int) ((colors[idx] >> (16 - 8 * axis)) & 255u); };
+    auto measure = [&](Box &b) {
+        int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+        uint64_t w = 0;
+        for (size_t k = b.begin; k < b.end; ++k) {
+            for (int a = 0; a < 3; ++a) {
+                const int c = channel(order[k], a);
+                lo[a] = std::min(lo[a], c);
+                hi[a] = std::max(hi[a], c);
+            }
+            w += weight[order[k]];
+        }
+        b.axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (hi[a] - lo[a] > hi[b.axis] - lo[b.axis]) b.axis = a;
+        const int extent = hi[b.axis] - lo[b.axis];
+        b.score = b.end - b.begin < 2 || extent == 0 ? 0 : (uint64_t) extent * w;
+    };
+    std::vector<Box> boxes{Box{0, n, 0, 0}};
+    measure(boxes[0]);
+    while (boxes.size() < limit) {
+        size_t best = 0;
+        for (size_t k = 1; k < boxes.size(); ++k)
+            if (boxes[k].score > boxes[best].score) best = k;
+        if (boxes[best].score == 0) break;
+        Box b = boxes[best];
+        std::sort(order.begin() + (long) b.begin, order.begin() + (long) b.end, [&](uint32_t x, uint32_t y) {
+            const int cx = channel(x, b.axis), cy = channel(y, b.axis);
+            return cx != cy ? cx < cy : colors[x] < colors[y];
+        });
+        uint64_t total = 0, run = 0;
+        for (size_t k = b.begin; k < b.end; ++k) total += weight[order[k]];
+        size_t cut = b.begin + 1;
+        for (size_t k = b.begin; k + 1 < b.end; ++k) {
+            run += weight[order[k]];
+            cut = k + 1;
+            if (run * 2 >= total) break;
+        }
+        Box lo_box{b.begin, cut, 0, 0}, hi_box{cut, b.end, 0, 0};
+        measure(lo_box);
+        measure(hi_box);
+        boxes[best] = lo_box;
+        boxes.push_back(hi_box);
+    }
+    for (size_t k = 0; k < boxes.size(); ++k) {
+        uint64_t sum[3] = {0, 0, 0}, w = 0;
+        for (size_t i = boxes[k].begin; i < boxes[k].end; ++i) {
+            const uint64_t wi = weight[order[i]];
+            for (int a = 0; a < 3; ++a) sum[a] += wi * (uint64_t) channel(order[i], a);
+            w += wi;
+            map[order[i]] = (uint32_t) k;
+        }
+        uint32_t c = 0xFF000000u;
+        for (int a = 0; a < 3; ++a) c |= (uint32_t) ((sum[a] + w / 2) / w) << (16 - 8 * a);
+        table.push_back(c);
+    }
+}
+
+struct PaletteSink final : VoxelSink {
+    ByteOut out;
+    FileFormat format;
+    bool is_memory;
+    bool finalized = false;
+    uint32_t resolution;
+    std::vector<uint32_t> voxels;  // (x, y, z, argb) as received
+
+    PaletteSink(FileFormat f, bool memory, uint32_t res) : format{f}, is_memory{memory}, resolution{res} {}
+
+    bool can_write() const override { return out.ok; }
+    void write(uint32_t *v, size_t count) override
+    {
+        written += count;
+        voxels.insert(voxels.end(), v, v + count * 4);
+    }
+    const std::vector<uint8_t> *memory() const override { return is_memory ? &out.mem : nullptr; }
+
+    // distinct colours (ascending) with their voxel counts; index[i] = position of voxel i's colour
+    void collect_colors(std::vector<uint32_t> &colors, std::vector<uint64_t> &weight, std::vector<uint32_t> &index) const
+    {
+        const size_t n = voxels.size() / 4;
+        colors.resize(n);
+        for (size_t i = 0; i < n; ++i) colors[i] = voxels[i * 4 + 3];
+        std::sort(colors.begin(), colors.end());
+        colors.erase(std::unique(colors.begin(), colors.end()), colors.end());
+        weight.assign(colors.size(), 0);
+        index.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            index[i] = (uint32_t) (std::lower_bound(colors.begin(), colors.end(), voxels[i * 4 + 3]) - colors.begin());
+            weight[index[i]] += 1;
+        }
+    }
+
+    void write_qef()
+    {
+        // Qubicle Exchange Format 0.2: three header lines, "sizeX sizeY sizeZ", colour count, one "r g b" line
+        // (0..1) per colour, then one "x y z colourIndex mask" line per voxel.  mask: 2 = -x face visible, 4 = +x,
+        // 8 = +y, 16 = -y, 32 = +z, 64 = -z (a face is visible if the neighbour cell is empty); 0 = enclosed.
+        std::vector<uint32_t> colors, index;
+        std::vector<uint64_t> weight;
+        collect_colors(colors, weight, index);
+        const size_t n = voxels.size() / 4;
+        std::vector<uint64_t> keys(n);
+        auto key = [](uint32_t x, uint32_t y, uint32_t z) { return (uint64_t) x | ((uint64_t) y << 21) | ((uint64_t) z << 42); };
+        for (size_t i = 0; i < n; ++i) keys[i] = key(voxels[i * 4], voxels[i * 4 + 1], voxels[i * 4 + 2]);
+        std::sort(keys.begin(), keys.end());
+        auto filled = [&](int64_t x, int64_t y, int64_t z) {
+            if (x < 0 || y < 0 || z < 0) return false;
+            return std::binary_search(keys.begin(), keys.end(), key((uint32_t) x, (uint32_t) y, (uint32_t) z));
+        };
+        std::string s = "Qubicle Exchange Format\nVersion 0.2\nwww.minddesk.com\n";
+        char buf[128];
+        std::snprintf(buf, sizeof(buf), "%u %u %u\n%zu\n", resolution, resolution, resolution, colors.size());
+        s += buf;
+        for (uint32_t c : colors) {
+            std::snprintf(buf, sizeof(buf), "%f %f %f\n", (double) ((c >> 16) & 255u) / 255.0, (double) ((c >> 8) & 255u) / 255.0,
+                          (double) (c & 255u) / 255.0);
+            s += buf;
+        }
+        out.put(s.data(), s.size());
+        s.clear();
+        for (size_t i = 0; i < n; ++i) {
+            const int64_t x = voxels[i * 4], y = voxels[i * 4 + 1], z = voxels[i * 4 + 2];
+            const unsigned mask = (filled(x - 1, y, z) ? 0u : 2u) | (filled(x + 1, y, z) ? 0u : 4u) | (filled(x, y + 1, z) ? 0u : 8u) |
+                                  (filled(x, y - 1, z) ? 0u : 16u) | (filled(x, y, z + 1) ? 0u : 32u) | (filled(x, y, z - 1) ? 0u : 64u);
+            const int len = std::snprintf(buf, sizeof(buf), "%lld %lld %lld %u %u\n", (long long) x, (long long) y, (long long) z,
+                                          index[i], mask);
+            s.append(buf, (size_t) len);
+            if (s.size() > (1u << 20)) {
+                out.put(s.data(), s.size());
+                s.clear();
+            }
+        }
+        out.put(s.data(), s.size());
+    }
+
+    // ---- MagicaVoxel ----
+    static void put_le32(std::vector<uint8_t> &b, uint32_t v)
+    {
+        for (int k = 0; k < 4; ++k) b.push_back((uint8_t) (v >> (8 * k)));
+    }
+    static void put_str(std::vector<uint8_t> &b, const std::string &str)
+    {
+        put_le32(b, (uint32_t) str.size());
+        b.insert(b.end(), str.begin(), str.end());
+    }
+    static void put_dict(std::vector<uint8_t> &b, const std::vector<std::pair<std::string, std::string>> &kv)
+    {
+        put_le32(b, (uint32_t) kv.size());
+        for (const auto &e : kv) {
+            put_str(b, e.first);
+            put_str(b, e.second);
+        }
+    }
+    static void put_chunk(std::vector<uint8_t> &b, const char *id, const std::vector<uint8_t> &content)
+    {
+        b.insert(b.end(), id, id + 4);
+        put_le32(b, (uint32_t) content.size());
+        put_le32(b, 0);
+        b.insert(b.end(), content.begin(), content.end());
+    }
+
+    void write_vox()
+    {
+        // .vox version 150: MAIN { (SIZE XYZI)* [nTRN nGRP (nTRN nSHP)*] RGBA }.  A model holds at most 256^3 cells with
+        // byte coordinates, so a larger grid becomes one model per non-empty 256^3 block, placed by a scene graph
+        // (a translation node's "_t" is the world position of the model's centre floor(size / 2)).  Colour index i of
+        // XYZI refers to RGBA entry i - 1; index 0 is reserved, leaving 255 usable colours (README.adoc:253-257).
+        // Axes are written as they are (MagicaVoxel shows z up).
+        std::vector<uint32_t> colors, index, table, map;
+        std::vector<uint64_t> weight;
+        collect_colors(colors, weight, index);
+        reduce_palette(colors, weight, 255, table, map);
+        if (colors.size() > 255)
+            log_message(LOG_INFO, "VOX: reduced " + std::to_string(colors.size()) + " colours to a palette of " +
+                                      std::to_string(table.size()));
+        const size_t n = voxels.size() / 4;
+        const uint32_t blocks = (resolution + 255u) / 256u;
+        std::map<uint32_t, std::vector<uint8_t>> models;  // block id -> XYZI payload without the count
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t x = voxels[i * 4], y = voxels[i * 4 + 1], z = voxels[i * 4 + 2];
+            const uint32_t id = ((z >> 8) * blocks + (y >> 8)) * blocks + (x >> 8);
+            std::vector<uint8_t> &m = models[id];
+            m.push_back((uint8_t) x);
+            m.push_back((uint8_t) y);
+            m.push_back((uint8_t) z);
+            m.push_back((uint8_t) (map[index[i]] + 1u));
+        }
+        if (models.empty()) models[0];  // an empty grid is still one (empty) model
+        std::vector<uint8_t> body;
+        auto block_size = [&](uint32_t b) { return std::min<uint32_t>(256u, resolution - b * 256u); };
+        for (const auto &m : models) {
+            const uint32_t bx = m.first % blocks, by = (m.first / blocks) % blocks, bz = m.first / (blocks * blocks);
+            std::vector<uint8_t> c;
+            put_le32(c, block_size(bx));
+            put_le32(c, block_size(by));
+            put_le32(c, block_size(bz));
+            put_chunk(body, "SIZE", c);
+            c.clear();
+            put_le32(c, (uint32_t) (m.second.size() / 4));
+            c.insert(c.end(), m.second.begin(), m.second.end());
+            put_chunk(body, "XYZI", c);
+        }
+        if (models.size() > 1 || blocks > 1) {
+            std::vector<uint8_t> c;
+            put_le32(c, 0);  // root transform
+            put_dict(c, {});
+            put_le32(c, 1);
+            put_le32(c, 0xffffffffu);
+            put_le32(c, 0xffffffffu);
+            put_le32(c, 1);
+            put_dict(c, {});
+            put_chunk(body, "nTRN", c);
+            c.clear();
+            put_le32(c, 1);  // group of all models
+            put_dict(c, {});
+            put_le32(c, (uint32_t) models.size());
+            for (uint32_t k = 0; k < models.size(); ++k) put_le32(c, 2u + 2u * k);
+            put_chunk(body, "nGRP", c);
+            uint32_t k = 0;
+            for (const auto &m : models) {
+                const uint32_t bx = m.first % blocks, by = (m.first / blocks) % blocks, bz = m.first / (blocks * blocks);
+                const std::string t = std::to_string(bx * 256u + block_size(bx) / 2u) + " " +
+                                      std::to_string(by * 256u + block_size(by) / 2u) + " " +
+                                      std::to_string(bz * 256u + block_size(bz) / 2u);
+                c.clear();
+                put_le32(c, 2u + 2u * k);
+                put_dict(c, {});
+                put_le32(c, 3u + 2u * k);
+                put_le32(c, 0xffffffffu);
+                put_le32(c, 0);
+                put_le32(c, 1);
+                put_dict(c, {{"_t", t}});
+                put_chunk(body, "nTRN", c);
+                c.clear();
+                put_le32(c, 3u + 2u * k);
+                put_dict(c, {});
+                put_le32(c, 1);
+                put_le32(c, k);
+                put_dict(c, {});
+                put_chunk(body, "nSHP", c);
+                ++k;
+            }
+        }
+        {
+            std::vector<uint8_t> c;
+            for (uint32_t i = 0; i < 256; ++i) {
+                const uint32_t argb = i < table.size() ? table[i] : 0u;
+                c.push_back((uint8_t) (argb >> 16));
+                c.push_back((uint8_t) (argb >> 8));
+                c.push_back((uint8_t) argb);
+                c.push_back((uint8_t) (argb >> 24));
+            }
+            put_chunk(body, "RGBA", c);
+        }
+        std::vector<uint8_t> file{'V', 'O', 'X', ' '};
+        put_le32(file, 150);
+        file.insert(file.end(), {'M', 'A', 'I', 'N'});
+        put_le32(file, 0);
+        put_le32(file, (uint32_t) body.size());
+        out.put(file.data(), file.size());
+        out.put(body.data(), body.size());
+    }
+
+    void finalize() override
+    {
+        if (finalized) return;
+        finalized = true;
+        if (!out.ok) return;
+        if (format == FileFormat::QEF) write_qef();
+        else write_vox();
+        out.flush();
+        voxels.clear();
+        voxels.shrink_to_fit();
+    }
+};
+
+std::unique_ptr<VoxelSink> make_list_sink(FileFormat format, const char *path, uint32_t resolution)
+{
+    const bool paletted = format == FileFormat::QEF || format == FileFormat::VOX;
+    if (!paletted && format != FileFormat::VL32 && format != FileFormat::PLY && format != FileFormat::XYZRGB) {
+        log_message(LOG_ERROR, "Not an output format (this build writes VL32, PLY, XYZRGB, QEF and VOX)");
         return nullptr;
     }
-    auto sink = std::make_unique<ListSink>(format, path == nullptr);
+    std::FILE *file = nullptr;
     if (path) {
-        sink->out.file = std::fopen(path, "wb");
-        if (!sink->out.file) {
+        file = std::fopen(path, "wb");
+        if (!file) {
             log_message(LOG_ERROR, std::string("Failed to open output file: \"") + path + "\"");
             return nullptr;
         }
     }
+    if (paletted) {
+        auto sink = std::make_unique<PaletteSink>(format, path == nullptr, resolution);
+        sink->out.file = file;
+        return sink;
+    }
+    auto sink = std::make_unique<ListSink>(format, path == nullptr);
+    sink->out.file = file;
     sink->begin();
     return sink;
 }
 
 }  // namespace
 
-std::unique_ptr<VoxelSink> open_file_sink(const char *path, FileFormat format, uint32_t) { return make_list_sink(format, path); }
-std::unique_ptr<VoxelSink> open_memory_sink(FileFormat format, uint32_t) { return make_list_sink(format, nullptr); }
+std::unique_ptr<VoxelSink> open_file_sink(const char *path, FileFormat format, uint32_t resolution)
+{
+    return make_list_sink(format, path, resolution);
+}
+std::unique_ptr<VoxelSink> open_memory_sink(FileFormat format, uint32_t resolution)
+{
+    return make_list_sink(format, nullptr, resolution);
+}
 
 }  // namespace o2v

@@ -81,8 +81,163 @@ def test_binary_stl_to_vl32_ply_xyzrgb(tmp_path, oracle):
     got = np.concatenate([rows[:, :3], argb[:, None]], axis=1).astype(np.uint32)
     assert np.array_equal(meshes.sorted_voxels(got), want)
 
-    err, _ = _run_files(a, stl, ("memory", "qef"), 72)        # palette formats are not built
-    assert err == capi.ERR_OPEN_OUTPUT
+    a.obj2voxel_set_log_level(capi.LOG_INFO)
+
+
+def _parse_qef(data):
+    lines = data.decode().splitlines()
+    assert lines[:3] == ["Qubicle Exchange Format", "Version 0.2", "www.minddesk.com"]
+    size = [int(t) for t in lines[3].split()]
+    n_col = int(lines[4])
+    colors = np.array([[float(t) for t in ln.split()] for ln in lines[5:5 + n_col]])
+    rows = np.array([[int(t) for t in ln.split()] for ln in lines[5 + n_col:]], dtype=np.int64).reshape(-1, 5)
+    return size, colors, rows
+
+
+def _parse_vox(data):
+    """MagicaVoxel .vox (version 150): returns (models [(size, xyzi uint8 [n, 4])], translations, palette [256, 4])."""
+    assert data[:4] == b"VOX " and struct.unpack("<I", data[4:8])[0] == 150
+    assert data[8:12] == b"MAIN"
+    n_content, n_children = struct.unpack("<II", data[12:20])
+    assert n_content == 0 and 20 + n_children == len(data)
+    pos, sizes, models, trans, palette = 20, [], [], {}, None
+
+    def rd_str(b, o):
+        n = struct.unpack("<I", b[o:o + 4])[0]
+        return b[o + 4:o + 4 + n].decode(), o + 4 + n
+
+    def rd_dict(b, o):
+        n = struct.unpack("<I", b[o:o + 4])[0]
+        o += 4
+        d = {}
+        for _ in range(n):
+            k, o = rd_str(b, o)
+            v, o = rd_str(b, o)
+            d[k] = v
+        return d, o
+    while pos < len(data):
+        cid = data[pos:pos + 4]
+        nc, nch = struct.unpack("<II", data[pos + 4:pos + 12])
+        body = data[pos + 12:pos + 12 + nc]
+        assert nch == 0
+        pos += 12 + nc
+        if cid == b"SIZE":
+            sizes.append(struct.unpack("<III", body))
+        elif cid == b"XYZI":
+            n = struct.unpack("<I", body[:4])[0]
+            assert len(body) == 4 + 4 * n
+            models.append((sizes[-1], np.frombuffer(body[4:], np.uint8).reshape(-1, 4)))
+        elif cid == b"nTRN":
+            node = struct.unpack("<I", body[:4])[0]
+            _, o = rd_dict(body, 4)
+            child, _res, _layer, frames = struct.unpack("<IiiI", body[o:o + 16])
+            fr, o = rd_dict(body, o + 16)
+            assert frames == 1 and o == len(body)
+            if "_t" in fr:
+                trans[child] = [int(t) for t in fr["_t"].split()]
+        elif cid == b"nSHP":
+            node = struct.unpack("<I", body[:4])[0]
+            _, o = rd_dict(body, 4)
+            n_models, model_id = struct.unpack("<II", body[o:o + 8])
+            assert n_models == 1
+            trans[("model", model_id)] = trans.pop(node)
+        elif cid == b"RGBA":
+            palette = np.frombuffer(body, np.uint8).reshape(256, 4)
+        else:
+            assert cid == b"nGRP", cid
+    return models, trans, palette
+
+
+def test_palette_formats_qef_and_vox(tmp_path, oracle):
+    """QEF (text, unlimited colour table, face-visibility mask) and MagicaVoxel VOX
+    (binary chunks, <= 255 colours, 256^3 models placed by a scene graph). The files are parsed back and compared with
+    the oracle's voxels: positions exactly; colours exactly when they fit the table, else within the quantiser's error."""
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    v, uv = meshes.uv_sphere(10, with_uv=True)
+    T = len(v)
+    (tmp_path / "tex.png").write_bytes(_png_rgb(meshes.checker_texture(64, 8)))
+    (tmp_path / "m.mtl").write_text("newmtl few\nKd 0.5 0.25 1\nnewmtl many\nKd 1 1 1\nmap_Kd tex.png\n")
+
+    def write_obj(path, material):
+        lines = ["mtllib m.mtl", "usemtl " + material]
+        for t in range(T):
+            for k in range(3):
+                lines.append("v %r %r %r" % tuple(float(x) for x in v[t, k * 3:k * 3 + 3]))
+                lines.append("vt %r %r" % tuple(float(x) for x in uv[t, k * 2:k * 2 + 2]))
+            i = 3 * t + 1
+            lines.append(f"f {i}/{i} {i + 1}/{i + 1} {i + 2}/{i + 2}")
+        path.write_text("\n".join(lines) + "\n")
+    write_obj(tmp_path / "few.obj", "few")
+    write_obj(tmp_path / "many.obj", "many")
+    res = 40
+    few = meshes.sorted_voxels(oracle.voxelize(v, res, types=np.full(T, 2, np.uint32),
+                                               colors=np.tile(np.array([0.5, 0.25, 1.0], np.float32), (T, 1))))
+
+    # QEF, one colour
+    err, data = _run_files(a, tmp_path / "few.obj", ("memory", "qef"), res)
+    assert err == capi.ERR_OK
+    size, colors, rows = _parse_qef(data)
+    assert size == [res, res, res] and len(colors) == 1 and len(rows) == len(few)
+    assert np.allclose(colors[0] * 255, [(few[0, 3] >> 16) & 255, (few[0, 3] >> 8) & 255, few[0, 3] & 255], atol=1e-3)
+    got = np.concatenate([rows[:, :3], np.full((len(rows), 1), few[0, 3])], axis=1).astype(np.uint32)
+    assert np.array_equal(meshes.sorted_voxels(got), few)
+    filled = {tuple(p) for p in rows[:, :3].tolist()}
+    for x, y, z, _, mask in rows[::37].tolist():          # face mask: a face is visible iff the neighbour is empty
+        want = sum(bit for bit, d in ((2, (-1, 0, 0)), (4, (1, 0, 0)), (8, (0, 1, 0)), (16, (0, -1, 0)), (32, (0, 0, 1)),
+                                      (64, (0, 0, -1))) if (x + d[0], y + d[1], z + d[2]) not in filled)
+        assert mask == want
+
+    # VOX, one colour, single model
+    err, data = _run_files(a, tmp_path / "few.obj", ("file", tmp_path / "few.vox"), res)
+    assert err == capi.ERR_OK
+    models, trans, palette = _parse_vox(data)
+    assert len(models) == 1 and models[0][0] == (res, res, res) and not trans
+    xyzi = models[0][1]
+    assert (xyzi[:, 3] == 1).all()
+    assert palette[0].tolist() == [(few[0, 3] >> 16) & 255, (few[0, 3] >> 8) & 255, few[0, 3] & 255, 255]
+    got = np.concatenate([xyzi[:, :3].astype(np.uint32), np.full((len(xyzi), 1), few[0, 3], np.uint32)], axis=1)
+    assert np.array_equal(meshes.sorted_voxels(got), few)
+
+    # VOX at 300^3: several 256^3 models placed by the scene graph; a texture with 2 colours blended at cell borders
+    res = 300
+    many = meshes.sorted_voxels(oracle.voxelize(v, res, uvs=uv, types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32),
+                                                textures=[(meshes.checker_texture(64, 8), 1)], strategy=1))
+    err, data = _run_files(a, tmp_path / "many.obj", ("memory", "vox"), res, strategy=1)
+    assert err == capi.ERR_OK
+    models, trans, palette = _parse_vox(data)
+    assert len(models) == 4            # the sphere's surface misses the blocks beyond 256 on two or three axes
+    parts = []
+    n_colors = len(np.unique(many[:, 3]))
+    for k, (size, xyzi) in enumerate(models):
+        t = np.array(trans[("model", k)])
+        origin = t - np.array(size) // 2
+        assert set(origin.tolist()) <= {0, 256} and all(s in (256, 44) for s in size)
+        assert (xyzi[:, 3] >= 1).all()
+        rgba = palette[xyzi[:, 3].astype(int) - 1].astype(np.uint32)
+        argb = (rgba[:, 3] << 24) | (rgba[:, 0] << 16) | (rgba[:, 1] << 8) | rgba[:, 2]
+        parts.append(np.concatenate([xyzi[:, :3].astype(np.uint32) + origin.astype(np.uint32), argb[:, None]], axis=1))
+    got = meshes.sorted_voxels(np.concatenate(parts).astype(np.uint32))
+    assert np.array_equal(got[:, :3], many[:, :3])
+    ga = (got[:, 3:4] >> np.array([16, 8, 0], np.uint32)) & 255
+    wa = (many[:, 3:4] >> np.array([16, 8, 0], np.uint32)) & 255
+    if n_colors <= 255:
+        assert np.array_equal(got[:, 3], many[:, 3])
+    else:
+        assert np.abs(ga.astype(int) - wa.astype(int)).mean() < 4.0     # median cut to 255 colours
+
+    # QEF keeps every colour
+    err, data = _run_files(a, tmp_path / "many.obj", ("memory", "qef"), 64, strategy=1)
+    assert err == capi.ERR_OK
+    want64 = meshes.sorted_voxels(oracle.voxelize(v, 64, uvs=uv, types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32),
+                                                  textures=[(meshes.checker_texture(64, 8), 1)], strategy=1))
+    size, colors, rows = _parse_qef(data)
+    rgb = np.rint(colors[rows[:, 3]] * 255).astype(np.uint32)
+    argb = 0xFF000000 | (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+    got = np.concatenate([rows[:, :3].astype(np.uint32), argb[:, None].astype(np.uint32)], axis=1)
+    assert np.array_equal(meshes.sorted_voxels(got), want64)
+    assert len(colors) == len(np.unique(want64[:, 3]))
     a.obj2voxel_set_log_level(capi.LOG_INFO)
 
 

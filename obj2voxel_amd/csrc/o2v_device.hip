@@ -1782,11 +1782,43 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
         }
         __syncthreads();
         if (p.blend) {
-            // BLEND: the weighted mean is folded in the reference's order (float mix is not associative)
+            // BLEND: the weighted mean is folded in the reference's order (float mix is not associative), but only the
+            // chain over the triangles is sequential: every triangle's own hits (its leaves in this cell) and its colour
+            // lookup are independent of the other triangles, so the lane at a group's first record folds the group and
+            // leaves {weight, r, g, b} there; lane 0 then combines the groups in order (CellFold's close_tri /
+            // close_sub sequence without the loads).
+            for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+                if (t == 0 || s_hi[t] != s_hi[t - 1]) {
+                    WUv acc{s_w[t], s_u[t], s_v[t]};
+                    for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                    float cr, cg, cb;
+                    color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                    s_w[t] = acc.w;
+                    s_u[t] = cr;
+                    s_v[t] = cg;
+                    s_idx[t] = __float_as_uint(cb);  // the sort indices are no longer needed
+                }
+            }
+            __syncthreads();
             if (threadIdx.x == 0) {
-                CellFold f;
-                for (uint32_t t = 0; t < n; ++t) f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
-                out[i] = cell_record(o, f.finish(m, p.blend), p);
+                bool have_sub = false, have_cell = false;
+                WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
+                uint32_t cur_sub = 0;
+                for (uint32_t t = 0; t < n; ++t) {
+                    const uint32_t hi = s_hi[t];
+                    if (t != 0 && hi == s_hi[t - 1]) continue;
+                    if (have_sub && (hi >> 29) != cur_sub) {
+                        cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                        have_cell = true;
+                        have_sub = false;
+                    }
+                    const WCol fresh{s_w[t], s_u[t], s_v[t], __uint_as_float(s_idx[t])};
+                    sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
+                    have_sub = true;
+                    cur_sub = hi >> 29;
+                }
+                if (have_sub) cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                out[i] = cell_record(o, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b), p);
             }
         }
         else {
@@ -2177,11 +2209,12 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                        ctx->d_big, ctx->d_nodes[0], p);
     O2V_STAGE("k_expand_roots");
     for (uint32_t round = 0; round < n_rounds; ++round) {
-        hipLaunchKernelGGL(k_expand_nodes, dim3(persistent), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
+        // most rounds are empty or small: a narrow grid keeps an empty launch short (the kernel strides over its input)
+        hipLaunchKernelGGL(k_expand_nodes, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
         O2V_STAGE("k_expand_nodes");
     }
-    hipLaunchKernelGGL(k_expand_big, dim3(persistent), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
+    hipLaunchKernelGGL(k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
     O2V_STAGE("k_expand_big");
     O2V_CHECK(hipEventRecord(ctx->ev[2], s));
 

@@ -1603,8 +1603,9 @@ template <uint32_t STRIDE>
 __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn,
                                                     const Counters *c, Materials m, uint4 *out, Params p)
 {
+    constexpr bool kUv = STRIDE == 6;  // 16-byte records carry no uv: the columns shrink to 24 KiB, 6 workgroups per CU
     __shared__ uint64_t s_key[kShortList][kBlock];
-    __shared__ float s_w[kShortList][kBlock], s_u[kShortList][kBlock], s_v[kShortList][kBlock];
+    __shared__ float s_w[kShortList][kBlock], s_u[kUv ? kShortList : 1][kBlock], s_v[kUv ? kShortList : 1][kBlock];
     const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads below stay branch-free
     if (pass_overflowed(c, p)) return;
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
@@ -1624,20 +1625,24 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
                 while (j > 0 && s_key[j - 1][threadIdx.x] > key) {
                     s_key[j][threadIdx.x] = s_key[j - 1][threadIdx.x];
                     s_w[j][threadIdx.x] = s_w[j - 1][threadIdx.x];
-                    s_u[j][threadIdx.x] = s_u[j - 1][threadIdx.x];
-                    s_v[j][threadIdx.x] = s_v[j - 1][threadIdx.x];
+                    if (kUv) {
+                        s_u[j][threadIdx.x] = s_u[j - 1][threadIdx.x];
+                        s_v[j][threadIdx.x] = s_v[j - 1][threadIdx.x];
+                    }
                     --j;
                 }
                 s_key[j][threadIdx.x] = key;
                 s_w[j][threadIdx.x] = r[k].w;
-                s_u[j][threadIdx.x] = r[k].u;
-                s_v[j][threadIdx.x] = r[k].v;
+                if (kUv) {
+                    s_u[j][threadIdx.x] = r[k].u;
+                    s_v[j][threadIdx.x] = r[k].v;
+                }
             }
         }
         CellFold f;
         for (uint32_t t = 0; t < o.count; ++t)
-            f.add(m, p.blend, (uint32_t) (s_key[t][threadIdx.x] >> 32), s_w[t][threadIdx.x], s_u[t][threadIdx.x],
-                  s_v[t][threadIdx.x]);
+            f.add(m, p.blend, (uint32_t) (s_key[t][threadIdx.x] >> 32), s_w[t][threadIdx.x],
+                  kUv ? s_u[t][threadIdx.x] : 0.f, kUv ? s_v[t][threadIdx.x] : 0.f);
         out[i] = cell_record(o, f.finish(m, p.blend), p);
     }
 }
@@ -2279,7 +2284,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         hipLaunchKernelGGL(k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_lane,
                            &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<32>");
-        hipLaunchKernelGGL(k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_w64,
+        hipLaunchKernelGGL(k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sm, ctx->d_list_w64,
                            &ctx->d_ctr->n_w64, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<64>");
         hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, sm,

@@ -10,6 +10,7 @@
 #include "../../include/obj2voxel.h"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -36,13 +37,9 @@ struct obj2voxel_texture {
 };
 
 // reference src/triangle.hpp:170-195; filled only through obj2voxel_set_triangle_*
-struct obj2voxel_triangle {
-    float v[9];
-    float t[6];
-    uint32_t type;
-    float color[3];
-    const obj2voxel_texture *texture;
-};
+// "implementation-defined" in the public header (include/obj2voxel.h): the cached-triangle record itself, so that a
+// triangle callback fills the staging object the cache reads from (reference triangle.hpp:170-195)
+struct obj2voxel_triangle : o2v::HostTriangle {};
 
 namespace {
 
@@ -119,21 +116,27 @@ struct obj2voxel_instance {
 
 namespace {
 
+// wall-clock phases of one obj2voxel_voxelize call, logged at DEBUG level
+struct PhaseClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double lap_ms()
+    {
+        const auto now = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+        return ms;
+    }
+};
+
 struct CallbackTriangleSource final : TriangleSource {
     obj2voxel_triangle_callback *callback;
     void *data;
     CallbackTriangleSource(obj2voxel_triangle_callback *cb, void *d) : callback{cb}, data{d} {}
-    bool next(HostTriangle &out) override
+    const HostTriangle *next() override
     {
         // like `CachedTriangle triangle{}` (obj2voxel.cpp:585) the staging object is zeroed once and reused,
         // so fields a setter does not write keep their previous value
-        if (!callback(data, &staging)) return false;
-        std::memcpy(out.v, staging.v, sizeof(out.v));
-        std::memcpy(out.t, staging.t, sizeof(out.t));
-        out.type = staging.type;
-        std::memcpy(out.color, staging.color, sizeof(out.color));
-        out.texture = staging.texture;
-        return true;
+        return callback(data, &staging) ? &staging : nullptr;
     }
     obj2voxel_triangle staging{};
 };
@@ -177,6 +180,49 @@ std::unique_ptr<VoxelSink> open_output(obj2voxel_instance &inst)
     default: return nullptr;
     }
 }
+
+// ---- triangle cache ------------------------------------------------------------------------------------------
+// The reference caches every triangle as a 104-byte CachedTriangle (obj2voxel.cpp:122-132,585-600); here the source is
+// drained straight into the flat arrays of the device C-ABI.  Arrays only some triangle types need are created when
+// the first such triangle arrives (earlier entries zero), so a material-less mesh uploads 36 bytes per triangle.
+struct MeshArrays {
+    std::vector<float> verts, uvs, colors;
+    std::vector<uint32_t> types;
+    std::vector<int32_t> texids;
+    std::map<const obj2voxel_texture *, int32_t> tex_index;
+    std::vector<const obj2voxel_texture *> tex_list;
+    uint64_t n = 0;
+
+    void push(const HostTriangle &t)
+    {
+        verts.insert(verts.end(), t.v, t.v + 9);
+        if (t.type != O2V_HIP_TRI_MATERIALLESS && types.empty()) types.assign(n, O2V_HIP_TRI_MATERIALLESS);
+        if (!types.empty() || t.type != O2V_HIP_TRI_MATERIALLESS) types.push_back(t.type);
+        if (t.type == O2V_HIP_TRI_UNTEXTURED && colors.empty()) colors.assign(n * 3, 0.f);
+        if (!colors.empty() || t.type == O2V_HIP_TRI_UNTEXTURED) colors.insert(colors.end(), t.color, t.color + 3);
+        if (t.type == O2V_HIP_TRI_TEXTURED) {
+            O2V_ASSERT(t.texture != nullptr && t.texture->loaded(), "textured triangle without a loaded texture");
+            if (uvs.empty()) {
+                uvs.assign(n * 6, 0.f);
+                texids.assign(n, 0);
+            }
+        }
+        if (!uvs.empty() || t.type == O2V_HIP_TRI_TEXTURED) {
+            int32_t id = 0;
+            if (t.type == O2V_HIP_TRI_TEXTURED) {
+                auto it = tex_index.find(t.texture);
+                if (it == tex_index.end()) {
+                    it = tex_index.emplace(t.texture, (int32_t) tex_list.size()).first;
+                    tex_list.push_back(t.texture);
+                }
+                id = it->second;
+            }
+            uvs.insert(uvs.end(), t.t, t.t + 6);
+            texids.push_back(id);
+        }
+        ++n;
+    }
+};
 
 // ---- process-wide device context cache ---------------------------------------------------------------------
 struct CachedContext {
@@ -222,35 +268,11 @@ void release_context(CachedContext c)
 
 // The GPU leg of voxelize_specialized (reference obj2voxel.cpp:467-520): bounds, transform, per-triangle
 // voxelization, colour combine and packing all happen on the device; the host only moves data.
-obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, std::vector<HostTriangle> &tris)
+obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, MeshArrays &mesh)
 {
-    const uint64_t T = tris.size();
-    std::vector<float> verts(T * 9), uvs(T * 6), colors(T * 3);
-    std::vector<uint32_t> types(T);
-    std::vector<int32_t> texids(T);
-    std::map<const obj2voxel_texture *, int32_t> tex_index;
-    std::vector<const obj2voxel_texture *> tex_list;
-    bool any_uv = false;
-    for (uint64_t i = 0; i < T; ++i) {
-        const HostTriangle &t = tris[i];
-        std::memcpy(&verts[i * 9], t.v, sizeof(t.v));
-        std::memcpy(&uvs[i * 6], t.t, sizeof(t.t));
-        std::memcpy(&colors[i * 3], t.color, sizeof(t.color));
-        types[i] = t.type;
-        texids[i] = 0;
-        if (t.type == O2V_HIP_TRI_TEXTURED) {
-            O2V_ASSERT(t.texture != nullptr && t.texture->loaded(), "textured triangle without a loaded texture");
-            auto it = tex_index.find(t.texture);
-            if (it == tex_index.end()) {
-                it = tex_index.emplace(t.texture, (int32_t) tex_list.size()).first;
-                tex_list.push_back(t.texture);
-            }
-            texids[i] = it->second;
-            any_uv = true;
-        }
-    }
-    tris.clear();
-    tris.shrink_to_fit();
+    const uint64_t T = mesh.n;
+    const std::vector<const obj2voxel_texture *> &tex_list = mesh.tex_list;
+    PhaseClock clock;
 
     int device = 0;
     if (const char *env = std::getenv("O2V_DEVICE")) device = std::atoi(env);
@@ -279,9 +301,13 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, std::vector<HostT
                                            (uint32_t) t->channels, t->wrap});
     if (!tex_desc.empty() && o2v_hip_set_textures(ctx, tex_desc.data(), (uint32_t) tex_desc.size()) != O2V_HIP_OK)
         return device_error("uploading textures failed");
-    if (o2v_hip_set_triangles(ctx, verts.data(), any_uv ? uvs.data() : nullptr, types.data(), colors.data(),
-                              texids.data(), T) != O2V_HIP_OK)
+    if (o2v_hip_set_triangles(ctx, mesh.verts.data(), mesh.uvs.empty() ? nullptr : mesh.uvs.data(),
+                              mesh.types.empty() ? nullptr : mesh.types.data(),
+                              mesh.colors.empty() ? nullptr : mesh.colors.data(),
+                              mesh.texids.empty() ? nullptr : mesh.texids.data(), T) != O2V_HIP_OK)
         return device_error("uploading triangles failed");
+    mesh = MeshArrays{};  // the device holds the triangles now
+    const double ms_upload = clock.lap_ms();
 
     o2v_hip_params params{};
     params.resolution = inst.output_resolution;
@@ -294,6 +320,7 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, std::vector<HostT
 
     uint64_t count = 0;
     if (o2v_hip_voxelize(ctx, &params, &count) != O2V_HIP_OK) return device_error("device voxelization failed");
+    const double ms_device = clock.lap_ms();
 
     o2v_hip_timings tm{};
     o2v_hip_get_timings(ctx, &tm);
@@ -314,6 +341,9 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, std::vector<HostT
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "Voxelization failed because of IO error");
         return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
     }
+    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: context + upload " + std::to_string(ms_upload) + " ms, device call " +
+                                               std::to_string(ms_device) + " ms, read back + sink " +
+                                               std::to_string(clock.lap_ms()) + " ms");
     log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Voxelized " + std::to_string(T) + " triangles, writing any buffered voxels ...");
     inst.sink->finalize();
     if (!inst.sink->can_write()) return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
@@ -343,19 +373,20 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
     if (!inst.sink) return OBJ2VOXEL_ERR_IO_ERROR_ON_OPEN_OUTPUT_FILE;
 
     log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "Caching triangles ...");
-    std::vector<HostTriangle> tris;
-    HostTriangle tri{};
-    while (input->next(tri)) tris.push_back(tri);
+    PhaseClock clock;
+    MeshArrays mesh;
+    while (const HostTriangle *tri = input->next()) mesh.push(*tri);
+    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: draining the triangle source " + std::to_string(clock.lap_ms()) + " ms");
 
     obj2voxel_error_t result;
-    if (tris.empty()) {
+    if (mesh.n == 0) {
         log_message(OBJ2VOXEL_LOG_LEVEL_WARNING, "Model has no triangles, aborting and writing empty voxel model");
         inst.sink->finalize();
         result = inst.sink->can_write() ? OBJ2VOXEL_ERR_OK : OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
     }
     else {
-        log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Cached model with " + std::to_string(tris.size()) + " triangles");
-        result = voxelize_on_device(inst, tris);
+        log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Cached model with " + std::to_string(mesh.n) + " triangles");
+        result = voxelize_on_device(inst, mesh);
     }
     if (inst.output_kind != IoKind::MEMORY) inst.sink.reset();
     inst.done = true;

@@ -209,12 +209,7 @@ struct VectorTriangleSource final : TriangleSource {
     {
         for (auto *t : owned_textures) texture_delete(t);
     }
-    bool next(HostTriangle &out) override
-    {
-        if (index >= tris.size()) return false;
-        out = tris[index++];
-        return true;
-    }
+    const HostTriangle *next() override { return index < tris.size() ? &tris[index++] : nullptr; }
 };
 
 }  // namespace

@@ -32,7 +32,8 @@ struct HostTriangle {
 
 struct TriangleSource {  // reference io.hpp:29-67
     virtual ~TriangleSource() = default;
-    virtual bool next(HostTriangle &out) = 0;
+    /// The next triangle (valid until the following call), or null at the end of the stream.
+    virtual const HostTriangle *next() = 0;
 };
 
 struct VoxelSink {  // reference io.hpp:69-92

@@ -58,7 +58,8 @@ def main():
         _fields_ = [("voxels", C.c_size_t), ("calls", C.c_size_t)]
 
     verts = np.ascontiguousarray(meshes.uv_sphere(nv))
-    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    debug = os.environ.get("O2V_CAPI_DEBUG") == "1"   # prints the library's per-phase wall times
+    a.obj2voxel_set_log_level(4 if debug else capi.LOG_SILENT)
     a.obj2voxel_set_input_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     a.obj2voxel_set_output_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     times = []

@@ -124,3 +124,30 @@ def test_dense_cells_case(dv, oracle, seed):
     got = meshes.sorted_voxels(dv.voxelize(res, **kw))
     want = meshes.sorted_voxels(oracle.voxelize(v, res, textures=textures, **mat, **kw))
     assert np.array_equal(got, want), seed
+
+
+def test_extended_sweep(dv, oracle):
+    """Opt-in long sweep (O2V_FUZZ_EXTRA=N): N more random cases, N/4 more planar-stress cases and N/25 more
+    dense-cell cases beyond the fixed seeds above; reports every failing seed instead of stopping at the first."""
+    import os
+    n = int(os.environ.get("O2V_FUZZ_EXTRA", "0"))
+    if n == 0:
+        pytest.skip("set O2V_FUZZ_EXTRA=N to run the extended sweep")
+    bad = []
+    for seed in range(120, 120 + n):
+        v, res, kw, mat, textures = _case(seed)
+        dv.set_textures(textures)
+        dv.set_triangles(v, **mat)
+        got = meshes.sorted_voxels(dv.voxelize(res, **kw))
+        want = meshes.sorted_voxels(oracle.voxelize(v, res, textures=textures, **mat, **kw))
+        if got.shape != want.shape or not np.array_equal(got, want):
+            bad.append(("random", seed))
+    dv.set_textures([])
+    for seed in range(40, 40 + n // 4):
+        v, res, kw, mat = _planar_case(seed)
+        dv.set_triangles(v, **mat)
+        got = meshes.sorted_voxels(dv.voxelize(res, **kw))
+        want = meshes.sorted_voxels(oracle.voxelize(v, res, **mat, **kw))
+        if got.shape != want.shape or not np.array_equal(got, want):
+            bad.append(("planar", seed))
+    assert not bad, bad

@@ -323,10 +323,13 @@ __global__ void k_setup(Counters *c, Params p)
 // does not depend on the order of the adds, so every rank derives the same cuts).
 constexpr uint32_t kPlanBins = 2048;
 __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ verts, const Counters *__restrict__ c,
-                                                   unsigned long long *hist, Params p, uint32_t bin_h)
+                                                   unsigned long long *hist, float2 *zrange, float *zrange_xform,
+                                                   Params p, uint32_t bin_h)
 {
     __shared__ unsigned long long s_hist[kPlanBins];
     __shared__ float s_v[kBlock * 9];
+    __shared__ float s_zr[2][kBlock / 64];
+    if (blockIdx.x == 0 && threadIdx.x < 12) zrange_xform[threadIdx.x] = c->xform[threadIdx.x];
     for (uint32_t t = threadIdx.x; t < kPlanBins; t += kBlock) s_hist[t] = 0;
     Affine a;
     for (int i = 0; i < 3; ++i) a.m[i] = {c->xform[i * 3], c->xform[i * 3 + 1], c->xform[i * 3 + 2]};
@@ -336,10 +339,38 @@ __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ vert
         const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
         for (uint32_t k = threadIdx.x; k < n_here * 9; k += kBlock) s_v[k] = verts[base * 9 + k];
         __syncthreads();
-        if (threadIdx.x >= n_here) continue;
-        const float *q = &s_v[threadIdx.x * 9];
+        const bool live = threadIdx.x < n_here;
+        const float *q = &s_v[(live ? threadIdx.x : 0u) * 9];
         const V3 v0 = affine_apply(a, V3{q[0], q[1], q[2]}), v1 = affine_apply(a, V3{q[3], q[4], q[5]}),
                  v2 = affine_apply(a, V3{q[6], q[7], q[8]});
+        {
+            // z extent of this block of 256 triangles (the same float operations as k_expand_roots, so it can skip
+            // the whole block when the extent misses its slab); a NaN disables the shortcut for the block
+            const float inf = __builtin_inff();
+            float blo = fmin2(v0.z, fmin2(v1.z, v2.z)), bhi = fmax2(v0.z, fmax2(v1.z, v2.z));
+            if (!(v0.z == v0.z) || !(v1.z == v1.z) || !(v2.z == v2.z)) {
+                blo = -inf;
+                bhi = inf;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                blo = fminf(blo, __shfl_xor(blo, d, 64));
+                bhi = fmaxf(bhi, __shfl_xor(bhi, d, 64));
+            }
+            if ((threadIdx.x & 63u) == 0) {
+                s_zr[0][threadIdx.x >> 6] = blo;
+                s_zr[1][threadIdx.x >> 6] = bhi;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBlock / 64; ++wv) {
+                    blo = fminf(blo, s_zr[0][wv]);
+                    bhi = fmaxf(bhi, s_zr[1][wv]);
+                }
+                zrange[base / kBlock] = make_float2(blo, bhi);
+            }
+        }
+        if (!live) continue;
         const V3 n = tri_normal(v0, v1, v2), e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
         float est = (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) * 0.5f +
                     (abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z) + abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z) + abs_f(e2.x) +
@@ -504,7 +535,8 @@ __device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, 
 // voxelizeTriangleToUvBuffer (voxelization.cpp:488-511).
 __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict__ verts, const float *__restrict__ uvs,
                                                          Counters *c, Leaf *leaves, Tile *tiles, BigLeaf *big,
-                                                         Node *nodes_out, Params p)
+                                                         Node *nodes_out, const float2 *__restrict__ zrange,
+                                                         const float *__restrict__ zrange_xform, Params p)
 {
     __shared__ __align__(8) uint32_t s_wave[2 * (kBlock / 64)];
     __shared__ uint32_t s_base[4];
@@ -518,8 +550,18 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
     xf.m[2] = {c->xform[6], c->xform[7], c->xform[8]};
     xf.t = {c->xform[9], c->xform[10], c->xform[11]};
 
+    // z extents per block of 256 triangles from the slab plan (k_zhist), valid if they were made with this transform
+    bool use_zrange = zrange != nullptr;
+    if (use_zrange)
+        for (int i = 0; i < 12; ++i) use_zrange &= __float_as_uint(zrange_xform[i]) == __float_as_uint(c->xform[i]);
+
     const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        if (use_zrange) {
+            // every triangle of the block fails misses_slab()'s z test (floor_u32 is monotonic), so none is read
+            const float2 r = zrange[blk];
+            if (r.y < 1e9f && (floor_u32(r.y) + 1u <= p.zs0 || floor_u32(r.x) >= p.zs1)) continue;
+        }
         const uint64_t base = blk * kBlock;
         const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
         __syncthreads();
@@ -2093,6 +2135,10 @@ struct o2v_hip_ctx {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the cooperative resolve tiers run beside tier 1
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     unsigned long long *d_zhist = nullptr, *h_zhist = nullptr;  // kPlanBins each (h_: pinned), o2v_hip_plan_slabs
+    float2 *d_zrange = nullptr;      // z extent per 256 triangles, written by the slab plan
+    float *d_zrange_xform = nullptr;  // the transform they were computed with (12 floats)
+    uint32_t cap_zrange = 0;
+    uint64_t tri_generation = 0, zrange_generation = ~0ull;  // the extents belong to the triangles of that upload
     Leaf *d_leaves = nullptr;
     Tile *d_tiles = nullptr;
     BigLeaf *d_big = nullptr;
@@ -2211,7 +2257,8 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 
     hipLaunchKernelGGL(k_expand_roots, dim3(std::min<uint64_t>(persistent, (p.n_tris + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
-                       ctx->d_big, ctx->d_nodes[0], p);
+                       ctx->d_big, ctx->d_nodes[0], ctx->zrange_generation == ctx->tri_generation ? ctx->d_zrange : nullptr,
+                       ctx->d_zrange_xform, p);
     O2V_STAGE("k_expand_roots");
     for (uint32_t round = 0; round < n_rounds; ++round) {
         // most rounds are empty or small: a narrow grid keeps an empty launch short (the kernel strides over its input)
@@ -2385,6 +2432,8 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
         if (q) (void) hipFree(q);
     if (ctx->h_ctr) (void) hipHostFree(ctx->h_ctr);
     if (ctx->d_zhist) (void) hipFree(ctx->d_zhist);
+    if (ctx->d_zrange) (void) hipFree(ctx->d_zrange);
+    if (ctx->d_zrange_xform) (void) hipFree(ctx->d_zrange_xform);
     if (ctx->h_zhist) (void) hipHostFree(ctx->h_zhist);
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
@@ -2415,6 +2464,7 @@ int o2v_hip_set_triangles(o2v_hip_ctx *ctx, const float *verts, const float *uvs
     if ((rc = upload(ctx, ctx->d_colors, colors, count * 3))) return rc;
     if ((rc = upload(ctx, ctx->d_texids, texids, count))) return rc;
     ctx->n_tris = count;
+    ctx->tri_generation += 1;
     ctx->any_textured = false;
     if (types)
         for (uint64_t i = 0; i < count; ++i)
@@ -2699,13 +2749,21 @@ int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t 
                            dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
     hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
     O2V_CHECK(hipMemsetAsync(ctx->d_zhist, 0, kPlanBins * sizeof(unsigned long long), s));
+    {
+        int rc;
+        if ((rc = grow(ctx, ctx->d_zrange, ctx->cap_zrange, (p.n_tris + kBlock - 1) / kBlock))) return rc;
+        if (!ctx->d_zrange_xform) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zrange_xform), 12 * sizeof(float)));
+    }
+    ctx->zrange_generation = ~0ull;
     hipLaunchKernelGGL(k_zhist, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 6u, (p.n_tris + kBlock - 1) / kBlock)),
-                       dim3(kBlock), 0, s, ctx->d_verts, ctx->d_ctr, ctx->d_zhist, p, bin_out * ss);
+                       dim3(kBlock), 0, s, ctx->d_verts, ctx->d_ctr, ctx->d_zhist, ctx->d_zrange, ctx->d_zrange_xform, p,
+                       bin_out * ss);
     O2V_STAGE("k_zhist");
     O2V_CHECK(hipMemcpyAsync(ctx->h_zhist, ctx->d_zhist, n_bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipStreamSynchronize(s));
     O2V_CHECK(hipGetLastError());
+    ctx->zrange_generation = ctx->tri_generation;  // k_expand_roots may use the extents (it checks the transform)
     if (out_bounds && !params->bounds_known)
         for (int i = 0; i < 6; ++i) out_bounds[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
 

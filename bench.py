@@ -143,7 +143,7 @@ def main():
         achieved = alg_bytes[dom] / (stage_avg[dom] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if n == 1 and os.path.exists(tpath):  # the committed PMC pass measured the N = 1 workload
             try:
                 traffic = json.load(open(tpath)).get(kernel_of[dom])
             except Exception:

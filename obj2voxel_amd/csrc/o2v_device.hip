@@ -42,7 +42,8 @@ namespace {
 // ---- device-side records ----------------------------------------------------------------------------------
 
 constexpr uint32_t kTileSize = 256;       // candidate voxels per work tile
-constexpr uint32_t kTilesPerBatch = 192;  // tiles a workgroup stages at once
+constexpr uint32_t kTilesPerBatch = 192;  // tiles a workgroup stages at once (at most)
+constexpr uint32_t kMinTilesPerBatch = 4;  // ... and at least (one tile per wavefront in phase 1)
 constexpr uint32_t kBlock = 256;          // threads per workgroup (4 wavefronts)
 constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key holds 15 levels)
 constexpr uint32_t kHitChunk = 256;       // hit-pool slots a wavefront reserves per global atomic
@@ -994,7 +995,13 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
 
     if (expand_overflowed(c, p)) return;
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
-    const uint32_t n_batches = (n_tiles + kTilesPerBatch - 1) / kTilesPerBatch;
+    // Batch size: the LDS staging holds kTilesPerBatch tiles, but a small job is cut into smaller batches so that every
+    // workgroup gets about four of them (a 96^3 job has a few thousand tiles: 192 per batch would keep 3 % of the
+    // machine busy).
+    uint32_t tiles_per_batch = (n_tiles + gridDim.x * 4u - 1u) / (gridDim.x * 4u);
+    tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
+                      : (tiles_per_batch > kTilesPerBatch ? kTilesPerBatch : tiles_per_batch);
+    const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
     if (threadIdx.x == 0) s_hits = 0;
@@ -1005,8 +1012,8 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
         __syncthreads();
         const uint32_t batch = s_batch;
         if (batch >= n_batches) break;
-        const uint32_t first = batch * kTilesPerBatch;
-        const uint32_t nt = n_tiles - first < kTilesPerBatch ? n_tiles - first : kTilesPerBatch;
+        const uint32_t first = batch * tiles_per_batch;
+        const uint32_t nt = n_tiles - first < tiles_per_batch ? n_tiles - first : tiles_per_batch;
         if (threadIdx.x < nt) {
             const Tile t = tiles[first + threadIdx.x];
             s_tleaf[threadIdx.x] = t.leaf;

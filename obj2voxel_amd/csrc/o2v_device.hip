@@ -42,7 +42,7 @@ namespace {
 // ---- device-side records ----------------------------------------------------------------------------------
 
 constexpr uint32_t kTileSize = 256;       // candidate voxels per work tile
-constexpr uint32_t kTilesPerBatch = 192;  // tiles a workgroup stages at once (at most)
+constexpr uint32_t kTilesPerBatch = 128;  // tiles a workgroup stages at once (at most)
 constexpr uint32_t kMinTilesPerBatch = 4;  // ... and at least (one tile per wavefront in phase 1)
 constexpr uint32_t kBlock = 256;          // threads per workgroup (4 wavefronts)
 constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key holds 15 levels)
@@ -995,10 +995,11 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
 
     if (expand_overflowed(c, p)) return;
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
-    // Batch size: the LDS staging holds kTilesPerBatch tiles, but a small job is cut into smaller batches so that every
-    // workgroup gets about four of them (a 96^3 job has a few thousand tiles: 192 per batch would keep 3 % of the
-    // machine busy).
-    uint32_t tiles_per_batch = (n_tiles + gridDim.x * 4u - 1u) / (gridDim.x * 4u);
+    // Batch size: about six batches per workgroup, between one tile per wavefront and what the LDS staging holds.  Few
+    // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
+    // of the machine busy); many small ones pay the per-batch staging and barriers too often.  Measured on seven
+    // workload shapes.
+    uint32_t tiles_per_batch = (n_tiles + gridDim.x * 6u - 1u) / (gridDim.x * 6u);
     tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
                       : (tiles_per_batch > kTilesPerBatch ? kTilesPerBatch : tiles_per_batch);
     const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;

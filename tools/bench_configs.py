@@ -10,7 +10,12 @@ import numpy as np
 from obj2voxel_amd import hip, meshes
 
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None   # substring of the case name: run only the matching cases
+
+
 def run(dv, name, verts, res, steps=5, **kw):
+    if ONLY and ONLY not in name:
+        return
     uvs, types, colors, texids, textures = (kw.get(k) for k in ("uvs", "types", "colors", "texids", "textures"))
     if textures:
         dv.set_textures(textures)

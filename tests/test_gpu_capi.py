@@ -180,3 +180,48 @@ def test_colored_triangles_render_white_like_the_reference():
     assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
     a.obj2voxel_free(inst)
     assert (out.voxels()[:, 3] == 0xFFFFFFFF).all()
+
+
+def test_concurrent_instances_and_worker_pool(oracle):
+    """Two host threads voxelize different meshes at once (the process-wide device context serves one of them, the other
+    gets a temporary context), one of them in the reference CLI's worker-pool mode (src/main.cpp:149-194: workers parked
+    in obj2voxel_run_worker, set_parallel(true), stop_workers afterwards). Both results equal the oracle's."""
+    import threading
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    meshes_in = [meshes.uv_sphere(20), meshes.uv_sphere(14, radius=0.7, center=(0.2, 0.1, 0.0))]
+    resolutions = [112, 96]
+    results, errors = [None, None], [None, None]
+
+    def job(k):
+        inst, inp = _instance(a, meshes_in[k])
+        out = capi.CollectingOutput()
+        a.obj2voxel_set_output_callback(inst, out.callback, None)
+        a.obj2voxel_set_resolution(inst, resolutions[k])
+        workers = []
+        if k == 0:
+            a.obj2voxel_set_parallel(inst, True)
+            workers = [threading.Thread(target=a.obj2voxel_run_worker, args=(inst,)) for _ in range(2)]
+            for w in workers:
+                w.start()
+        errors[k] = a.obj2voxel_voxelize(inst)
+        if k == 0:
+            a.obj2voxel_stop_workers(inst)
+            for w in workers:
+                w.join(timeout=30)
+            assert not any(w.is_alive() for w in workers)
+        a.obj2voxel_free(inst)
+        results[k] = out.voxels()
+
+    for _ in range(3):   # a few rounds: the cache hand-over happens in either order
+        threads = [threading.Thread(target=job, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        assert errors == [capi.ERR_OK, capi.ERR_OK]
+        for k in range(2):
+            want = oracle.voxelize(meshes_in[k], resolutions[k])
+            assert np.array_equal(meshes.sorted_voxels(results[k]), meshes.sorted_voxels(want))
+    a.obj2voxel_set_log_level(capi.LOG_INFO)

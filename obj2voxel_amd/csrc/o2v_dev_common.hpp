@@ -1,0 +1,191 @@
+// o2v_dev_common.hpp -- records, constants and small helpers shared by the kernels.
+//
+// Part of the device code of o2v_device.hip, which includes this file inside its anonymous namespace (one
+// translation unit: the stages share records and launch parameters).  Not a stand-alone header.
+
+// ---- device-side records ----------------------------------------------------------------------------------
+
+constexpr uint32_t kTileSize = 256;       // candidate voxels per work tile
+constexpr uint32_t kTilesPerBatch = 128;  // tiles a workgroup stages at once (at most)
+constexpr uint32_t kMinTilesPerBatch = 4;  // ... and at least (one tile per wavefront in phase 1)
+constexpr uint32_t kBlock = 256;          // threads per workgroup (4 wavefronts)
+constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key holds 15 levels)
+constexpr uint32_t kHitChunk = 256;       // hit-pool slots a wavefront reserves per global atomic
+constexpr uint32_t kInlineTiles = 4;      // leaves with more tiles are expanded by k_expand_big
+
+struct __attribute__((aligned(16))) Leaf {  // 96 B
+    float v[9];        // sample-space vertices
+    float n[3];        // normalize(normal): plane of the distance cull
+    float t[6];        // uv per vertex
+    uint32_t tri;      // input triangle index
+    uint32_t pathkey;  // order key of this leaf among the leaves of `tri` (0 = unsplit triangle)
+    uint32_t bmin_xy;  // clamped AABB min: x | y << 16
+    uint32_t bmin_z_dx;  // z | dx << 16
+    uint32_t dy_dz;      // dy | dz << 16
+    float area;          // area of the whole input triangle (voxelization.cpp:416)
+};
+static_assert(sizeof(Leaf) == 96, "Leaf layout");
+
+struct __attribute__((aligned(16))) Node {  // 80 B: a sub-triangle that still has to be subdivided
+    float v[9];
+    float t[6];
+    uint32_t tri;
+    uint32_t pathkey;
+    uint32_t depth;
+    float area;
+    uint32_t pad;
+};
+static_assert(sizeof(Node) == 80, "Node layout");
+
+struct Tile {
+    uint32_t leaf;
+    uint32_t start;  // first candidate index inside the leaf's clamped AABB
+};
+
+struct BigLeaf {
+    uint32_t leaf, first_tile, ntiles, pad;
+};
+
+struct __attribute__((aligned(16))) HitRec {  // 32 B: one (leaf, voxel) hit as emitted by k_voxelize
+    uint32_t brick;       // brick of the cell; kHoleBrick marks a pool slot that holds no hit
+    uint32_t local_rank;  // cell inside the brick << 24 | rank of this hit among the hits of its cell
+    uint32_t keyhi;       // sub-voxel << 29 | triangle index
+    uint32_t keylo;       // leaf order key
+    float w, u, v;        // WeightedUv of this (leaf, voxel) pair (voxelization.cpp:414-423)
+    uint32_t pad;
+};
+constexpr uint32_t kHoleBrick = 0xffffffffu;
+constexpr uint32_t kMaxRank = 1u << 24;
+
+struct __attribute__((aligned(8))) SortedRec {  // 24 B: the same hit, placed contiguously with its cell's other hits
+    uint32_t keyhi, keylo;
+    float w, u, v;
+    uint32_t pad;
+};
+
+// The sorted array is read through a view: 6 dwords per record in general, 4 (keyhi, keylo, w, pad: one 16-byte access)
+// when the mesh has no textured triangle, because then u and v are never used and the scatter's cost scales with the
+// bytes it writes.
+struct SortedView {
+    const uint32_t *base;
+    uint32_t stride;  // dwords per record: 6 or 4
+    __device__ __forceinline__ SortedRec load(uint32_t i) const
+    {
+        if (stride == 4u) {
+            const uint4 q = reinterpret_cast<const uint4 *>(base)[i];
+            return SortedRec{q.x, q.y, __uint_as_float(q.z), 0.f, 0.f, 0u};
+        }
+        return reinterpret_cast<const SortedRec *>(base)[i];
+    }
+};
+
+struct __attribute__((aligned(16))) Occ {  // 16 B: one occupied cell
+    uint32_t cell_lo, cell_hi;  // brick * 256 + cell in brick
+    uint32_t offset;            // first SortedRec of the cell
+    uint32_t count;             // number of hits
+};
+
+struct DevTexture {
+    const uint8_t *pixels;
+    uint32_t width, height, channels, wrap;
+};
+
+struct Counters {
+    uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
+    uint32_t n_vox, batch_cursor, err_flags, n_lane16;
+    uint32_t n_mid, n_long, n_huge, scratch_used;
+    uint32_t n_dirty, n_sorted, n_bigl, cursor_big;
+    uint32_t cursor_mid, cursor_long, cursor_huge, n_lane;
+    uint32_t n_nodes[kMaxRounds + 1];
+    uint32_t n_w64, pad1[2];
+    unsigned long long n_candidates, n_hits;
+    uint32_t bounds_enc[6];
+    uint32_t pad2[2];
+    float xform[12];
+};
+
+enum : uint32_t {
+    kErrLeafTooLarge = 1u,
+    kErrDepth = 2u,
+    kErrRank = 4u,
+};
+
+struct Params {
+    uint64_t n_tris;
+    uint32_t S;            // sample resolution = resolution * supersampling
+    uint32_t G;            // output resolution
+    uint32_t NBx, NBy;     // bricks per grid row / per z layer (brick = 16 x 4 x 4 cells, stored contiguously)
+    uint32_t ss_shift;     // 0, or 1 for 2x supersampling
+    uint32_t zs0, zs1;     // slab in sample space
+    uint32_t zo0;          // slab begin in output space
+    uint32_t blend;
+    uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
+    uint32_t n_bricks;     // bricks of this slab
+    uint32_t bounds_known;
+    float bounds[6];
+    int32_t unit[9];
+    uint32_t has_uv;
+};
+
+// ---- small device helpers ---------------------------------------------------------------------------------
+
+// A pass that ran out of hit-pool or cell-list space has cell offsets that point past the sorted records: the
+// resolve kernels skip such a pass (the host grows the buffers and runs it again).
+// A pass whose subdivision ran out of leaf / tile / queue space is discarded by the host as well; k_voxelize skips it
+// (a tile may name a leaf that was never written).
+__device__ __forceinline__ bool expand_overflowed(const Counters *c, const Params &p)
+{
+    bool over = c->n_leaves > p.cap_leaves || c->n_tiles > p.cap_tiles || c->n_big > p.cap_big;
+    for (uint32_t r = 0; r <= kMaxRounds; ++r) over |= c->n_nodes[r] > p.cap_nodes;
+    return over;
+}
+__device__ __forceinline__ bool pass_overflowed(const Counters *c, const Params &p)
+{
+    return c->n_hits_reserved > p.cap_hits || c->n_sorted > p.cap_hits || c->n_vox > p.cap_vox;
+}
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o)
+{
+    uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(b);
+}
+
+// Dense grid layout: bricks of 16 (x) x 4 (y) x 4 (z) cells, each brick 256 consecutive u32 (1 KiB), bricks ordered
+// x fastest.  A surface marks ~12 cells' worth of brick volume per unit area in this shape (the same as 8^3 bricks)
+// while every brick row is a full 64-byte line; one wavefront reads a brick with a single 16-byte load per lane.
+constexpr uint32_t kBrickX = 16, kBrickY = 4, kBrickZ = 4, kBrickCells = 256;
+
+__device__ __forceinline__ uint64_t cell_index(uint32_t ox, uint32_t oy, uint32_t oz_rel, const Params &p, uint32_t &brick)
+{
+    brick = ((oz_rel >> 2) * p.NBy + (oy >> 2)) * p.NBx + (ox >> 4);
+    return (uint64_t) brick * kBrickCells + (((oz_rel & 3u) * 4u + (oy & 3u)) * 16u + (ox & 15u));
+}
+
+// exclusive scan of one uint32 per thread over a 256-thread block; returns the block total in `total`
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &total)
+{
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        uint32_t c = s_wave[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + inc - v;
+}

@@ -1,0 +1,171 @@
+// o2v_dev_k0_bounds_plan.hpp -- K0: mesh bounds + transform (k_init, k_bounds, k_setup) and the slab plan (k_zhist).
+//
+// Part of the device code of o2v_device.hip, which includes this file inside its anonymous namespace (one
+// translation unit: the stages share records and launch parameters).  Not a stand-alone header.
+
+// ---- K0: bounds + transform ---------------------------------------------------------------------------------
+
+__global__ void k_init(Counters *c)
+{
+    uint32_t i = threadIdx.x;
+    uint32_t *w = reinterpret_cast<uint32_t *>(c);
+    for (uint32_t k = i; k < sizeof(Counters) / 4; k += blockDim.x) w[k] = 0;
+    __syncthreads();
+    if (i < 3) c->bounds_enc[i] = f2ord(__builtin_inff());
+    else if (i < 6) c->bounds_enc[i] = f2ord(-__builtin_inff());
+}
+
+// findMeshBounds (obj2voxel.cpp:180-200): min/max are exact and order-free, so one reduce replaces the batches.
+// The vertex array is streamed as float4 triples (12 floats = 4 vertices, so the axis of every element is static);
+// one set of six atomics per workgroup.
+__global__ __launch_bounds__(kBlock) void k_bounds(const float *__restrict__ verts, uint64_t n_floats, Counters *c)
+{
+    __shared__ float s_red[6][kBlock / 64];
+    const float inf = __builtin_inff();
+    float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+    const uint64_t n_groups = n_floats / 12;
+    const float4 *v4 = reinterpret_cast<const float4 *>(verts);
+    for (uint64_t g = (uint64_t) blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += (uint64_t) gridDim.x * kBlock) {
+        const float4 a = v4[g * 3], b = v4[g * 3 + 1], d = v4[g * 3 + 2];
+        const float e[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            mn[k % 3] = fmin2(e[k], mn[k % 3]);
+            mx[k % 3] = fmax2(e[k], mx[k % 3]);
+        }
+    }
+    if (blockIdx.x == 0)
+        for (uint64_t i = n_groups * 12 + threadIdx.x; i < n_floats; i += kBlock) {
+            const float f = verts[i];
+            const int a = (int) (i % 3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k == a) {
+                    mn[k] = fmin2(f, mn[k]);
+                    mx[k] = fmax2(f, mx[k]);
+                }
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s_red[a][threadIdx.x >> 6] = mn[a];
+            s_red[3 + a][threadIdx.x >> 6] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = s_red[threadIdx.x][0];
+        for (uint32_t w = 1; w < kBlock / 64; ++w) r = threadIdx.x < 3 ? fminf(r, s_red[threadIdx.x][w]) : fmaxf(r, s_red[threadIdx.x][w]);
+        if (threadIdx.x < 3) atomicMin(&c->bounds_enc[threadIdx.x], f2ord(r));
+        else atomicMax(&c->bounds_enc[threadIdx.x], f2ord(r));
+    }
+}
+
+__global__ void k_setup(Counters *c, Params p)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    V3 mn, mx;
+    if (p.bounds_known) {
+        mn = {p.bounds[0], p.bounds[1], p.bounds[2]};
+        mx = {p.bounds[3], p.bounds[4], p.bounds[5]};
+    }
+    else {
+        mn = {ord2f(c->bounds_enc[0]), ord2f(c->bounds_enc[1]), ord2f(c->bounds_enc[2])};
+        mx = {ord2f(c->bounds_enc[3]), ord2f(c->bounds_enc[4]), ord2f(c->bounds_enc[5])};
+    }
+    Affine a = compute_mesh_transform(mn, mx, p.S, p.unit);
+    for (int i = 0; i < 3; ++i) {
+        c->xform[i * 3 + 0] = a.m[i].x;
+        c->xform[i * 3 + 1] = a.m[i].y;
+        c->xform[i * 3 + 2] = a.m[i].z;
+    }
+    c->xform[9] = a.t.x;
+    c->xform[10] = a.t.y;
+    c->xform[11] = a.t.z;
+}
+
+// ---- slab planning: where to cut the grid so that N GPUs get equal work ------------------------------------
+//
+// Pipeline time is proportional to the number of (triangle, voxel) hits (measured: 0.23 ms per million on every
+// slab of the weak-scaling job), and the hits of one triangle are predicted to ~0.1 % per slab by the Steiner-type
+// count  A_x + A_y + A_z + (L1 perimeter) / 2 + 1  (projected areas and edge lengths in voxel units).  k_zhist
+// spreads that estimate over the triangle's z layers into <= 2048 bins (fixed point, integer atomics: the result
+// does not depend on the order of the adds, so every rank derives the same cuts).
+constexpr uint32_t kPlanBins = 2048;
+__global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ verts, const Counters *__restrict__ c,
+                                                   unsigned long long *hist, float2 *zrange, float *zrange_xform,
+                                                   Params p, uint32_t bin_h)
+{
+    __shared__ unsigned long long s_hist[kPlanBins];
+    __shared__ float s_v[kBlock * 9];
+    __shared__ float s_zr[2][kBlock / 64];
+    if (blockIdx.x == 0 && threadIdx.x < 12) zrange_xform[threadIdx.x] = c->xform[threadIdx.x];
+    for (uint32_t t = threadIdx.x; t < kPlanBins; t += kBlock) s_hist[t] = 0;
+    Affine a;
+    for (int i = 0; i < 3; ++i) a.m[i] = {c->xform[i * 3], c->xform[i * 3 + 1], c->xform[i * 3 + 2]};
+    a.t = {c->xform[9], c->xform[10], c->xform[11]};
+    for (uint64_t base = (uint64_t) blockIdx.x * kBlock; base < p.n_tris; base += (uint64_t) gridDim.x * kBlock) {
+        __syncthreads();
+        const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
+        for (uint32_t k = threadIdx.x; k < n_here * 9; k += kBlock) s_v[k] = verts[base * 9 + k];
+        __syncthreads();
+        const bool live = threadIdx.x < n_here;
+        const float *q = &s_v[(live ? threadIdx.x : 0u) * 9];
+        const V3 v0 = affine_apply(a, V3{q[0], q[1], q[2]}), v1 = affine_apply(a, V3{q[3], q[4], q[5]}),
+                 v2 = affine_apply(a, V3{q[6], q[7], q[8]});
+        {
+            // z extent of this block of 256 triangles (the same float operations as k_expand_roots, so it can skip
+            // the whole block when the extent misses its slab); a NaN disables the shortcut for the block
+            const float inf = __builtin_inff();
+            float blo = fmin2(v0.z, fmin2(v1.z, v2.z)), bhi = fmax2(v0.z, fmax2(v1.z, v2.z));
+            if (!(v0.z == v0.z) || !(v1.z == v1.z) || !(v2.z == v2.z)) {
+                blo = -inf;
+                bhi = inf;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                blo = fminf(blo, __shfl_xor(blo, d, 64));
+                bhi = fmaxf(bhi, __shfl_xor(bhi, d, 64));
+            }
+            if ((threadIdx.x & 63u) == 0) {
+                s_zr[0][threadIdx.x >> 6] = blo;
+                s_zr[1][threadIdx.x >> 6] = bhi;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBlock / 64; ++wv) {
+                    blo = fminf(blo, s_zr[0][wv]);
+                    bhi = fmaxf(bhi, s_zr[1][wv]);
+                }
+                zrange[base / kBlock] = make_float2(blo, bhi);
+            }
+        }
+        if (!live) continue;
+        const V3 n = tri_normal(v0, v1, v2), e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
+        float est = (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) * 0.5f +
+                    (abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z) + abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z) + abs_f(e2.x) +
+                     abs_f(e2.y) + abs_f(e2.z)) * 0.5f + 1.0f;
+        if (!(est < 1e12f)) est = 1e12f;  // also catches NaN
+        const float zlo = fmin2(v0.z, fmin2(v1.z, v2.z)), zhi = fmax2(v0.z, fmax2(v1.z, v2.z));
+        if (!(zhi >= 0.f) || !(zlo < (float) p.S)) continue;
+        const uint32_t l0 = zlo > 0.f ? (uint32_t) zlo : 0u;
+        const uint32_t l1 = zhi < (float) (p.S - 1) ? (uint32_t) zhi : p.S - 1;
+        const float per_layer = est * 16.0f / (float) (l1 - l0 + 1);
+        for (uint32_t b = l0 / bin_h; b <= l1 / bin_h; ++b) {
+            const uint32_t lo = b * bin_h > l0 ? b * bin_h : l0;
+            const uint32_t hi = (b + 1) * bin_h - 1 < l1 ? (b + 1) * bin_h - 1 : l1;
+            atomicAdd(&s_hist[b], (unsigned long long) (per_layer * (float) (hi - lo + 1) + 0.5f));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < kPlanBins; t += kBlock)
+        if (s_hist[t]) atomicAdd(&hist[t], s_hist[t]);
+}

@@ -1,0 +1,366 @@
+// o2v_dev_k1_expand.hpp -- K1: leaves - root triangles, exact subdivision rounds, tiles (k_expand_roots / _nodes / _big).
+//
+// Part of the device code of o2v_device.hip, which includes this file inside its anonymous namespace (one
+// translation unit: the stages share records and launch parameters).  Not a stand-alone header.
+
+// ---- K1: leaves --------------------------------------------------------------------------------------------
+
+struct Sub {  // a (sub-)triangle in registers
+    V3 v0, v1, v2;
+    V2 t0, t1, t2;
+};
+
+struct LeafPlan {
+    uint32_t lo[3], d[3];
+    uint32_t ntiles;  // 0 = nothing to do (outside the slab)
+    uint64_t count;
+};
+
+// Clamp the voxel AABB of a leaf to the grid and the slab: voxelization.cpp:440-444 with min/max = slab bounds.
+__device__ __forceinline__ LeafPlan plan_leaf(const Sub &s, const Params &p)
+{
+    LeafPlan pl;
+    V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
+    uint32_t lo[3] = {floor_u32(mn.x), floor_u32(mn.y), floor_u32(mn.z)};
+    uint32_t hi[3] = {floor_u32(mx.x) + 1u, floor_u32(mx.y) + 1u, floor_u32(mx.z) + 1u};
+    uint32_t glo[3] = {0u, 0u, p.zs0}, ghi[3] = {p.S, p.S, p.zs1};
+    bool empty = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = lo[a] > glo[a] ? lo[a] : glo[a];
+        hi[a] = hi[a] < ghi[a] ? hi[a] : ghi[a];
+        empty |= lo[a] >= hi[a];
+        pl.lo[a] = lo[a];
+        pl.d[a] = empty ? 0u : hi[a] - lo[a];
+    }
+    pl.count = empty ? 0ull : (uint64_t) pl.d[0] * pl.d[1] * pl.d[2];
+    pl.ntiles = (uint32_t) ((pl.count + kTileSize - 1) / kTileSize);
+    return pl;
+}
+
+// u32 voxel AABB volume, wrapping like the reference's Vec3u32 product (voxelization.cpp:357-361)
+__device__ __forceinline__ uint32_t voxel_volume(const Sub &s)
+{
+    V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
+    uint32_t dx = (floor_u32(mx.x) + 1u) - floor_u32(mn.x);
+    uint32_t dy = (floor_u32(mx.y) + 1u) - floor_u32(mn.y);
+    uint32_t dz = (floor_u32(mx.z) + 1u) - floor_u32(mn.z);
+    return dx * dy * dz;
+}
+
+// true if the sub-triangle's voxel AABB misses the slab entirely (then none of its descendants can touch it:
+// midpoints stay inside the parent's AABB because rounding is monotonic)
+__device__ __forceinline__ bool misses_slab(const Sub &s, const Params &p)
+{
+    V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
+    uint32_t zlo = floor_u32(mn.z), zhi = floor_u32(mx.z) + 1u;
+    uint32_t xlo = floor_u32(mn.x), ylo = floor_u32(mn.y);
+    return zhi <= p.zs0 || zlo >= p.zs1 || xlo >= p.S || ylo >= p.S;
+}
+
+__device__ __forceinline__ void write_leaf(Leaf *leaves, uint32_t idx, const Sub &s, uint32_t tri, uint32_t pathkey,
+                                           float area, const LeafPlan &pl)
+{
+    V3 n = normalize(tri_normal(s.v0, s.v1, s.v2));  // voxelization.cpp:438
+    Leaf l;
+    l.v[0] = s.v0.x; l.v[1] = s.v0.y; l.v[2] = s.v0.z;
+    l.v[3] = s.v1.x; l.v[4] = s.v1.y; l.v[5] = s.v1.z;
+    l.v[6] = s.v2.x; l.v[7] = s.v2.y; l.v[8] = s.v2.z;
+    l.n[0] = n.x; l.n[1] = n.y; l.n[2] = n.z;
+    l.t[0] = s.t0.x; l.t[1] = s.t0.y; l.t[2] = s.t1.x; l.t[3] = s.t1.y; l.t[4] = s.t2.x; l.t[5] = s.t2.y;
+    l.tri = tri;
+    l.pathkey = pathkey;
+    l.bmin_xy = pl.lo[0] | (pl.lo[1] << 16);
+    l.bmin_z_dx = pl.lo[2] | (pl.d[0] << 16);
+    l.dy_dz = pl.d[1] | (pl.d[2] << 16);
+    l.area = area;
+    leaves[idx] = l;
+}
+
+__device__ __forceinline__ void write_tiles(Tile *tiles, BigLeaf *big, uint32_t leaf_idx, uint32_t first_tile,
+                                            uint32_t ntiles, uint32_t big_slot, const Params &p)
+{
+    if (ntiles <= kInlineTiles) {
+        for (uint32_t k = 0; k < ntiles; ++k)
+            if (first_tile + k < p.cap_tiles) tiles[first_tile + k] = Tile{leaf_idx, k * kTileSize};
+    }
+    else if (big_slot < p.cap_big) {
+        big[big_slot] = BigLeaf{leaf_idx, first_tile, ntiles, 0};
+    }
+}
+
+struct Emit {  // what one lane wants to append this round
+    uint32_t n_leaf, n_tile, n_big, n_node;
+};
+
+struct BlockSlots {
+    uint32_t leaf, tile, big, node;
+};
+
+// One reservation per counter per workgroup (a per-lane atomic on one address would serialise at ~88/us).  The four
+// per-lane counts are packed into one 64-bit value (tiles: 31 bits; leaves, big leaves, nodes: 11 bits each, a lane
+// emits at most 4 of each, so a block at most 1024) so that a single block scan yields all four offsets.
+__device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, uint32_t node_round, uint32_t *s_wave,
+                                                    uint32_t *s_base)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long mine = (unsigned long long) e.n_tile | ((unsigned long long) e.n_leaf << 31) |
+                                    ((unsigned long long) e.n_big << 42) | ((unsigned long long) e.n_node << 53);
+    unsigned long long inc = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    unsigned long long *s_wave64 = reinterpret_cast<unsigned long long *>(s_wave);  // [kBlock / 64], 8-byte aligned
+    __syncthreads();
+    if (lane == 63) s_wave64[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const unsigned long long v = s_wave64[w];
+        if (w < wave) base += v;
+        tot += v;
+    }
+    const unsigned long long ex = base + inc - mine;
+    const uint32_t tot_tile = (uint32_t) tot & 0x7fffffffu, tot_leaf = (uint32_t) (tot >> 31) & 2047u,
+                   tot_big = (uint32_t) (tot >> 42) & 2047u, tot_node = (uint32_t) (tot >> 53) & 2047u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base[0] = tot_leaf ? atomicAdd(&c->n_leaves, tot_leaf) : 0u;
+        s_base[1] = tot_tile ? atomicAdd(&c->n_tiles, tot_tile) : 0u;
+        s_base[2] = tot_big ? atomicAdd(&c->n_big, tot_big) : 0u;
+        s_base[3] = tot_node ? atomicAdd(&c->n_nodes[node_round], tot_node) : 0u;
+    }
+    __syncthreads();
+    BlockSlots off;
+    off.tile = ((uint32_t) ex & 0x7fffffffu) + s_base[1];
+    off.leaf = ((uint32_t) (ex >> 31) & 2047u) + s_base[0];
+    off.big = ((uint32_t) (ex >> 42) & 2047u) + s_base[2];
+    off.node = ((uint32_t) (ex >> 53) & 2047u) + s_base[3];
+    return off;
+}
+
+// Roots: one lane per input triangle.  applyMeshTransform (obj2voxel.cpp:202-224) then the head of
+// voxelizeTriangleToUvBuffer (voxelization.cpp:488-511).
+__global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict__ verts, const float *__restrict__ uvs,
+                                                         Counters *c, Leaf *leaves, Tile *tiles, BigLeaf *big,
+                                                         Node *nodes_out, const float2 *__restrict__ zrange,
+                                                         const float *__restrict__ zrange_xform, Params p)
+{
+    __shared__ __align__(8) uint32_t s_wave[2 * (kBlock / 64)];
+    __shared__ uint32_t s_base[4];
+    __shared__ float s_v[kBlock * 9];
+    __shared__ float s_t[kBlock * 6];
+    __shared__ unsigned long long s_cand;
+
+    Affine xf;
+    xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
+    xf.m[1] = {c->xform[3], c->xform[4], c->xform[5]};
+    xf.m[2] = {c->xform[6], c->xform[7], c->xform[8]};
+    xf.t = {c->xform[9], c->xform[10], c->xform[11]};
+
+    // z extents per block of 256 triangles from the slab plan (k_zhist), valid if they were made with this transform
+    bool use_zrange = zrange != nullptr;
+    if (use_zrange)
+        for (int i = 0; i < 12; ++i) use_zrange &= __float_as_uint(zrange_xform[i]) == __float_as_uint(c->xform[i]);
+
+    const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
+    for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        if (use_zrange) {
+            // every triangle of the block fails misses_slab()'s z test (floor_u32 is monotonic), so none is read
+            const float2 r = zrange[blk];
+            if (r.y < 1e9f && (floor_u32(r.y) + 1u <= p.zs0 || floor_u32(r.x) >= p.zs1)) continue;
+        }
+        const uint64_t base = blk * kBlock;
+        const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
+        __syncthreads();
+        if (threadIdx.x == 0) s_cand = 0;
+        // coalesced staging of this block's vertices / uvs through LDS
+        for (uint32_t i = threadIdx.x; i < n_here * 9; i += kBlock) s_v[i] = verts[base * 9 + i];
+        if (p.has_uv)
+            for (uint32_t i = threadIdx.x; i < n_here * 6; i += kBlock) s_t[i] = uvs[base * 6 + i];
+        __syncthreads();
+
+        const bool live = threadIdx.x < n_here;
+        Sub s{};
+        Emit e{0, 0, 0, 0};
+        LeafPlan pl{};
+        float area = 0;
+        bool as_leaf = false, as_node = false;
+        if (live) {
+            const float *q = &s_v[threadIdx.x * 9];
+            s.v0 = affine_apply(xf, V3{q[0], q[1], q[2]});
+            s.v1 = affine_apply(xf, V3{q[3], q[4], q[5]});
+            s.v2 = affine_apply(xf, V3{q[6], q[7], q[8]});
+            if (p.has_uv) {
+                const float *r = &s_t[threadIdx.x * 6];
+                s.t0 = {r[0], r[1]};
+                s.t1 = {r[2], r[3]};
+                s.t2 = {r[4], r[5]};
+            }
+            if (!misses_slab(s, p)) {
+                area = tri_area(s.v0, s.v1, s.v2);
+                if (roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit) {
+                    pl = plan_leaf(s, p);
+                    if (pl.count >> 32) {
+                        atomicOr(&c->err_flags, kErrLeafTooLarge);
+                    }
+                    else if (pl.ntiles) {
+                        as_leaf = true;
+                        e.n_leaf = 1;
+                        e.n_tile = pl.ntiles;
+                        e.n_big = pl.ntiles > kInlineTiles ? 1u : 0u;
+                    }
+                }
+                else {
+                    as_node = true;
+                    e.n_node = 1;
+                }
+            }
+        }
+        // a block whose triangles all miss this GPU's slab has nothing to reserve (the common case on the other
+        // ranks of a multi-GPU run, where every rank filters the whole triangle list)
+        if (!__syncthreads_or((int) (as_leaf || as_node))) continue;
+        BlockSlots slot = reserve_slots(e, c, 0, s_wave, s_base);
+        if (as_leaf) {
+            if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, (uint32_t) (base + threadIdx.x), 0u, area, pl);
+            write_tiles(tiles, big, slot.leaf, slot.tile, pl.ntiles, slot.big, p);
+            atomicAdd(&s_cand, pl.count);
+        }
+        if (as_node && slot.node < p.cap_nodes) {
+            Node n;
+            n.v[0] = s.v0.x; n.v[1] = s.v0.y; n.v[2] = s.v0.z;
+            n.v[3] = s.v1.x; n.v[4] = s.v1.y; n.v[5] = s.v1.z;
+            n.v[6] = s.v2.x; n.v[7] = s.v2.y; n.v[8] = s.v2.z;
+            n.t[0] = s.t0.x; n.t[1] = s.t0.y; n.t[2] = s.t1.x; n.t[3] = s.t1.y; n.t[4] = s.t2.x; n.t[5] = s.t2.y;
+            n.tri = (uint32_t) (base + threadIdx.x);
+            n.pathkey = 0;
+            n.depth = 0;
+            n.area = area;
+            n.pad = 0;
+            nodes_out[slot.node] = n;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
+    }
+}
+
+// One breadth-first round of forEachSubdividedTriangle (voxelization.cpp:349-379).  The reference pops a LIFO
+// stack: after subdivide4 the centre piece (index 0) replaces the parent and pieces 1,2,3 are pushed, so the
+// processing order of the children is 3, 2, 1, 0 (depth first).  A leaf's position in that order is encoded
+// in `pathkey`: two bits (3 - childIndex) per level, most significant first, then a terminating 1 bit, so that
+// unsigned comparison of keys of one triangle equals the reference's processing order.
+__global__ __launch_bounds__(kBlock) void k_expand_nodes(const Node *__restrict__ nodes_in, uint32_t round, Counters *c,
+                                                         Leaf *leaves, Tile *tiles, BigLeaf *big, Node *nodes_out,
+                                                         Params p)
+{
+    __shared__ __align__(8) uint32_t s_wave[2 * (kBlock / 64)];
+    __shared__ uint32_t s_base[4];
+    __shared__ unsigned long long s_cand;
+    const uint32_t n_in = c->n_nodes[round] < p.cap_nodes ? c->n_nodes[round] : p.cap_nodes;
+    const uint32_t n_blocks = (n_in + kBlock - 1) / kBlock;
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint32_t i = blk * kBlock + threadIdx.x;
+        const bool live = i < n_in;
+        __syncthreads();
+        if (threadIdx.x == 0) s_cand = 0;
+        Sub ch[4];
+        LeafPlan pl[4];
+        uint32_t kind[4] = {0, 0, 0, 0};  // 0 drop, 1 leaf, 2 node
+        uint32_t tri = 0, pathkey = 0, depth = 0;
+        float area = 0;
+        Emit e{0, 0, 0, 0};
+        if (live) {
+            const Node n = nodes_in[i];
+            tri = n.tri;
+            pathkey = n.pathkey;
+            depth = n.depth;
+            area = n.area;
+            V3 v0{n.v[0], n.v[1], n.v[2]}, v1{n.v[3], n.v[4], n.v[5]}, v2{n.v[6], n.v[7], n.v[8]};
+            V2 t0{n.t[0], n.t[1]}, t1{n.t[2], n.t[3]}, t2{n.t[4], n.t[5]};
+            // subdivide4, triangle.hpp:134-143
+            V3 g0 = mix(v0, v1, 0.5f), g1 = mix(v1, v2, 0.5f), g2 = mix(v2, v0, 0.5f);
+            V2 x0 = mix(t0, t1, 0.5f), x1 = mix(t1, t2, 0.5f), x2 = mix(t2, t0, 0.5f);
+            ch[0] = Sub{g0, g1, g2, x0, x1, x2};
+            ch[1] = Sub{v0, g0, g2, t0, x0, x2};
+            ch[2] = Sub{v1, g1, g0, t1, x1, x0};
+            ch[3] = Sub{v2, g2, g1, t2, x2, x1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (misses_slab(ch[k], p)) continue;
+                if (voxel_volume(ch[k]) < kSubdivisionVolumeLimit) {
+                    pl[k] = plan_leaf(ch[k], p);
+                    if (pl[k].count >> 32) {
+                        atomicOr(&c->err_flags, kErrLeafTooLarge);
+                    }
+                    else if (pl[k].ntiles) {
+                        kind[k] = 1;
+                        e.n_leaf += 1;
+                        e.n_tile += pl[k].ntiles;
+                        e.n_big += pl[k].ntiles > kInlineTiles ? 1u : 0u;
+                    }
+                }
+                else if (depth + 1 >= 15) {
+                    atomicOr(&c->err_flags, kErrDepth);
+                }
+                else {
+                    kind[k] = 2;
+                    e.n_node += 1;
+                }
+            }
+        }
+        BlockSlots slot = reserve_slots(e, c, round + 1, s_wave, s_base);
+        if (live) {
+            unsigned long long cand = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // child digit at this level, then the terminator bit one position below it
+                const uint32_t shift = 30u - 2u * depth;
+                const uint32_t digit_key = pathkey | ((3u - (uint32_t) k) << shift);
+                if (kind[k] == 1) {
+                    const uint32_t key = digit_key | (1u << (shift - 1u));
+                    if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, ch[k], tri, key, area, pl[k]);
+                    write_tiles(tiles, big, slot.leaf, slot.tile, pl[k].ntiles, slot.big, p);
+                    cand += pl[k].count;
+                    slot.leaf += 1;
+                    slot.tile += pl[k].ntiles;
+                    slot.big += pl[k].ntiles > kInlineTiles ? 1u : 0u;
+                }
+                else if (kind[k] == 2) {
+                    if (slot.node < p.cap_nodes) {
+                        Node o;
+                        const Sub &s = ch[k];
+                        o.v[0] = s.v0.x; o.v[1] = s.v0.y; o.v[2] = s.v0.z;
+                        o.v[3] = s.v1.x; o.v[4] = s.v1.y; o.v[5] = s.v1.z;
+                        o.v[6] = s.v2.x; o.v[7] = s.v2.y; o.v[8] = s.v2.z;
+                        o.t[0] = s.t0.x; o.t[1] = s.t0.y; o.t[2] = s.t1.x; o.t[3] = s.t1.y; o.t[4] = s.t2.x; o.t[5] = s.t2.y;
+                        o.tri = tri;
+                        o.pathkey = digit_key;
+                        o.depth = depth + 1;
+                        o.area = area;
+                        o.pad = 0;
+                        nodes_out[slot.node] = o;
+                    }
+                    slot.node += 1;
+                }
+            }
+            if (cand) atomicAdd(&s_cand, cand);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
+    }
+}
+
+
+__global__ __launch_bounds__(kBlock) void k_expand_big(const BigLeaf *__restrict__ big, const Counters *c, Tile *tiles,
+                                                       Params p)
+{
+    const uint32_t n = c->n_big < p.cap_big ? c->n_big : p.cap_big;
+    for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+        const BigLeaf bl = big[b];
+        for (uint32_t k = threadIdx.x; k < bl.ntiles; k += kBlock)
+            if (bl.first_tile + k < p.cap_tiles) tiles[bl.first_tile + k] = Tile{bl.leaf, k * kTileSize};
+    }
+}

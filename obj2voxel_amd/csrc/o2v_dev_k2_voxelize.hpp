@@ -1,0 +1,568 @@
+// o2v_dev_k2_voxelize.hpp -- K2: candidate test and six-plane clip (k_voxelize<UV>).
+//
+// Part of the device code of o2v_device.hip, which includes this file inside its anonymous namespace (one
+// translation unit: the stages share records and launch parameters).  Not a stand-alone header.
+
+// ---- K2: voxelize -------------------------------------------------------------------------------------------
+
+template <bool UV>
+struct Piece {  // TexturedTriangle (triangle.hpp:113-144); the uv members are dead code when !UV
+    V3 a, b, c;
+    V2 ta, tb, tc;
+};
+
+// Classification of one piece against one axis plane: SplittingValues + the case switch of splitTriangle
+// (voxelization.cpp:110-153,190-232).  Packed so that it can be carried in one register between the cheap
+// classification pass and the expensive split pass of the clip loop.
+enum : uint32_t {
+    kClsModeMask = 3u,   // 0: whole triangle goes to one side, 1: one-planar split, 2: regular split
+    kClsSideLo = 4u,     // mode 0: the side is "lo"
+    kClsRotShift = 3u,   // bits 3..4: rotation index r (planar vertex for mode 1, isolated vertex for mode 2)
+    kClsFlagLo = 32u,    // mode 1: lo flag of vertex r+1;  mode 2: the isolated vertex is lo
+};
+
+__device__ __forceinline__ uint32_t classify_piece(float c0, float c1, float c2, float plane)
+{
+    // SplittingValues, voxelization.cpp:121-131
+    const bool p0 = abs_f(c0 - plane) < kEpsilon, p1 = abs_f(c1 - plane) < kEpsilon, p2 = abs_f(c2 - plane) < kEpsilon;
+    const bool l0 = c0 < plane, l1 = c1 < plane, l2 = c2 < plane;
+    const uint32_t lo_sum = (uint32_t) l0 + (uint32_t) l1 + (uint32_t) l2;
+    const uint32_t pl_sum = (uint32_t) p0 + (uint32_t) p1 + (uint32_t) p2;
+    if (lo_sum == 0) return 0u;
+    if (lo_sum == 3) return kClsSideLo;
+    if (pl_sum == 3) return 0u;  // parallel to the plane: pushed by bias (IS_LO_BIASED = false) = hi
+    if (pl_sum == 2) return (!p0 ? l0 : (!p1 ? l1 : l2)) ? kClsSideLo : 0u;
+    if (pl_sum == 1) {
+        const uint32_t r = p0 ? 0u : (p1 ? 1u : 2u);
+        const bool lq = r == 0 ? l1 : (r == 1 ? l2 : l0);
+        const bool lr = r == 0 ? l2 : (r == 1 ? l0 : l1);
+        if (lq == lr) return lq ? kClsSideLo : 0u;
+        return 1u | (r << kClsRotShift) | (lq ? kClsFlagLo : 0u);
+    }
+    const bool iso_lo = lo_sum == 1;
+    const uint32_t r = iso_lo ? (l0 ? 0u : (l1 ? 1u : 2u)) : (!l0 ? 0u : (!l1 ? 1u : 2u));
+    return 2u | (r << kClsRotShift) | (iso_lo ? kClsFlagLo : 0u);
+}
+
+// The geometric part of splitTriangle<DISCARD_LO|DISCARD_HI> for a piece whose classification says it is cut
+// (modes 1 and 2).  keep_lo selects DISCARD_HI.  Returns the number of kept pieces (1 or 2): `cur` becomes the
+// first kept piece in emission order, `sec` the second.  Vertex order inside emitted pieces is the reference's,
+// because later splits depend on it.
+template <bool UV>
+__device__ __forceinline__ uint32_t split_cut(Piece<UV> &cur, Piece<UV> &sec, uint32_t cls, uint32_t axis, float plane,
+                                              bool keep_lo)
+{
+    const uint32_t r = (cls >> kClsRotShift) & 3u;
+    const bool flag_lo = (cls & kClsFlagLo) != 0;
+    // rotate (a, b, c) left by r with two conditional cyclic shifts (18 selects instead of 54)
+    const bool s1 = r >= 1u, s2 = r == 2u;
+    const V3 P1 = s1 ? cur.b : cur.a, Q1 = s1 ? cur.c : cur.b, R1 = s1 ? cur.a : cur.c;
+    const V3 P = s2 ? Q1 : P1, Q = s2 ? R1 : Q1, R = s2 ? P1 : R1;
+    V2 tP{}, tQ{}, tR{};
+    if (UV) {
+        const V2 tP1 = s1 ? cur.tb : cur.ta, tQ1 = s1 ? cur.tc : cur.tb, tR1 = s1 ? cur.ta : cur.tc;
+        tP = s2 ? tQ1 : tP1;
+        tQ = s2 ? tR1 : tQ1;
+        tR = s2 ? tP1 : tR1;
+    }
+    const float cP = comp(P, axis), cQ = comp(Q, axis), cR = comp(R, axis);
+    const bool regular = (cls & kClsModeMask) == 2u;
+    // first intersection: regular case P->Q (voxelization.cpp:305-311), one-planar case Q->R (:262-266)
+    const V3 A0 = regular ? P : Q, A1 = regular ? Q : R;
+    const float cA0 = regular ? cP : cQ, cA1 = regular ? cQ : cR;
+    const float d0 = -(cA1 - cA0);
+    const float i0 = abs_f(d0) < kEpsilon ? 0.f : (cA0 - plane) / d0;
+    const V3 G0 = mix(A0, A1, i0);
+    V2 x0{};
+    if (UV) x0 = mix(regular ? tP : tQ, regular ? tQ : tR, i0);
+    if (!regular) {
+        // splitTriangle_onePlanarCase: {P,Q,G} goes to Q's side, {P,G,R} to the other
+        if (flag_lo == keep_lo) {
+            cur.a = P; cur.b = Q; cur.c = G0;
+            if (UV) { cur.ta = tP; cur.tb = tQ; cur.tc = x0; }
+        }
+        else {
+            cur.a = P; cur.b = G0; cur.c = R;
+            if (UV) { cur.ta = tP; cur.tb = x0; cur.tc = tR; }
+        }
+        return 1;
+    }
+    // splitTriangle_regularCase, voxelization.cpp:279-331: P isolated, second intersection P->R
+    const float d1 = -(cR - cP);
+    const float i1 = abs_f(d1) < kEpsilon ? 0.f : (cP - plane) / d1;
+    const V3 G1 = mix(P, R, i1);
+    V2 x1{};
+    if (UV) x1 = mix(tP, tR, i1);
+    if (flag_lo == keep_lo) {
+        cur.a = P; cur.b = G0; cur.c = G1;
+        if (UV) { cur.ta = tP; cur.tb = x0; cur.tc = x1; }
+        return 1;
+    }
+    cur.a = G0; cur.b = Q; cur.c = R;
+    sec.a = G0; sec.b = G1; sec.c = R;
+    if (UV) {
+        cur.ta = x0; cur.tb = tQ; cur.tc = tR;
+        sec.ta = x0; sec.tb = x1; sec.tc = tR;
+    }
+    return 2;
+}
+
+template <bool UV>
+__device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area, float &w, float &u, float &v)
+{
+    // result = mix(result, {area(inputTriangle), piece.textureCenter()}), voxelization.cpp:414-420, util.hpp:160-165
+    const float ws = w + area;
+    if (UV) {
+        const float uc = ((pc.ta.x + pc.tb.x) + pc.tc.x) / 3;
+        const float vc = ((pc.ta.y + pc.tb.y) + pc.tc.y) / 3;
+        u = (w * u + area * uc) / ws;
+        v = (w * v + area * vc) / ws;
+    }
+    w = ws;
+}
+
+// Pending sibling pieces of the depth-first clip walk, one slot per level 1..5, held in registers: every access
+// uses a compile-time slot index (selected by a switch), so the array never leaves the VGPR file.
+template <bool UV>
+struct PieceStack {
+    Piece<UV> s0, s1, s2, s3, s4;
+};
+
+// Value-level selects (v_cndmask), not control flow: a branchy form gets folded by the compiler into a select of
+// addresses, which forces the stack into scratch memory.
+template <bool UV>
+__device__ __forceinline__ Piece<UV> sel_piece(bool take_x, const Piece<UV> &x, const Piece<UV> &y)
+{
+    Piece<UV> r;
+    r.a = {take_x ? x.a.x : y.a.x, take_x ? x.a.y : y.a.y, take_x ? x.a.z : y.a.z};
+    r.b = {take_x ? x.b.x : y.b.x, take_x ? x.b.y : y.b.y, take_x ? x.b.z : y.b.z};
+    r.c = {take_x ? x.c.x : y.c.x, take_x ? x.c.y : y.c.y, take_x ? x.c.z : y.c.z};
+    if (UV) {
+        r.ta = {take_x ? x.ta.x : y.ta.x, take_x ? x.ta.y : y.ta.y};
+        r.tb = {take_x ? x.tb.x : y.tb.x, take_x ? x.tb.y : y.tb.y};
+        r.tc = {take_x ? x.tc.x : y.tc.x, take_x ? x.tc.y : y.tc.y};
+    }
+    return r;
+}
+template <bool UV>
+__device__ __forceinline__ void stack_store(PieceStack<UV> &st, uint32_t slot, const Piece<UV> &pc)
+{
+    st.s0 = sel_piece<UV>(slot == 0, pc, st.s0);
+    st.s1 = sel_piece<UV>(slot == 1, pc, st.s1);
+    st.s2 = sel_piece<UV>(slot == 2, pc, st.s2);
+    st.s3 = sel_piece<UV>(slot == 3, pc, st.s3);
+    st.s4 = sel_piece<UV>(slot == 4, pc, st.s4);
+}
+template <bool UV>
+__device__ __forceinline__ void stack_load(const PieceStack<UV> &st, uint32_t slot, Piece<UV> &pc)
+{
+    Piece<UV> r = st.s4;
+    r = sel_piece<UV>(slot == 3, st.s3, r);
+    r = sel_piece<UV>(slot == 2, st.s2, r);
+    r = sel_piece<UV>(slot == 1, st.s1, r);
+    r = sel_piece<UV>(slot == 0, st.s0, r);
+    pc = r;
+}
+
+// Conservative triangle / voxel overlap test (separating axes: the triangle's plane and the nine edge x axis
+// directions; the three box axes are implied by the AABB walk).  The box is inflated by kSatMargin, far more than
+// the float32 rounding of the clip (<= a few ulp of the coordinate, 5e-4 at 4096) and than its planarity epsilon
+// (2^-16), so every voxel the exact clip can mark is kept: this only removes work, never results.  The test's own
+// rounding is covered too: everything is evaluated in the voxel-centred frame, the plane axis uses the unnormalised
+// normal e0 x e1 with an explicit error bound (for a sliver, whose normal direction is numerically meaningless, the
+// bound exceeds the radius and the plane axis simply never separates), and all comparisons are written so that a
+// NaN rejects nothing.
+constexpr float kSatMargin = 0.02f;
+
+__device__ __forceinline__ bool sat_axis_separates(float p0, float p1, float rad)
+{
+    const float lo = p0 < p1 ? p0 : p1, hi = p0 < p1 ? p1 : p0;
+    return lo > rad || hi < -rad;
+}
+
+__device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, float cx, float cy, float cz)
+{
+    const float h = 0.5f + kSatMargin;
+    const V3 c{cx, cy, cz};
+    const V3 a = v0 - c, b = v1 - c, d = v2 - c;
+    const V3 e0 = b - a, e1 = d - b, e2 = a - d;
+    {
+        // plane axis: |n . a| <= h * |n|_1, n = e0 x e1.  Each component of n carries an absolute rounding error of a
+        // few ulp of |e0|_1 |e1|_1 (cancellation), which the bound below over-estimates by more than 10x.
+        const V3 n = cross(e0, e1);
+        const float dist = n.x * a.x + n.y * a.y + n.z * a.z;
+        const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z));
+        const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
+        const float la = abs_f(a.x) + abs_f(a.y) + abs_f(a.z);
+        const float err = 1e-5f * l0 * l1 * (la + 1.0f);
+        if (abs_f(dist) > rad + err) return false;
+    }
+    // axis = X x e: projections use only the vertices not on edge e (the edge's own vertices project equally)
+#define O2V_SAT_EDGE(E, U, W)                                                                               \
+    if (sat_axis_separates(E.z * U.y - E.y * U.z, E.z * W.y - E.y * W.z, h * (abs_f(E.z) + abs_f(E.y)))) return false; \
+    if (sat_axis_separates(E.x * U.z - E.z * U.x, E.x * W.z - E.z * W.x, h * (abs_f(E.x) + abs_f(E.z)))) return false; \
+    if (sat_axis_separates(E.y * U.x - E.x * U.y, E.y * W.x - E.x * W.y, h * (abs_f(E.y) + abs_f(E.x)))) return false;
+    O2V_SAT_EDGE(e0, a, d)
+    O2V_SAT_EDGE(e1, b, a)
+    O2V_SAT_EDGE(e2, d, b)
+#undef O2V_SAT_EDGE
+    return true;
+}
+
+constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
+constexpr uint32_t kMaxSurvivors = 8192;      // survivor queue entries (= candidate voxels) per sub-batch
+
+// K2.  Persistent workgroups pull batches of tiles.  Per batch:
+//   phase 1  every candidate voxel of the tiles: decode, plane-distance cull (voxelization.cpp:451-458), SAT
+//            pre-test; survivors are queued in LDS (tile slot + index in tile)
+//   phase 2  persistent lanes pop survivors and run computeTrianglesUvInVoxel (voxelization.cpp:383-424) as a
+//            depth-first walk of the split tree: the reference clips level by level with two 64-entry buffers;
+//            visiting the first emitted piece first reproduces its buffer order, so the running mean of
+//            :414-420 accumulates in the identical sequence.  Under DISCARD every split keeps <= 2 pieces, so at
+//            most one sibling per level 1..5 is pending (register stack).  Per iteration a lane skips every
+//            plane its piece passes whole (AABB check), classifies it against the first plane it does not, and
+//            cuts if needed; lanes that run out of pieces pop the next survivor, so the wavefront stays full.
+// Register budget: 4 waves per SIMD without uv arithmetic, 3 with it (the allocator spills a handful of cold values;
+// measured faster than running one wave fewer on the bench mesh and on the large textured workloads).
+template <bool UV>
+__global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+                                                     Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
+                                                     Params p)
+{
+    __shared__ uint32_t s_leaf[kTilesPerBatch * kLeafStride];
+    __shared__ uint32_t s_tleaf[kTilesPerBatch];
+    __shared__ uint32_t s_tstart[kTilesPerBatch];
+    __shared__ uint32_t s_tcount[kTilesPerBatch];
+    __shared__ uint32_t s_tprefix[kTilesPerBatch + 2];
+    __shared__ uint32_t s_scan[kBlock / 64];
+    __shared__ uint32_t s_tend;
+    __shared__ uint32_t s_chunk_tile[kMaxSurvivors / 64 + 1];
+    __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
+    __shared__ uint16_t s_surv[kMaxSurvivors];
+    __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits;
+
+    if (expand_overflowed(c, p)) return;
+    const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
+    // Batch size: about six batches per workgroup, between one tile per wavefront and what the LDS staging holds.  Few
+    // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
+    // of the machine busy); many small ones pay the per-batch staging and barriers too often.  Measured on seven
+    // workload shapes.
+    uint32_t tiles_per_batch = (n_tiles + gridDim.x * 6u - 1u) / (gridDim.x * 6u);
+    tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
+                      : (tiles_per_batch > kTilesPerBatch ? kTilesPerBatch : tiles_per_batch);
+    const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
+    if (threadIdx.x == 0) s_hits = 0;
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_batch = atomicAdd(&c->batch_cursor, 1u);
+        __syncthreads();
+        const uint32_t batch = s_batch;
+        if (batch >= n_batches) break;
+        const uint32_t first = batch * tiles_per_batch;
+        const uint32_t nt = n_tiles - first < tiles_per_batch ? n_tiles - first : tiles_per_batch;
+        if (threadIdx.x < nt) {
+            const Tile t = tiles[first + threadIdx.x];
+            s_tleaf[threadIdx.x] = t.leaf;
+            s_tstart[threadIdx.x] = t.start;
+        }
+        __syncthreads();
+        // stage the leaves of this batch in LDS
+        for (uint32_t i = threadIdx.x; i < nt * 24u; i += kBlock) {
+            const uint32_t k = i / 24u, j = i - k * 24u;
+            s_leaf[k * kLeafStride + j] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
+        }
+        __syncthreads();
+        uint32_t my_count = 0;
+        if (threadIdx.x < nt) {
+            const uint32_t *lf = &s_leaf[threadIdx.x * kLeafStride];
+            const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
+            const uint32_t rem = dx * dy * dz - s_tstart[threadIdx.x];
+            my_count = rem < kTileSize ? rem : kTileSize;
+            s_tcount[threadIdx.x] = my_count;
+            s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
+            s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
+        }
+        {
+            // exclusive prefix of the tile sizes: s_tprefix[k] = candidates before tile k, s_tprefix[nt] = total
+            uint32_t total;
+            const uint32_t ex = block_exscan(my_count, s_scan, total);
+            if (threadIdx.x <= nt) s_tprefix[threadIdx.x] = threadIdx.x < nt ? ex : total;
+        }
+
+        // sub-batches of whole tiles with at most kMaxSurvivors candidates
+        uint32_t t_begin = 0;
+        while (t_begin < nt) {
+            __syncthreads();
+            const uint32_t base_cand = s_tprefix[t_begin];
+            // the last tile whose end still fits decides t_end (found by the thread that owns it)
+            if (threadIdx.x >= t_begin && threadIdx.x < nt) {
+                const bool fits = s_tprefix[threadIdx.x + 1] - base_cand <= kMaxSurvivors;
+                const bool next_fits = threadIdx.x + 1 < nt && s_tprefix[threadIdx.x + 2] - base_cand <= kMaxSurvivors;
+                if (fits && !next_fits) s_tend = threadIdx.x + 1;
+            }
+            if (threadIdx.x == 0) {
+                s_nsurv = 0;
+                s_next = 0;
+            }
+            __syncthreads();
+            const uint32_t t_end = s_tend;
+
+            // ---- phase 1: the sub-batch's candidates flattened over the lanes ------------------------------
+            // Candidate g (in sub-batch order) belongs to the tile k with s_tprefix[k] <= g < s_tprefix[k + 1].  A small
+            // table gives every 64-candidate chunk the tile its first candidate falls in; a lane then walks forward a
+            // few tiles at most, so the 64 lanes stay busy however small the tiles are.
+            const uint32_t n_cand = s_tprefix[t_end] - base_cand;
+            if (threadIdx.x >= t_begin && threadIdx.x < t_end) {
+                const uint32_t lo = s_tprefix[threadIdx.x] - base_cand, hi = s_tprefix[threadIdx.x + 1] - base_cand;
+                if (hi > lo)
+                    for (uint32_t ch = (lo + 63u) / 64u; ch * 64u < hi; ++ch) s_chunk_tile[ch] = threadIdx.x;
+            }
+            __syncthreads();
+            for (uint32_t g0 = wave * 64u; g0 < n_cand; g0 += kBlock) {
+                const uint32_t g = g0 + lane;
+                bool keep = false;
+                uint32_t k = s_chunk_tile[g0 / 64u], i = 0;
+                if (g < n_cand) {
+                    while (s_tprefix[k + 1] - base_cand <= g) ++k;
+                    i = g - (s_tprefix[k] - base_cand);
+                    const uint32_t *lf = &s_leaf[k * kLeafStride];
+                    const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
+                    const uint32_t j = s_tstart[k] + i;
+                    uint32_t row, lx, lz, ly;
+                    if (j < (1u << 24)) {
+                        // exact quotient from a float estimate (j < 2^24, divisor < 2^16): off by at most one
+                        row = (uint32_t) ((float) j * s_inv_dx[k]);
+                        int32_t rx = (int32_t) (j - row * dx);
+                        if (rx < 0) { row -= 1; rx += (int32_t) dx; }
+                        else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
+                        lx = (uint32_t) rx;
+                        lz = (uint32_t) ((float) row * s_inv_dy[k]);
+                        int32_t ry = (int32_t) (row - lz * dy);
+                        if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
+                        else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
+                        ly = (uint32_t) ry;
+                    }
+                    else {
+                        row = j / dx;
+                        lx = j - row * dx;
+                        lz = row / dy;
+                        ly = row - lz * dy;
+                    }
+                    const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                    const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                    const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                    const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
+                    const float cx = (float) ((lf[20] & 0xffffu) + lx) + 0.5f, cy = (float) ((lf[20] >> 16) + ly) + 0.5f,
+                                cz = (float) ((lf[21] & 0xffffu) + lz) + 0.5f;
+                    // plane distance cull, voxelization.cpp:451-458
+                    const float sd = dot(nrm, V3{cx, cy, cz} - v0);
+                    keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, cx, cy, cz);
+                }
+                const unsigned long long m = __ballot(keep);
+                if (m) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_nsurv, (uint32_t) __popcll(m));
+                    base = __shfl(base, 0, 64);
+                    if (keep) s_surv[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) (((k - t_begin) << 8) | i);
+                }
+            }
+            __syncthreads();
+            const uint32_t n_surv = s_nsurv;
+
+            // ---- phase 2: persistent lanes ------------------------------------------------------------------
+            Piece<UV> cur{}, sec{};
+            PieceStack<UV> stack{};
+            uint32_t level = 0, pending = 0, my_k = 0;
+            bool active = false, has_job = false;
+            float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
+            float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
+            uint32_t px = 0, py = 0, pz = 0;
+            bool queue_empty = n_surv == 0;
+            // parked result of this lane's last finished hit
+            float d_w = 0.f, d_u = 0.f, d_v = 0.f;
+            uint32_t d_xy = 0, d_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
+            bool d_valid = false;
+            auto flush_results = [&]() {
+                const unsigned long long mask = __ballot(d_valid);
+                if (!mask) return;
+                const uint32_t cnt = (uint32_t) __popcll(mask);
+                const uint32_t leader = (uint32_t) __ffsll((long long) mask) - 1u;
+                if (chunk_used + cnt > kHitChunk) {
+                    // abandon the rest of the chunk (marked as holes for the scatter pass) and reserve a new one
+                    const uint32_t hole = chunk_base + chunk_used + lane;
+                    if (chunk_used + lane < kHitChunk && hole < p.cap_hits) pool[hole].brick = kHoleBrick;
+                    if (chunk_used + 64u + lane < kHitChunk && hole + 64u < p.cap_hits) pool[hole + 64u].brick = kHoleBrick;
+                    if (chunk_used + 128u + lane < kHitChunk && hole + 128u < p.cap_hits) pool[hole + 128u].brick = kHoleBrick;
+                    if (chunk_used + 192u + lane < kHitChunk && hole + 192u < p.cap_hits) pool[hole + 192u].brick = kHoleBrick;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
+                    chunk_base = __shfl(base, (int) leader, 64);
+                    chunk_used = 0;
+                }
+                const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+                chunk_used += cnt;
+                if (d_valid && mine < p.cap_hits) {
+                    const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
+                    const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
+                    const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
+                    uint32_t brick;
+                    const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                    const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
+                    // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
+                    const uint32_t rank = atomicAdd(&grid[cell], 1u);
+                    if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
+                    brick_dirty[brick] = 1;  // benign race: every writer stores the same value
+                    pool[mine] = HitRec{brick, (((uint32_t) cell & 255u) << 24) | (rank & (kMaxRank - 1u)),
+                                        (sub << 29) | lf[18], lf[19], d_w, d_u, d_v, 0u};
+                }
+                if (lane == leader) atomicAdd(&s_hits, cnt);
+                d_valid = false;
+            };
+            for (;;) {
+                // pop a pending sibling, or fetch the next survivor
+                if (!active) {
+                    if (pending) {
+                        level = 31u - (uint32_t) __clz((int) pending);
+                        pending ^= 1u << level;
+                        stack_load<UV>(stack, level - 1u, cur);
+                        active = true;
+                    }
+                    else if (!queue_empty) {
+                        const uint32_t q = atomicAdd(&s_next, 1u);
+                        if (q < n_surv) {
+                            const uint32_t e = s_surv[q];
+                            my_k = t_begin + (e >> 8);
+                            const uint32_t *lf = &s_leaf[my_k * kLeafStride];
+                            const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
+                            const uint32_t j = s_tstart[my_k] + (e & 255u);
+                            uint32_t row, lx, ly, lz;
+                            if (j < (1u << 24)) {
+                                row = (uint32_t) ((float) j * s_inv_dx[my_k]);
+                                int32_t rx = (int32_t) (j - row * dx);
+                                if (rx < 0) { row -= 1; rx += (int32_t) dx; }
+                                else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
+                                lx = (uint32_t) rx;
+                                lz = (uint32_t) ((float) row * s_inv_dy[my_k]);
+                                int32_t ry = (int32_t) (row - lz * dy);
+                                if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
+                                else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
+                                ly = (uint32_t) ry;
+                            }
+                            else {
+                                row = j / dx;
+                                lx = j - row * dx;
+                                lz = row / dy;
+                                ly = row - lz * dy;
+                            }
+                            px = (lf[20] & 0xffffu) + lx;
+                            py = (lf[20] >> 16) + ly;
+                            pz = (lf[21] & 0xffffu) + lz;
+                            fx = (float) px;
+                            fy = (float) py;
+                            fz = (float) pz;
+                            cur.a = {__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                            cur.b = {__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                            cur.c = {__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                            if (UV) {
+                                cur.ta = {__uint_as_float(lf[12]), __uint_as_float(lf[13])};
+                                cur.tb = {__uint_as_float(lf[14]), __uint_as_float(lf[15])};
+                                cur.tc = {__uint_as_float(lf[16]), __uint_as_float(lf[17])};
+                            }
+                            area = __uint_as_float(lf[23]);
+                            level = 0;
+                            w = 0.f;
+                            u = 0.f;
+                            v = 0.f;
+                            active = true;
+                            has_job = true;
+                        }
+                        else {
+                            queue_empty = true;
+                        }
+                    }
+                }
+                if (active) {
+                    // Skip ahead: a piece whose vertices all satisfy v >= plane (lower planes) or v < plane (upper
+                    // planes) is the loSum == 0 / loSum == 3 case of splitTriangle (voxelization.cpp:194-205) and
+                    // passes whole, so every such plane from `level` on is skipped at once.
+                    const V3 mn = tri_min(cur.a, cur.b, cur.c), mx = tri_max(cur.a, cur.b, cur.c);
+                    uint32_t fail = 0;
+                    fail |= (mn.x >= fx) ? 0u : 1u;
+                    fail |= (mn.y >= fy) ? 0u : 2u;
+                    fail |= (mn.z >= fz) ? 0u : 4u;
+                    fail |= (mx.x < fx + 1.0f) ? 0u : 8u;
+                    fail |= (mx.y < fy + 1.0f) ? 0u : 16u;
+                    fail |= (mx.z < fz + 1.0f) ? 0u : 32u;
+                    fail &= ~((1u << level) - 1u);
+                    if (fail == 0) {
+                        accumulate_piece<UV>(cur, area, w, u, v);  // inside all remaining planes
+                        active = false;
+                    }
+                    else {
+                        level = (uint32_t) __ffs((int) fail) - 1u;
+                        const bool keep_lo = level >= 3u;
+                        const uint32_t axis = keep_lo ? level - 3u : level;
+                        const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
+                        const uint32_t cls = classify_piece(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane);
+                        if ((cls & kClsModeMask) == 0u) {
+                            // whole triangle to one side (all-lo/all-hi or one of the planar special cases)
+                            if (((cls & kClsSideLo) != 0) == keep_lo) {
+                                level += 1u;
+                                if (level == 6u) {
+                                    accumulate_piece<UV>(cur, area, w, u, v);
+                                    active = false;
+                                }
+                            }
+                            else {
+                                active = false;  // discarded
+                            }
+                        }
+                        else {
+                            const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo);
+                            if (level == 5u) {
+                                accumulate_piece<UV>(cur, area, w, u, v);
+                                if (n == 2) accumulate_piece<UV>(sec, area, w, u, v);
+                                active = false;
+                            }
+                            else {
+                                if (n == 2) {
+                                    stack_store<UV>(stack, level, sec);  // slot of level + 1
+                                    pending |= 1u << (level + 1u);
+                                }
+                                level += 1u;
+                            }
+                        }
+                    }
+                }
+                // A job is finished when nothing of it is in flight.  `not eqExactly(uv.weight, 0.f)` -> insertWeighted
+                // (voxelization.cpp:466-468): the hit is appended to the pool and counted in its cell; the ordered
+                // combine happens in the resolve kernels.  A finished hit is parked in the lane's result registers and
+                // the append section runs only when half the wavefront holds one (or a lane needs its slot again, or
+                // the wavefront leaves), not in every iteration.
+                const bool finished = has_job && !active && pending == 0;
+                const bool fin_hit = finished && w != 0.f;
+                if (finished) has_job = false;
+                if (__ballot(fin_hit && d_valid)) flush_results();
+                if (fin_hit) {
+                    d_w = w; d_u = u; d_v = v;
+                    d_xy = px | (py << 16);
+                    d_zk = pz | (my_k << 16);
+                    d_valid = true;
+                }
+                const bool leaving = !__ballot(active || pending != 0 || !queue_empty);
+                const unsigned long long dm = __ballot(d_valid);
+                if (dm && ((uint32_t) __popcll(dm) >= 32u || leaving)) flush_results();
+                if (leaving) break;
+            }
+            t_begin = t_end;
+        }
+    }
+    // the unused tail of this wavefront's last chunk holds no hits
+    for (uint32_t k = chunk_used + lane; k < kHitChunk; k += 64)
+        if (chunk_used != kHitChunk && chunk_base + k < p.cap_hits) pool[chunk_base + k].brick = kHoleBrick;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hits) atomicAdd(&c->n_hits, (unsigned long long) s_hits);
+}

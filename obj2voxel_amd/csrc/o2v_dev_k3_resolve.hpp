@@ -1,0 +1,582 @@
+// o2v_dev_k3_resolve.hpp -- K3: ordered per-cell replay (k_resolve and the cooperative tiers).
+//
+// Part of the device code of o2v_device.hip, which includes this file inside its anonymous namespace (one
+// translation unit: the stages share records and launch parameters).  Not a stand-alone header.
+
+// ---- K3: resolve ---------------------------------------------------------------------------------------------
+
+struct Materials {
+    const uint32_t *types;   // nullable: all MATERIALLESS
+    const float *colors;     // nullable
+    const int32_t *texids;   // nullable: all 0
+    const DevTexture *textures;
+    uint32_t n_textures;
+};
+
+// colorAt_f, triangle.hpp:181-194 (+ texture get, triangle.hpp:161-166; getPixel semantics: see DESIGN.md)
+__device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float u, float v, float &r, float &g, float &b)
+{
+    const uint32_t type = m.types ? m.types[tri] : (uint32_t) kTriMaterialless;
+    if (type == kTriMaterialless) {
+        r = g = b = 1.f;
+    }
+    else if (type == kTriUntextured) {
+        r = m.colors ? m.colors[(size_t) tri * 3 + 0] : 0.f;
+        g = m.colors ? m.colors[(size_t) tri * 3 + 1] : 0.f;
+        b = m.colors ? m.colors[(size_t) tri * 3 + 2] : 0.f;
+    }
+    else if (type == kTriTextured && m.n_textures) {
+        uint32_t id = m.texids ? (uint32_t) m.texids[tri] : 0u;
+        if (id >= m.n_textures) id = 0;
+        const DevTexture tx = m.textures[id];
+        float tu = u, tv = 1 - v;
+        if (tx.wrap) {
+            tu = tu - floor_f(tu);
+            tv = tv - floor_f(tv);
+        }
+        else {
+            tu = tu < 0.f ? 0.f : (tu > 1.f ? 1.f : tu);
+            tv = tv < 0.f ? 0.f : (tv > 1.f ? 1.f : tv);
+        }
+        uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
+        if (px >= tx.width) px = tx.width - 1;
+        if (py >= tx.height) py = tx.height - 1;
+        const uint8_t *q = tx.pixels + ((size_t) py * tx.width + px) * tx.channels;
+        const uint32_t o = tx.channels == 4 ? 1u : 0u;
+        r = (float) q[o] / 255.f;
+        g = (float) q[o + 1] / 255.f;
+        b = (float) q[o + 2] / 255.f;
+    }
+    else {
+        r = 1.f;
+        g = 0.f;
+        b = 1.f;
+    }
+}
+
+// ---- ordered replay of one cell's hits --------------------------------------------------------------------------
+// The hits of a cell arrive in arbitrary order; the reference's result is a sequential fold, so they are
+// replayed in the reference's order, i.e. ascending in the key (sub-voxel, triangle index, leaf order):
+//   leaves of one triangle   -> insertWeighted<BLEND>(uvBuffer, ...)  voxelization.cpp:466-468 (new, existing)
+//   triangles, ascending     -> moveUvBufferIntoVoxels                voxelization.cpp:513-526 (new, existing)
+//   sub-voxels, ascending    -> documented downscale semantics        voxelization.hpp:82-85
+struct CellFold {
+    bool have_tri = false, have_sub = false, have_cell = false;
+    uint32_t cur_group = 0;
+    WUv tri_acc{0, 0, 0};
+    WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
+
+    __device__ __forceinline__ void close_tri(const Materials &m, uint32_t blend)
+    {
+        float cr, cg, cb;
+        color_at(m, cur_group & 0x1fffffffu, tri_acc.u, tri_acc.v, cr, cg, cb);
+        const WCol fresh{tri_acc.w, cr, cg, cb};
+        sub_acc = have_sub ? wcombine(blend, fresh, sub_acc) : fresh;
+        have_sub = true;
+        have_tri = false;
+    }
+    __device__ __forceinline__ void close_sub(uint32_t blend)
+    {
+        cell_acc = have_cell ? wcombine(blend, sub_acc, cell_acc) : sub_acc;
+        have_cell = true;
+        have_sub = false;
+    }
+    // hits must be added in ascending key order
+    __device__ __forceinline__ void add(const Materials &m, uint32_t blend, uint32_t keyhi, float w, float u, float v)
+    {
+        if (have_tri && keyhi != cur_group) close_tri(m, blend);
+        if (have_sub && (keyhi >> 29) != (cur_group >> 29)) close_sub(blend);
+        const WUv hit{w, u, v};
+        tri_acc = have_tri ? wmix(hit, tri_acc) : hit;
+        have_tri = true;
+        cur_group = keyhi;
+    }
+    __device__ __forceinline__ uint32_t finish(const Materials &m, uint32_t blend)
+    {
+        if (have_tri) close_tri(m, blend);
+        if (have_sub) close_sub(blend);
+        return pack_argb(cell_acc.r, cell_acc.g, cell_acc.b);
+    }
+};
+
+__device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const Params &p)
+{
+    const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+    const uint32_t brick = (uint32_t) (cell >> 8), local = (uint32_t) cell & 255u;
+    const uint32_t row = brick / p.NBx;
+    const uint32_t bx = brick - row * p.NBx;
+    const uint32_t bz = row / p.NBy;
+    const uint32_t by = row - bz * p.NBy;
+    const uint32_t x = bx * kBrickX + (local & 15u), y = by * kBrickY + ((local >> 4) & 3u), z = bz * kBrickZ + (local >> 6);
+    return make_uint4(x, y, z + p.zo0, argb);
+}
+
+
+// Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
+// from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
+template <uint32_t STRIDE>
+__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn,
+                                                    const Counters *c, Materials m, uint4 *out, Params p)
+{
+    constexpr bool kUv = STRIDE == 6;  // 16-byte records carry no uv: the columns shrink to 24 KiB, 6 workgroups per CU
+    __shared__ uint64_t s_key[kShortList][kBlock];
+    __shared__ float s_w[kShortList][kBlock], s_u[kUv ? kShortList : 1][kBlock], s_v[kUv ? kShortList : 1][kBlock];
+    const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads below stay branch-free
+    if (pass_overflowed(c, p)) return;
+    const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const Occ o = occ[i];
+        if (o.count > kShortList) continue;  // filed for a cooperative tier by k_scan_bricks
+        // all loads are issued before anything is consumed (independent round trips overlap), then the records are
+        // insertion-sorted into this lane's private LDS column and folded by a rolled loop
+        SortedRec r[kShortList];
+#pragma unroll
+        for (uint32_t k = 0; k < kShortList; ++k) r[k] = sorted.load(o.offset + (k < o.count ? k : 0u));
+#pragma unroll
+        for (uint32_t k = 0; k < kShortList; ++k) {
+            if (k < o.count) {
+                const uint64_t key = ((uint64_t) r[k].keyhi << 32) | r[k].keylo;
+                uint32_t j = k;
+                while (j > 0 && s_key[j - 1][threadIdx.x] > key) {
+                    s_key[j][threadIdx.x] = s_key[j - 1][threadIdx.x];
+                    s_w[j][threadIdx.x] = s_w[j - 1][threadIdx.x];
+                    if (kUv) {
+                        s_u[j][threadIdx.x] = s_u[j - 1][threadIdx.x];
+                        s_v[j][threadIdx.x] = s_v[j - 1][threadIdx.x];
+                    }
+                    --j;
+                }
+                s_key[j][threadIdx.x] = key;
+                s_w[j][threadIdx.x] = r[k].w;
+                if (kUv) {
+                    s_u[j][threadIdx.x] = r[k].u;
+                    s_v[j][threadIdx.x] = r[k].v;
+                }
+            }
+        }
+        CellFold f;
+        for (uint32_t t = 0; t < o.count; ++t)
+            f.add(m, p.blend, (uint32_t) (s_key[t][threadIdx.x] >> 32), s_w[t][threadIdx.x],
+                  kUv ? s_u[t][threadIdx.x] : 0.f, kUv ? s_v[t][threadIdx.x] : 0.f);
+        out[i] = cell_record(o, f.finish(m, p.blend), p);
+    }
+}
+
+// Tier 2: cells with 9..64 hits, W = 16, 32 or 64 lanes per cell (64 / W cells per wavefront).  Every lane loads one
+// record; the (key, position) pairs are bitonic-sorted across the W lanes with cross-lane moves only (no LDS, no
+// barrier); the payload is gathered to its sorted lane and the cell is folded in order, every lane of the group
+// running the same fold on broadcast values.
+template <uint32_t W>
+__global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                         const Counters *c, const Occ *__restrict__ occ,
+                                                         SortedView sorted, Materials m, uint4 *out, uint32_t list_cap,
+                                                         Params p)
+{
+    constexpr uint32_t kPerWave = 64u / W;
+    if (pass_overflowed(c, p)) return;
+    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane / W, sl = lane % W, base_lane = sub * W;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64u);
+    for (uint32_t item0 = wave * kPerWave; item0 < total; item0 += n_waves * kPerWave) {  // wave-uniform
+        const uint32_t item = item0 + sub;
+        const bool valid = item < total;
+        uint32_t i = 0;
+        Occ o{};
+        if (valid) {
+            i = list[item];
+            o = occ[i];
+        }
+        const uint32_t n = valid ? (o.count < W ? o.count : W) : 0u;
+        uint64_t key = ~0ull;
+        uint32_t hi = 0, idx = sl;
+        float w = 0.f, u = 0.f, v = 0.f;
+        if (sl < n) {
+            const SortedRec r = sorted.load(o.offset + sl);
+            key = ((uint64_t) r.keyhi << 32) | r.keylo;
+            hi = r.keyhi;
+            w = r.w;
+            u = r.u;
+            v = r.v;
+        }
+#pragma unroll
+        for (uint32_t k = 2; k <= W; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint64_t okey = __shfl_xor(key, (int) j, 64);
+                const uint32_t oidx = __shfl_xor(idx, (int) j, 64);
+                const bool keep_min = ((sl & k) == 0) == ((sl & j) == 0);
+                if (keep_min ? okey < key : okey > key) {
+                    key = okey;
+                    idx = oidx;
+                }
+            }
+        }
+        const int src = (int) (base_lane + idx);
+        hi = __shfl(hi, src, 64);
+        w = __shfl(w, src, 64);
+        u = __shfl(u, src, 64);
+        v = __shfl(v, src, 64);
+        CellFold f;
+        for (uint32_t t = 0; t < W; ++t) {
+            if (!__any(t < n)) break;
+            const int from = (int) (base_lane + t);
+            const uint32_t hh = __shfl(hi, from, 64);
+            const float ww = __shfl(w, from, 64), uu = __shfl(u, from, 64), vv = __shfl(v, from, 64);
+            if (t < n) f.add(m, p.blend, hh, ww, uu, vv);
+        }
+        if (n != 0 && sl == 0) out[i] = cell_record(o, f.finish(m, p.blend), p);
+    }
+}
+
+template <typename KeyPtr, typename IdxPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_pow2, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < n_pow2; t += nthreads) {
+                const uint32_t partner = t ^ j;
+                if (partner > t) {
+                    const bool up = (t & k) == 0;
+                    const uint64_t a = key[t], b = key[partner];
+                    if ((a > b) == up) {
+                        key[t] = b;
+                        key[partner] = a;
+                        const uint32_t ia = idx[t];
+                        idx[t] = idx[partner];
+                        idx[partner] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Tiers 2 and 3: THREADS lanes cooperate on one cell (a wavefront for up to 256 hits, a workgroup for up to 2048).
+// The cell's records are contiguous: keys are loaded coalesced, (key, idx) pairs are bitonic-sorted in LDS, the
+// payload is gathered in sorted order, and lane 0 replays the fold (which is inherently sequential: the float
+// combine is not associative).
+template <uint32_t THREADS, uint32_t CAP>
+__global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                            uint32_t *cursor, const Counters *c,
+                                                            const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                            uint4 *out, uint32_t list_cap, Params p)
+{
+    if (pass_overflowed(c, p)) return;
+    __shared__ uint64_t s_key[CAP];
+    __shared__ uint32_t s_idx[CAP];
+    __shared__ uint32_t s_hi[CAP];
+    __shared__ float s_w[CAP], s_u[CAP], s_v[CAP];
+    __shared__ uint32_t s_item;
+    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(cursor, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count < CAP ? o.count : CAP;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += THREADS) {
+            if (t < n) {
+                const SortedRec r = sorted.load(o.offset + t);
+                s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                s_idx[t] = t;
+            }
+            else {
+                s_key[t] = ~0ull;
+                s_idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, THREADS);
+        for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+            const SortedRec r = sorted.load(o.offset + s_idx[t]);
+            s_hi[t] = r.keyhi;
+            s_w[t] = r.w;
+            s_u[t] = r.u;
+            s_v[t] = r.v;
+        }
+        __syncthreads();
+        if (p.blend) {
+            // BLEND: the weighted mean is folded in the reference's order (float mix is not associative), but only the
+            // chain over the triangles is sequential: every triangle's own hits (its leaves in this cell) and its colour
+            // lookup are independent of the other triangles, so the lane at a group's first record folds the group and
+            // leaves {weight, r, g, b} there; lane 0 then combines the groups in order (CellFold's close_tri /
+            // close_sub sequence without the loads).
+            for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+                if (t == 0 || s_hi[t] != s_hi[t - 1]) {
+                    WUv acc{s_w[t], s_u[t], s_v[t]};
+                    for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                    float cr, cg, cb;
+                    color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                    s_w[t] = acc.w;
+                    s_u[t] = cr;
+                    s_v[t] = cg;
+                    s_idx[t] = __float_as_uint(cb);  // the sort indices are no longer needed
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                bool have_sub = false, have_cell = false;
+                WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
+                uint32_t cur_sub = 0;
+                for (uint32_t t = 0; t < n; ++t) {
+                    const uint32_t hi = s_hi[t];
+                    if (t != 0 && hi == s_hi[t - 1]) continue;
+                    if (have_sub && (hi >> 29) != cur_sub) {
+                        cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                        have_cell = true;
+                        have_sub = false;
+                    }
+                    const WCol fresh{s_w[t], s_u[t], s_v[t], __uint_as_float(s_idx[t])};
+                    sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
+                    have_sub = true;
+                    cur_sub = hi >> 29;
+                }
+                if (have_sub) cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                out[i] = cell_record(o, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b), p);
+            }
+        }
+        else {
+            // MAX: `new.w > existing.w ? new : existing` over ascending (sub-voxel, triangle) groups keeps the first
+            // group with the greatest weight, which is a true reduction: every group is folded by the lane at its
+            // first record (leaves of one triangle, in order), then the groups are max-reduced with ties to the
+            // lower position.
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+                if (t == 0 || s_hi[t] != s_hi[t - 1]) {
+                    WUv acc{s_w[t], s_u[t], s_v[t]};
+                    uint32_t j = t + 1;
+                    for (; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                    // weights are non-negative, so their bit patterns order like the values
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            if (THREADS > 64) {
+                __syncthreads();
+                if ((threadIdx.x & 63u) == 0) s_key[threadIdx.x >> 6] = best;  // s_key is free after the sort
+                __syncthreads();
+                best = s_key[0];
+                for (uint32_t wv = 1; wv < THREADS / 64; ++wv) best = s_key[wv] > best ? s_key[wv] : best;
+            }
+            if (threadIdx.x == 0) {
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                // rebuild the winning group's uv (needed for a textured winner) and emit
+                WUv acc{s_w[t], s_u[t], s_v[t]};
+                for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                float cr, cg, cb;
+                color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+            }
+        }
+    }
+}
+
+// Tier 3b: cells with 2049..8192 hits (the poles of a finely tessellated sphere at high resolution).  One workgroup
+// per cell; (key, idx) pairs are bitonic-sorted in dynamic LDS (96 KiB), the payload stays in global memory: MAX
+// folds the groups in parallel straight from it, BLEND stages it in sorted order, 1024 records at a time, for the
+// sequential replay.
+constexpr uint32_t kBigStage = 1024, kBigThreads = 1024;
+__global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__restrict__ list, Counters *c,
+                                                        const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                        uint4 *out, uint32_t list_cap, Params p)
+{
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    uint64_t *s_key = reinterpret_cast<uint64_t *>(s_dyn);                                  // [kBigList]
+    uint32_t *s_idx = reinterpret_cast<uint32_t *>(s_dyn + (size_t) kBigList * 8);           // [kBigList]
+    __shared__ uint32_t s_hi[kBigStage];
+    __shared__ float s_w[kBigStage], s_u[kBigStage], s_v[kBigStage];
+    __shared__ unsigned long long s_best[kBigThreads / 64];
+    __shared__ uint32_t s_item;
+    if (pass_overflowed(c, p)) return;
+    const uint32_t total = c->n_bigl < list_cap ? c->n_bigl : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(&c->cursor_big, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count < kBigList ? o.count : kBigList;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBigThreads) {
+            if (t < n) {
+                const SortedRec r = sorted.load(o.offset + t);
+                s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                s_idx[t] = t;
+            }
+            else {
+                s_key[t] = ~0ull;
+                s_idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, kBigThreads);
+        if (p.blend) {
+            CellFold f;  // only thread 0's copy is used
+            for (uint32_t base = 0; base < n; base += kBigStage) {
+                const uint32_t m_here = n - base < kBigStage ? n - base : kBigStage;
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < m_here; t += kBigThreads) {
+                    const SortedRec r = sorted.load(o.offset + s_idx[base + t]);
+                    s_hi[t] = r.keyhi;
+                    s_w[t] = r.w;
+                    s_u[t] = r.u;
+                    s_v[t] = r.v;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    for (uint32_t t = 0; t < m_here; ++t) f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
+            }
+            if (threadIdx.x == 0) out[i] = cell_record(o, f.finish(m, p.blend), p);
+        }
+        else {
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += kBigThreads) {
+                const uint32_t hi = (uint32_t) (s_key[t] >> 32);
+                if (t == 0 || (uint32_t) (s_key[t - 1] >> 32) != hi) {
+                    SortedRec r = sorted.load(o.offset + s_idx[t]);
+                    WUv acc{r.w, r.u, r.v};
+                    for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
+                        r = sorted.load(o.offset + s_idx[j]);
+                        acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                    }
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBigThreads / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                const uint32_t hi = (uint32_t) (s_key[t] >> 32);
+                SortedRec r = sorted.load(o.offset + s_idx[t]);
+                WUv acc{r.w, r.u, r.v};
+                for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
+                    r = sorted.load(o.offset + s_idx[j]);
+                    acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                }
+                float cr, cg, cb;
+                color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+            }
+        }
+    }
+}
+
+// Tier 4: cells with more than 8192 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
+// pairs in a global scratch area; each cell bump-allocates a power-of-two range (scratch holds 2 * cap_hits pairs).
+__global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restrict__ list, Counters *c,
+                                                         const Occ *__restrict__ occ, SortedView sorted,
+                                                         Materials m, uint4 *out, uint64_t *scratch_key,
+                                                         uint32_t *scratch_idx, uint32_t scratch_cap, uint32_t list_cap,
+                                                         Params p)
+{
+    __shared__ uint32_t s_item, s_base, s_ok;
+    __shared__ unsigned long long s_best[kBlock / 64];
+    if (pass_overflowed(c, p)) return;
+    const uint32_t total = c->n_huge < list_cap ? c->n_huge : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(&c->cursor_huge, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        if (threadIdx.x == 0) {
+            s_base = atomicAdd(&c->scratch_used, n_pow2);
+            // scratch too small: the host sees scratch_used > capacity, grows it and re-runs
+            s_ok = (uint64_t) s_base + n_pow2 <= scratch_cap ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_ok) continue;
+        uint64_t *key = scratch_key + s_base;
+        uint32_t *idx = scratch_idx + s_base;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
+            if (t < n) {
+                const SortedRec r = sorted.load(o.offset + t);
+                key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                idx[t] = t;
+            }
+            else {
+                key[t] = ~0ull;
+                idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(key, idx, n_pow2, threadIdx.x, kBlock);
+        if (p.blend) {
+            // BLEND: sequential by nature (see k_resolve_sorted)
+            if (threadIdx.x == 0) {
+                CellFold f;
+                for (uint32_t t = 0; t < n; ++t) {
+                    const SortedRec r = sorted.load(o.offset + idx[t]);
+                    f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
+                }
+                out[i] = cell_record(o, f.finish(m, p.blend), p);
+            }
+        }
+        else {
+            // MAX: fold every (sub-voxel, triangle) group at its first record, max-reduce with ties to the earlier group
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += kBlock) {
+                const uint32_t hi = (uint32_t) (key[t] >> 32);
+                if (t == 0 || (uint32_t) (key[t - 1] >> 32) != hi) {
+                    SortedRec r = sorted.load(o.offset + idx[t]);
+                    WUv acc{r.w, r.u, r.v};
+                    for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
+                        r = sorted.load(o.offset + idx[j]);
+                        acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                    }
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBlock / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                const uint32_t hi = (uint32_t) (key[t] >> 32);
+                SortedRec r = sorted.load(o.offset + idx[t]);
+                WUv acc{r.w, r.u, r.v};
+                for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
+                    r = sorted.load(o.offset + idx[j]);
+                    acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                }
+                float cr, cg, cb;
+                color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+            }
+        }
+    }
+}

@@ -97,10 +97,11 @@ struct Counters {
     uint32_t n_dirty, n_sorted, n_bigl, cursor_big;
     uint32_t cursor_mid, cursor_long, cursor_huge, n_lane;
     uint32_t n_nodes[kMaxRounds + 1];
-    uint32_t n_w64, pad1[2];
+    uint32_t n_w64, n_dirty_max, n_out;
     unsigned long long n_candidates, n_hits;
     uint32_t bounds_enc[6];
-    uint32_t pad2[2];
+    uint32_t n_root_leaves, pad2;  // root triangles that became leaves as they are (the others are in n_nodes[0])
+    unsigned long long n_direct;
     float xform[12];
 };
 
@@ -125,6 +126,11 @@ struct Params {
     float bounds[6];
     int32_t unit[9];
     uint32_t has_uv;
+    // Direct MAX path (MAX strategy, no textured triangle; section 4 of DESIGN.md): one 64-bit cell per output voxel that
+    // holds max over {weight bits << 32 | ~(sub-voxel << 29 | triangle)}, and its own dirty-brick map.
+    uint32_t direct_max;
+    unsigned long long *maxgrid;
+    uint8_t *dirty_max;
 };
 
 // ---- small device helpers ---------------------------------------------------------------------------------
@@ -138,6 +144,13 @@ __device__ __forceinline__ bool expand_overflowed(const Counters *c, const Param
     bool over = c->n_leaves > p.cap_leaves || c->n_tiles > p.cap_tiles || c->n_big > p.cap_big;
     for (uint32_t r = 0; r <= kMaxRounds; ++r) over |= c->n_nodes[r] > p.cap_nodes;
     return over;
+}
+// The direct MAX path pays off when most triangles are voxelized whole (their hits skip the pool / sort / replay);
+// for a mesh whose triangles are mostly subdivided it would only add a pass.  Decided on the device from K1's counters,
+// identically by every kernel of the pass (and by the host afterwards).
+__device__ __forceinline__ bool direct_active(const Counters *c, const Params &p)
+{
+    return p.direct_max && c->n_nodes[0] <= c->n_root_leaves;
 }
 __device__ __forceinline__ bool pass_overflowed(const Counters *c, const Params &p)
 {

@@ -129,6 +129,7 @@ __device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, 
     __syncthreads();
     if (threadIdx.x == 0) {
         s_base[0] = tot_leaf ? atomicAdd(&c->n_leaves, tot_leaf) : 0u;
+        if (tot_leaf && node_round == 0) atomicAdd(&c->n_root_leaves, tot_leaf);
         s_base[1] = tot_tile ? atomicAdd(&c->n_tiles, tot_tile) : 0u;
         s_base[2] = tot_big ? atomicAdd(&c->n_big, tot_big) : 0u;
         s_base[3] = tot_node ? atomicAdd(&c->n_nodes[node_round], tot_node) : 0u;

@@ -239,9 +239,10 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     __shared__ uint32_t s_chunk_tile[kMaxSurvivors / 64 + 1];
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
     __shared__ uint16_t s_surv[kMaxSurvivors];
-    __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits;
+    __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits, s_direct;
 
     if (expand_overflowed(c, p)) return;
+    const bool use_direct = !UV && direct_active(c, p);
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
     // Batch size: about six batches per workgroup, between one tile per wavefront and what the LDS staging holds.  Few
     // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
@@ -253,7 +254,10 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
-    if (threadIdx.x == 0) s_hits = 0;
+    if (threadIdx.x == 0) {
+        s_hits = 0;
+        s_direct = 0;
+    }
 
     for (;;) {
         __syncthreads();
@@ -386,11 +390,17 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             uint32_t d_xy = 0, d_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
             bool d_valid = false;
             auto flush_results = [&]() {
-                const unsigned long long mask = __ballot(d_valid);
-                if (!mask) return;
+                const unsigned long long all = __ballot(d_valid);
+                if (!all) return;
+                // Direct MAX path: a hit of an unsplit triangle (order key 0: its only leaf) is the triangle's whole weight in
+                // this (sub-)voxel, so it competes at once - one 64-bit atomic max on the cell, no hit record.  Hits of
+                // subdivided triangles still go through the pool (their leaves' weights must be added up in order first).
+                const bool direct = d_valid && use_direct && s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u;
+                const bool pooled = d_valid && !direct;
+                const unsigned long long mask = __ballot(pooled);
                 const uint32_t cnt = (uint32_t) __popcll(mask);
-                const uint32_t leader = (uint32_t) __ffsll((long long) mask) - 1u;
-                if (chunk_used + cnt > kHitChunk) {
+                const uint32_t leader = mask ? (uint32_t) __ffsll((long long) mask) - 1u : 0u;
+                if (cnt && chunk_used + cnt > kHitChunk) {
                     // abandon the rest of the chunk (marked as holes for the scatter pass) and reserve a new one
                     const uint32_t hole = chunk_base + chunk_used + lane;
                     if (chunk_used + lane < kHitChunk && hole < p.cap_hits) pool[hole].brick = kHoleBrick;
@@ -404,21 +414,33 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 }
                 const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
                 chunk_used += cnt;
-                if (d_valid && mine < p.cap_hits) {
+                if (d_valid) {
                     const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
                     const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
                     const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
                     uint32_t brick;
                     const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
                     const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
-                    // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
-                    const uint32_t rank = atomicAdd(&grid[cell], 1u);
-                    if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
-                    brick_dirty[brick] = 1;  // benign race: every writer stores the same value
-                    pool[mine] = HitRec{brick, (((uint32_t) cell & 255u) << 24) | (rank & (kMaxRank - 1u)),
-                                        (sub << 29) | lf[18], lf[19], d_w, d_u, d_v, 0u};
+                    const uint32_t keyhi = (sub << 29) | lf[18];
+                    if (direct) {
+                        atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
+                        p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
+                    }
+                    else if (mine < p.cap_hits) {
+                        // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
+                        const uint32_t rank = atomicAdd(&grid[cell], 1u);
+                        if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
+                        brick_dirty[brick] = 1;  // benign race: every writer stores the same value
+                        if (use_direct) p.dirty_max[brick] = 1;  // the resolve kernels will add this cell's result
+                        pool[mine] = HitRec{brick, (((uint32_t) cell & 255u) << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w,
+                                            d_u, d_v, 0u};
+                    }
                 }
-                if (lane == leader) atomicAdd(&s_hits, cnt);
+                if (lane == 0) atomicAdd(&s_hits, (uint32_t) __popcll(all));
+                if (use_direct) {
+                    const unsigned long long dmask = __ballot(direct);
+                    if (lane == 0 && dmask) atomicAdd(&s_direct, (uint32_t) __popcll(dmask));
+                }
                 d_valid = false;
             };
             for (;;) {
@@ -565,4 +587,5 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
         if (chunk_used != kHitChunk && chunk_base + k < p.cap_hits) pool[chunk_base + k].brick = kHoleBrick;
     __syncthreads();
     if (threadIdx.x == 0 && s_hits) atomicAdd(&c->n_hits, (unsigned long long) s_hits);
+    if (threadIdx.x == 0 && s_direct) atomicAdd(&c->n_direct, (unsigned long long) s_direct);
 }

@@ -62,7 +62,7 @@ __device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float
 //   sub-voxels, ascending    -> documented downscale semantics        voxelization.hpp:82-85
 struct CellFold {
     bool have_tri = false, have_sub = false, have_cell = false;
-    uint32_t cur_group = 0;
+    uint32_t cur_group = 0, sub_key = 0, cell_key = 0;  // MAX: the group (sub-voxel | triangle) that holds sub_acc / cell_acc
     WUv tri_acc{0, 0, 0};
     WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
 
@@ -71,12 +71,14 @@ struct CellFold {
         float cr, cg, cb;
         color_at(m, cur_group & 0x1fffffffu, tri_acc.u, tri_acc.v, cr, cg, cb);
         const WCol fresh{tri_acc.w, cr, cg, cb};
+        if (!have_sub || (!blend && fresh.w > sub_acc.w)) sub_key = cur_group;  // wmax keeps the existing value on a tie
         sub_acc = have_sub ? wcombine(blend, fresh, sub_acc) : fresh;
         have_sub = true;
         have_tri = false;
     }
     __device__ __forceinline__ void close_sub(uint32_t blend)
     {
+        if (!have_cell || (!blend && sub_acc.w > cell_acc.w)) cell_key = sub_key;
         cell_acc = have_cell ? wcombine(blend, sub_acc, cell_acc) : sub_acc;
         have_cell = true;
         have_sub = false;
@@ -109,6 +111,22 @@ __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const 
     const uint32_t by = row - bz * p.NBy;
     const uint32_t x = bx * kBrickX + (local & 15u), y = by * kBrickY + ((local >> 4) & 3u), z = bz * kBrickZ + (local >> 6);
     return make_uint4(x, y, z + p.zo0, argb);
+}
+
+// Where a resolved cell goes.  Normally its (x, y, z, argb) record is final.  On the direct MAX path (Params::direct_max)
+// the cell may also have received hits of unsplit triangles straight from k_voxelize, so the winner of the hits resolved
+// here - weight `w`, group `keyhi` = sub-voxel << 29 | triangle - competes in the same 64-bit cell and k_emit_max
+// writes the record.
+__device__ __forceinline__ void emit_cell(const Occ &o, uint32_t argb, float w, uint32_t keyhi, uint4 *out, uint32_t i,
+                                          const Counters *c, const Params &p)
+{
+    if (direct_active(c, p)) {
+        const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+        atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(w) << 32) | (0xffffffffu - keyhi));
+    }
+    else {
+        out[i] = cell_record(o, argb, p);
+    }
 }
 
 
@@ -158,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         for (uint32_t t = 0; t < o.count; ++t)
             f.add(m, p.blend, (uint32_t) (s_key[t][threadIdx.x] >> 32), s_w[t][threadIdx.x],
                   kUv ? s_u[t][threadIdx.x] : 0.f, kUv ? s_v[t][threadIdx.x] : 0.f);
-        out[i] = cell_record(o, f.finish(m, p.blend), p);
+        const uint32_t argb = f.finish(m, p.blend);
+        emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
 
@@ -224,7 +243,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restr
             const float ww = __shfl(w, from, 64), uu = __shfl(u, from, 64), vv = __shfl(v, from, 64);
             if (t < n) f.add(m, p.blend, hh, ww, uu, vv);
         }
-        if (n != 0 && sl == 0) out[i] = cell_record(o, f.finish(m, p.blend), p);
+        const uint32_t argb = f.finish(m, p.blend);
+        if (n != 0 && sl == 0) emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
 
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
                 for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
                 float cr, cg, cb;
                 color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
-                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+                emit_cell(o, pack_argb(cr, cg, cb), acc.w, s_hi[t], out, i, c, p);
             }
         }
     }
@@ -477,7 +497,7 @@ __global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__r
                 }
                 float cr, cg, cb;
                 color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
-                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+                emit_cell(o, pack_argb(cr, cg, cb), acc.w, hi, out, i, c, p);
             }
         }
     }
@@ -575,8 +595,94 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
                 }
                 float cr, cg, cb;
                 color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
-                out[i] = cell_record(o, pack_argb(cr, cg, cb), p);
+                emit_cell(o, pack_argb(cr, cg, cb), acc.w, hi, out, i, c, p);
             }
         }
     }
+}
+
+// ---- direct MAX path: emission -----------------------------------------------------------------------------------
+// MAX strategy without textured triangles: `new.w > existing.w ? new : existing` over ascending (sub-voxel, triangle)
+// is a true reduction - the greatest weight wins, ties go to the smaller (sub-voxel, triangle) - and a triangle's colour
+// does not depend on where it was hit, so a voxel only has to remember max{weight bits << 32 | ~(sub << 29 | triangle)}
+// (weights are positive floats: their bit patterns order like the values).  k_voxelize feeds that cell directly for
+// unsplit triangles, the resolve kernels add the summed-up subdivided ones, and this kernel turns every non-zero
+// cell of the dirty bricks into its (x, y, z, argb) record and zeroes it again (moveUvBufferIntoVoxels + the pack of
+// obj2voxel.cpp:279-297).  Records are staged in LDS so that a workgroup reserves output space once per ~2048 voxels.
+constexpr uint32_t kEmitBricksPerWave = 2;
+constexpr uint32_t kEmitBricksPerRound = (kBlock / 64) * kEmitBricksPerWave;
+constexpr uint32_t kEmitFlushAt = 2048;
+constexpr uint32_t kEmitCap = kEmitFlushAt + kEmitBricksPerRound * kBrickCells;
+
+__global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict__ dirty_list, Counters *c, Materials m, uint4 *out,
+                                                     Params p)
+{
+    __shared__ uint4 s_rec[kEmitCap];
+    __shared__ uint32_t s_n, s_base;
+    if (!direct_active(c, p)) return;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t n_dirty = c->n_dirty_max;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_rounds = (n_dirty + kEmitBricksPerRound - 1) / kEmitBricksPerRound;
+    auto flush = [&](uint32_t n) {
+        if (threadIdx.x == 0) s_base = atomicAdd(&c->n_out, n);
+        __syncthreads();
+        const uint32_t base = s_base;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+            if (base + i < p.cap_vox) out[base + i] = s_rec[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    };
+    for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
+        uint32_t brick[kEmitBricksPerWave];
+        ulonglong2 lo[kEmitBricksPerWave], hi[kEmitBricksPerWave];
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
+            const uint32_t item = r * kEmitBricksPerRound + wave * kEmitBricksPerWave + k;
+            brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
+            lo[k] = hi[k] = make_ulonglong2(0, 0);
+            if (brick[k] != 0xffffffffu) {
+                const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p.maxgrid + (uint64_t) brick[k] * kBrickCells) + lane * 2u;
+                lo[k] = q[0];
+                hi[k] = q[1];
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
+            const unsigned long long v4[4] = {lo[k].x, lo[k].y, hi[k].x, hi[k].y};
+            if (v4[0] | v4[1] | v4[2] | v4[3]) {
+                const uint32_t row = brick[k] / p.NBx;
+                const uint32_t bx = brick[k] - row * p.NBx;
+                const uint32_t bz = row / p.NBy;
+                const uint32_t by = row - bz * p.NBy;
+#pragma unroll
+                for (uint32_t e = 0; e < 4; ++e) {
+                    if (v4[e]) {
+                        const uint32_t local = lane * 4u + e;
+                        const uint32_t keyhi = 0xffffffffu - (uint32_t) v4[e];
+                        float cr, cg, cb;
+                        color_at(m, keyhi & 0x1fffffffu, 0.f, 0.f, cr, cg, cb);
+                        const uint32_t slot = atomicAdd(&s_n, 1u);
+                        s_rec[slot] = make_uint4(bx * kBrickX + (local & 15u), by * kBrickY + ((local >> 4) & 3u),
+                                                 bz * kBrickZ + (local >> 6) + p.zo0, pack_argb(cr, cg, cb));
+                    }
+                }
+                // leave the cells clean for the next run
+                ulonglong2 *q = reinterpret_cast<ulonglong2 *>(p.maxgrid + (uint64_t) brick[k] * kBrickCells) + lane * 2u;
+                q[0] = make_ulonglong2(0, 0);
+                q[1] = make_ulonglong2(0, 0);
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n >= kEmitFlushAt) flush(n);
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (n) flush(n);
 }

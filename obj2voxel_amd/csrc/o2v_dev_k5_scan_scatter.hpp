@@ -9,7 +9,7 @@
 // per lane), compacts the occupied cells into `occ` through an LDS staging buffer (one global atomic per flush,
 // not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.
 
-__global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, Counters *c, uint32_t *dirty_list, Params p)
+__global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uint32_t *n_dirty, uint32_t *dirty_list, Params p)
 {
     __shared__ uint32_t s_list[kBlock * 16];
     __shared__ uint32_t s_n, s_base;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, Cou
         __syncthreads();
         const uint32_t n = s_n;
         if (n) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&c->n_dirty, n);
+            if (threadIdx.x == 0) s_base = atomicAdd(n_dirty, n);
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n; i += kBlock) dirty_list[s_base + i] = s_list[i];
         }

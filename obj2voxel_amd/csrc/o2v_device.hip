@@ -98,6 +98,11 @@ struct o2v_hip_ctx {
     uint64_t grid_cells = 0;      // allocated
     uint8_t *d_brick_dirty = nullptr;   // one flag per brick (padded to 16 bytes)
     uint32_t *d_dirty_list = nullptr;   // dirty brick ids of the current run
+    unsigned long long *d_maxgrid = nullptr;  // direct MAX path: one 64-bit cell per output voxel (same bricked layout)
+    uint8_t *d_dirty_max = nullptr;           // ... its dirty-brick flags and list
+    uint32_t *d_dirty_list_max = nullptr;
+    uint64_t maxgrid_cells = 0, maxgrid_brick_cap = 0;
+    bool maxgrid_dirty = false;
     uint64_t brick_cap = 0;
     bool grid_dirty = false;
 
@@ -226,7 +231,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     {
         const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
         hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_brick_dirty, ctx->d_ctr, ctx->d_dirty_list, p);
+                           dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, p);
         O2V_STAGE("k_scan_flags");
         const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
                                  ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
@@ -263,16 +268,16 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             hipLaunchKernelGGL(k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
                                ctx->d_out, p);
         O2V_STAGE("k_resolve");
-        hipLaunchKernelGGL(k_resolve_wave<16>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
+        hipLaunchKernelGGL(k_resolve_wave<16>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
                            &ctx->d_ctr->n_lane16, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<16>");
-        hipLaunchKernelGGL(k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sw, ctx->d_list_lane,
+        hipLaunchKernelGGL(k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane,
                            &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<32>");
-        hipLaunchKernelGGL(k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 8u), dim3(kBlock), 0, sm, ctx->d_list_w64,
+        hipLaunchKernelGGL(k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_w64,
                            &ctx->d_ctr->n_w64, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_wave<64>");
-        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, sm,
+        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 8u), dim3(64), 0, sm,
                            ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
@@ -280,11 +285,11 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                            ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_sorted");
-        hipLaunchKernelGGL(k_resolve_big, dim3((uint32_t) ctx->num_cus), dim3(kBigThreads), kBigList * 12u, sl, ctx->d_list_big,
+        hipLaunchKernelGGL(k_resolve_big, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBigThreads), kBigList * 12u, sl, ctx->d_list_big,
                            ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_STAGE("k_resolve_big");
         if (ctx->d_scratch_key) {
-            hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus), dim3(kBlock), 0, sl, ctx->d_list_huge,
+            hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBlock), 0, sl, ctx->d_list_huge,
                                ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, ctx->d_scratch_key,
                                ctx->d_scratch_idx, ctx->cap_scratch, p.cap_vox, p);
             O2V_STAGE("k_resolve_huge");
@@ -294,6 +299,16 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                 O2V_CHECK(hipEventRecord(ctx->ev_join[j], ctx->aux[j]));
                 O2V_CHECK(hipStreamWaitEvent(s, ctx->ev_join[j], 0));
             }
+        if (p.direct_max) {
+            // every voxel's winner is in the 64-bit grid now (k_voxelize: unsplit triangles, resolve: the rest)
+            const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
+            hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),
+                               dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, p);
+            O2V_STAGE("k_scan_flags (max)");
+            hipLaunchKernelGGL(k_emit_max, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
+                               ctx->d_out, p);
+            O2V_STAGE("k_emit_max");
+        }
     }
     O2V_CHECK(hipEventRecord(ctx->ev[5], s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -363,7 +378,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
                     ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid,
                     ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
-                    ctx->d_brick_dirty, ctx->d_dirty_list};
+                    ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
     for (uint8_t *q : ctx->d_texpix)
@@ -519,6 +534,35 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
         ctx->grid_dirty = false;
     }
+    // Direct MAX path: MAX strategy and no textured triangle
+    {
+        const char *off = std::getenv("O2V_NO_DIRECT_MAX");
+        p.direct_max = (params->strategy == 0u && !use_uv && !(off && off[0] == '1')) ? 1u : 0u;
+    }
+    if (p.direct_max) {
+        if (cells > ctx->maxgrid_cells || !ctx->d_maxgrid) {
+            for (void *q : {(void *) ctx->d_maxgrid, (void *) ctx->d_dirty_max, (void *) ctx->d_dirty_list_max})
+                if (q) O2V_CHECK(hipFree(q));
+            ctx->d_maxgrid = nullptr;
+            ctx->d_dirty_max = nullptr;
+            ctx->d_dirty_list_max = nullptr;
+            ctx->maxgrid_cells = 0;
+            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_maxgrid), cells * sizeof(unsigned long long)));
+            ctx->maxgrid_cells = cells;
+            ctx->maxgrid_brick_cap = (n_bricks + 15u) & ~15ull;
+            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), ctx->maxgrid_brick_cap));
+            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), ctx->maxgrid_brick_cap * sizeof(uint32_t)));
+            ctx->maxgrid_dirty = true;
+        }
+        if (ctx->maxgrid_dirty) {
+            O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
+            O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_brick_cap, ctx->stream));
+            ctx->maxgrid_dirty = false;
+        }
+        p.maxgrid = ctx->d_maxgrid;
+        p.dirty_max = ctx->d_dirty_max;
+        ctx->stats.grid_bytes += cells * sizeof(unsigned long long) + n_bricks;
+    }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
 
     // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
@@ -546,12 +590,17 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     uint32_t n_rounds = 4;
     while ((1u << n_rounds) < p.S && n_rounds < kMaxRounds) ++n_rounds;
     ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
+    if (p.direct_max) ctx->maxgrid_dirty = true;
     for (uint32_t pass = 1; pass <= 12; ++pass) {
         int rc;
         if (pass > 1) {
             // a pass that overflowed a buffer may have left counters / offsets in cells it could not list
             O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
             O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
+            if (p.direct_max) {
+                O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
+                O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_brick_cap, ctx->stream));
+            }
         }
         if ((rc = grow(ctx, ctx->d_leaves, ctx->cap_leaves, want_leaves))) return rc;
         if ((rc = grow(ctx, ctx->d_tiles, ctx->cap_tiles, want_tiles))) return rc;
@@ -612,6 +661,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(max_nodes, ctx->cap_nodes, want_nodes);
         need(h.n_hits_reserved, ctx->cap_hits, want_hits);
         need(h.n_vox, ctx->cap_vox, want_vox);
+        if (p.direct_max) need(h.n_out, ctx->cap_vox, want_vox);
         if (n_rounds < kMaxRounds && h.n_nodes[n_rounds] != 0) {
             n_rounds = kMaxRounds;  // unusually deep subdivision
             again = true;
@@ -623,14 +673,18 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         }
         if (!again) {
             ctx->grid_dirty = false;
-            ctx->n_vox = h.n_vox;
+            ctx->maxgrid_dirty = false;
+            const bool direct = p.direct_max && h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
+            const uint64_t n_final = direct ? h.n_out : h.n_vox;
+            ctx->n_vox = n_final;
             ctx->stats.leaves = h.n_leaves;
             ctx->stats.tiles = h.n_tiles;
             ctx->stats.candidates = h.n_candidates;
             ctx->stats.hits = h.n_hits;
-            ctx->stats.voxels = h.n_vox;
+            ctx->stats.voxels = n_final;
+            ctx->stats.direct_hits = h.n_direct;
             ctx->stats.bricks = p.n_bricks;
-            ctx->stats.dirty_bricks = h.n_dirty;
+            ctx->stats.dirty_bricks = direct ? h.n_dirty_max : h.n_dirty;
             ctx->stats.pool_slots = h.n_hits_reserved;
             std::memcpy(ctx->xform, h.xform, sizeof(ctx->xform));
             float ms[5];

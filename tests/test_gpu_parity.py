@@ -394,3 +394,28 @@ def test_buffer_overflow_regrow_paths(oracle, monkeypatch):
 
 def kw_mat(kw):
     return {k: v for k, v in kw.items() if k in ("types", "colors", "uvs", "texids")}
+
+
+@pytest.mark.parametrize("supersampling", [1, 2])
+def test_direct_max_path_mixes_whole_and_subdivided_triangles(dv, oracle, supersampling):
+    """MAX strategy without textured triangles: hits of unsplit triangles go straight into the 64-bit max grid, hits of
+    subdivided ones through the pool / sort / replay, and both meet in the same cells - small triangles (one leaf each)
+    scattered over a few large ones (subdivided), equal weights included (duplicates: ties go to the lower index)."""
+    from obj2voxel_amd import hip
+    rng = np.random.default_rng(77)
+    big = rng.random((6, 3, 3)).astype(np.float32)                                # subdivided at this resolution
+    c = rng.random((900, 1, 3)).astype(np.float32)
+    small = np.clip(c + 0.03 * (rng.random((900, 3, 3)).astype(np.float32) - 0.5), 0, 1)
+    v = np.concatenate([small[:450], big, small[450:], small[:40]]).reshape(-1, 9)   # duplicates at the end
+    T = len(v)
+    types = np.where(np.arange(T) % 3 == 0, hip.TRI_MATERIALLESS, hip.TRI_UNTEXTURED).astype(np.uint32)
+    kw = dict(types=types, colors=rng.random((T, 3)).astype(np.float32), strategy=0, supersampling=supersampling)
+    got, want = _run_both(dv, oracle, v, 96, **kw)
+    _compare(got, want)
+    st = dv.stats()
+    assert 0 < st["direct_hits"] < st["hits"]            # both routes were taken
+    # the same mesh with BLEND never uses the direct path
+    kw["strategy"] = 1
+    got, want = _run_both(dv, oracle, v, 96, **kw)
+    _compare(got, want)
+    assert dv.stats()["direct_hits"] == 0

@@ -9,8 +9,8 @@ no network, so the stand-in is the deterministic UV sphere of SURVEY.md section 
 triangles, MATERIALLESS, MAX strategy, resolution 1024.
 
 One step = one pass of the whole device pipeline (bounds -> transform -> exact subdivision -> AABB walk + clip
--> grid scan -> ordered resolve) over triangles already resident in HBM, leaving the (x, y, z, argb) records
-in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the grid is split into N z-slabs,
+-> per-voxel combine: for this workload (MAX, no textures) a 64-bit atomic max per hit and one emission pass over the
+dirty bricks) over triangles already resident in HBM, leaving the (x, y, z, argb) records in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the grid is split into N z-slabs,
 every rank voxelizes its slab from the replicated triangle list (triangles are binned to slabs on the device
 by AABB; no data-path collective is needed: SURVEY.md section 8e).  The slab cuts are work-balanced: each step
 every rank runs o2v_hip_plan_slabs (a z-histogram of predicted hits over the replicated triangles) and takes its
@@ -131,14 +131,25 @@ def main():
         B, D, slots = stats["bricks"], stats["dirty_bricks"], stats["pool_slots"]
         # algorithmic bytes per launch of each stage
         REC = 16  # sorted record: 16 bytes for a mesh without textured triangles (this workload), else 24
-        alg_bytes = {
-            "expand_ms": 36 * T + 96 * L + 8 * tiles,
-            "voxelize_ms": 96 * L + 8 * tiles + (32 + 4 + 1) * H,
-            "scan_ms": B + 1024 * D + (16 + 4) * V + 32 * slots + (4 + REC) * H + 1024 * D,
-            "resolve_ms": 16 * V + REC * H + 16 * V,
-        }
+        Hd = stats["direct_hits"]  # MAX without textures: hits that went straight into the 64-bit max grid
+        Hp = H - Hd                # hits that took the pool -> counting sort -> ordered replay route
+        if Hd:
+            # direct MAX path: the dirty bricks / voxels reported belong to the 64-bit grid (2 KiB per brick)
+            alg_bytes = {
+                "expand_ms": 36 * T + 96 * L + 8 * tiles,
+                "voxelize_ms": 96 * L + 8 * tiles + (8 + 1) * Hd + (32 + 4 + 1) * Hp,
+                "scan_ms": B + 32 * slots + (4 + REC) * Hp,
+                "resolve_ms": REC * Hp + B + 2 * 2048 * D + 16 * V,
+            }
+        else:
+            alg_bytes = {
+                "expand_ms": 36 * T + 96 * L + 8 * tiles,
+                "voxelize_ms": 96 * L + 8 * tiles + (32 + 4 + 1) * H,
+                "scan_ms": B + 1024 * D + (16 + 4) * V + 32 * slots + (4 + REC) * H + 1024 * D,
+                "resolve_ms": 16 * V + REC * H + 16 * V,
+            }
         kernel_of = {"expand_ms": "k_expand_roots+k_expand_nodes", "voxelize_ms": "k_voxelize",
-                     "scan_ms": "k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks", "resolve_ms": "k_resolve*"}
+                     "scan_ms": "k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks", "resolve_ms": "k_resolve*+k_emit_max"}
         dom = max(alg_bytes, key=lambda k: stage_avg[k])
         achieved = alg_bytes[dom] / (stage_avg[dom] * 1e-3) / 1e9
         traffic = None

@@ -54,7 +54,7 @@ K = out["kernels"]
 out["k_voxelize"] = K["k_voxelize<false>"]["hbm_bytes_corrected"]
 out["k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks"] = sum(
     K[k]["hbm_bytes_corrected"] for k in ("k_scan_flags", "k_scan_bricks", "k_scatter", "k_reset_bricks"))
-out["k_resolve*"] = sum(K[k]["hbm_bytes_corrected"] for k in K if k.startswith("k_resolve"))
+out["k_resolve*+k_emit_max"] = sum(K[k]["hbm_bytes_corrected"] for k in K if k.startswith("k_resolve") or k == "k_emit_max")
 out["k_expand_roots+k_expand_nodes"] = K["k_expand_roots"]["hbm_bytes_corrected"]
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 json.dump(out, open(os.path.join(out_dir, "pmc_hbm_traffic.json"), "w"), indent=1)
@@ -66,7 +66,7 @@ for r in csv.DictReader(open(find("gpurun_out/pmcf_sq/**/p_counter_collection.cs
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 sq = {"_comment": "rocprofv3 --pmc pass (8 SQ counters, --kernel-trace only), bench workload, averages per launch. "
                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)."}
-for k in ("k_voxelize<false>", "k_scatter", "k_resolve<4u>", "k_scan_bricks"):
+for k in ("k_voxelize<false>", "k_emit_max", "k_expand_roots", "k_scatter"):
     d = {c: round(sum(v) / len(v)) for c, v in acc[k].items()}
     if d.get("SQ_INSTS_VALU"):
         d["derived"] = {"valu_active_fraction_per_wave": round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 3),

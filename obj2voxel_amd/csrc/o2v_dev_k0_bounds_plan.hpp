@@ -69,6 +69,32 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float *__restrict__ ver
     }
 }
 
+// Largest triangle extent (L-infinity, mesh space), computed once per upload: with the mesh extent it bounds the
+// subdivision depth, i.e. how many k_expand_nodes rounds a voxelization has to launch (each is ~10 us even when empty).
+__global__ __launch_bounds__(kBlock) void k_tri_extent(const float *__restrict__ verts, uint64_t n_tris, uint32_t *out_enc)
+{
+    __shared__ float s_red[kBlock / 64];
+    float ext = 0.f;
+    for (uint64_t t = (uint64_t) blockIdx.x * kBlock + threadIdx.x; t < n_tris; t += (uint64_t) gridDim.x * kBlock) {
+        const float *q = verts + t * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = fminf(q[a], fminf(q[3 + a], q[6 + a])), hi = fmaxf(q[a], fmaxf(q[3 + a], q[6 + a]));
+            float e = hi - lo;
+            if (!(e == e)) e = __builtin_inff();  // NaN: no bound
+            ext = fmaxf(ext, e);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ext = fmaxf(ext, __shfl_xor(ext, d, 64));
+    if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = ext;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < kBlock / 64; ++w) ext = fmaxf(ext, s_red[w]);
+        atomicMax(out_enc, f2ord(ext));
+    }
+}
+
 __global__ void k_setup(Counters *c, Params p)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,6 +77,8 @@ struct o2v_hip_ctx {
     float2 *d_zrange = nullptr;      // z extent per 256 triangles, written by the slab plan
     float *d_zrange_xform = nullptr;  // the transform they were computed with (12 floats)
     uint32_t cap_zrange = 0;
+    float mesh_bounds_hint[6] = {0, 0, 0, 0, 0, 0};  // bounds and largest triangle extent of the uploaded mesh: only used to
+    float max_tri_extent = -1.f;                     // bound the number of subdivision rounds (-1: unknown)
     uint64_t tri_generation = 0, zrange_generation = ~0ull;  // the extents belong to the triangles of that upload
     Leaf *d_leaves = nullptr;
     Tile *d_tiles = nullptr;
@@ -418,6 +421,20 @@ int o2v_hip_set_triangles(o2v_hip_ctx *ctx, const float *verts, const float *uvs
     if ((rc = upload(ctx, ctx->d_texids, texids, count))) return rc;
     ctx->n_tris = count;
     ctx->tri_generation += 1;
+    ctx->max_tri_extent = -1.f;
+    if (count) {
+        // launch-configuration hint for later voxelizations (see k_tri_extent); the bounds themselves are recomputed there
+        hipStream_t s = ctx->stream;
+        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count * 9 / 12 + kBlock) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
+        hipLaunchKernelGGL(k_tri_extent, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_verts, count, &ctx->d_ctr->pad2);
+        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        O2V_CHECK(hipStreamSynchronize(s));
+        for (int i = 0; i < 6; ++i) ctx->mesh_bounds_hint[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
+        ctx->max_tri_extent = ord2f_host(ctx->h_ctr->pad2);
+    }
     ctx->any_textured = false;
     if (types)
         for (uint64_t i = 0; i < count; ++i)
@@ -589,6 +606,21 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     // last round the pass is repeated with the full kMaxRounds (nothing is lost, only re-run).
     uint32_t n_rounds = 4;
     while ((1u << n_rounds) < p.S && n_rounds < kMaxRounds) ++n_rounds;
+    if (ctx->max_tri_extent >= 0.f) {
+        // tighter: a (sub-)triangle whose extent is at most 5 voxels has a voxel AABB of at most 7^3 < 512 cells and is
+        // a leaf; every round halves the extents.  Scale = the mesh transform's (obj2voxel.cpp:370-402).
+        const float *b = params->bounds_known ? params->bounds : ctx->mesh_bounds_hint;
+        const float max_axis = std::max(b[3] - b[0], std::max(b[4] - b[1], b[5] - b[2]));
+        float unit_norm = 0.f;
+        for (int i = 0; i < 3; ++i)
+            unit_norm = std::max(unit_norm, std::fabs((float) p.unit[i * 3]) + std::fabs((float) p.unit[i * 3 + 1]) + std::fabs((float) p.unit[i * 3 + 2]));
+        const float ext_vox = ctx->max_tri_extent * unit_norm * ((float) p.S / max_axis) + 1.0f;
+        if (max_axis > 0.f && ext_vox == ext_vox && ext_vox < 3.0e9f) {
+            uint32_t depth = 0;
+            for (float e = ext_vox; e > 5.0f; e *= 0.5f) ++depth;
+            n_rounds = std::min<uint32_t>(n_rounds, depth + 1u);
+        }
+    }
     ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
     if (p.direct_max) ctx->maxgrid_dirty = true;
     for (uint32_t pass = 1; pass <= 12; ++pass) {

@@ -30,7 +30,7 @@ def run(dv, name, verts, res, steps=5, **kw):
     tm, st = dv.timings(), dv.stats()
     print(json.dumps({"case": name, "tris": len(verts), "res": res, "voxels": n, "ms": round(dt * 1e3, 3),
                       "mvox_s": round(n / dt / 1e6, 1), "stages_ms": {k: round(v, 3) for k, v in tm.items() if k != "passes"},
-                      "leaves": st["leaves"], "candidates": st["candidates"], "hits": st["hits"]}), flush=True)
+                      "leaves": st["leaves"], "candidates": st["candidates"], "hits": st["hits"], "passes": tm["passes"]}), flush=True)
 
 
 def main():

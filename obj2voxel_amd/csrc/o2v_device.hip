@@ -231,7 +231,20 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
 
-    {
+    // With the direct MAX path the rest of the pass depends on what k_voxelize found: a mesh whose hits all went into
+    // the 64-bit grid needs neither the counting sort nor the replay (a dozen launches that would each find nothing),
+    // one whose triangles are mostly subdivided does not use the 64-bit grid at all.  One look at the counters costs
+    // less than those launches.
+    bool run_general = true, run_emit = false;
+    if (p.direct_max) {
+        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        O2V_CHECK(hipStreamSynchronize(s));
+        const Counters &h = *ctx->h_ctr;
+        run_emit = h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
+        run_general = !run_emit || h.n_hits_reserved != 0;
+    }
+
+    if (run_general) {
         const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
         hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, p);
@@ -250,8 +263,8 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
 
-    {
-        Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
+    Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
+    if (run_general) {
         const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
         // The tiers work on disjoint cells and were filed by k_scan_bricks, so they run side by side: tier 1 on the
         // main stream, the cooperative tiers (short, latency-bound launches) on three auxiliary streams.
@@ -302,7 +315,9 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                 O2V_CHECK(hipEventRecord(ctx->ev_join[j], ctx->aux[j]));
                 O2V_CHECK(hipStreamWaitEvent(s, ctx->ev_join[j], 0));
             }
-        if (p.direct_max) {
+    }
+    {
+        if (run_emit) {
             // every voxel's winner is in the 64-bit grid now (k_voxelize: unsplit triangles, resolve: the rest)
             const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
             hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),

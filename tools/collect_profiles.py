@@ -51,11 +51,16 @@ for k, v in res.items():
     f, w = v.get("FETCH_SIZE", 0) * 1024, v.get("WRITE_SIZE", 0) * 1024
     out["kernels"][k] = {"fetch_size_raw_bytes": round(f), "write_size_bytes": round(w), "hbm_bytes_corrected": round(2 * f + w)}
 K = out["kernels"]
-out["k_voxelize"] = K["k_voxelize<false>"]["hbm_bytes_corrected"]
-out["k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks"] = sum(
-    K[k]["hbm_bytes_corrected"] for k in ("k_scan_flags", "k_scan_bricks", "k_scatter", "k_reset_bricks"))
-out["k_resolve*+k_emit_max"] = sum(K[k]["hbm_bytes_corrected"] for k in K if k.startswith("k_resolve") or k == "k_emit_max")
-out["k_expand_roots+k_expand_nodes"] = K["k_expand_roots"]["hbm_bytes_corrected"]
+
+
+def hbm(k):
+    return K.get(k, {}).get("hbm_bytes_corrected", 0)  # a kernel the workload never launches contributes nothing
+
+
+out["k_voxelize"] = hbm("k_voxelize<false>")
+out["k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks"] = sum(hbm(k) for k in ("k_scan_bricks", "k_scatter", "k_reset_bricks"))
+out["k_resolve*+k_emit_max"] = sum(hbm(k) for k in K if k.startswith("k_resolve") or k in ("k_emit_max", "k_scan_flags"))
+out["k_expand_roots+k_expand_nodes"] = hbm("k_expand_roots")
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 json.dump(out, open(os.path.join(out_dir, "pmc_hbm_traffic.json"), "w"), indent=1)
 
@@ -67,6 +72,8 @@ for r in csv.DictReader(open(find("gpurun_out/pmcf_sq/**/p_counter_collection.cs
 sq = {"_comment": "rocprofv3 --pmc pass (8 SQ counters, --kernel-trace only), bench workload, averages per launch. "
                   "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)."}
 for k in ("k_voxelize<false>", "k_emit_max", "k_expand_roots", "k_scatter"):
+    if k not in acc:
+        continue
     d = {c: round(sum(v) / len(v)) for c, v in acc[k].items()}
     if d.get("SQ_INSTS_VALU"):
         d["derived"] = {"valu_active_fraction_per_wave": round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 3),

@@ -2,24 +2,28 @@
 //
 // Replaces, for one GPU's z-slab of the grid, the reference's chunk loop (src/obj2voxel.cpp:467-520) and
 // Voxelizer::voxelize (src/voxelization.cpp:480-526).  Written for CDNA4: 64-wide wavefronts, LDS-staged leaf
-// geometry and work queues, register-resident clip stacks, 32-bit atomics on a dense (bricked) HBM grid of per-cell
-// counters.  No MFMA: the path is float32 VALU + HBM/atomic traffic.
+// geometry and work queues, register-resident clip stacks, 32- and 64-bit atomics on dense (bricked) HBM grids of per-cell
+// counters / maxima.  No MFMA: the path is float32 VALU + HBM/atomic traffic.
 //
-// Stages (all on one HIP stream, no host round trips between them):
+// Stages (one HIP stream; the replay tiers fork onto three auxiliary streams; kernels in o2v_dev_k*.hpp):
 //   K0  k_bounds / k_setup     mesh bounds (obj2voxel.cpp:180-200) and mesh transform (obj2voxel.cpp:370-402)
 //   K1  k_expand_roots         transform (obj2voxel.cpp:202-224), alignment test (voxelization.cpp:335-347),
 //       k_expand_nodes         exact LIFO subdivision (voxelization.cpp:349-379) done breadth-first with an
 //                              order key that reproduces the reference's processing order,
 //       k_expand_big           tiles of <= 256 candidate voxels for large leaves
 //   K2  k_voxelize<UV>         AABB walk + plane cull (voxelization.cpp:426-472) + six-plane clip by triangle
-//                              splitting (voxelization.cpp:175-331,383-424); every hit is appended to the hit
-//                              pool and counted in its cell with one atomicAdd on the dense grid (-> rank)
-//   K5a k_scan_flags/_bricks   reads the dirty bricks of the dense grid, compacts occupied cells, turns the
-//                              per-cell counts into offsets (counting sort); k_scatter places the hits
-//   K3  k_resolve              per occupied cell: orders the hits like the reference's sequential loops
+//                              splitting (voxelization.cpp:175-331,383-424).  A hit either goes straight into the
+//                              64-bit max grid (MAX strategy, no textures, unsplit triangle: one atomicMax) or is
+//                              appended to the hit pool and counted in its cell (atomicAdd on the dense grid -> rank)
+//   K5  k_scan_flags/_bricks   reads the dirty bricks of the dense grid, compacts occupied cells, turns the
+//                              per-cell counts into offsets (counting sort); k_scatter places the pooled hits
+//   K3  k_resolve + tiers      per occupied cell: orders the hits like the reference's sequential loops
 //                              (sub-voxel, triangle index, leaf order), replays insertWeighted
 //                              (voxelization.cpp:56-63,466-468) and moveUvBufferIntoVoxels (:513-526) with
-//                              MAX / BLEND, then packs (x, y, z, argb) (obj2voxel.cpp:279-297)
+//                              MAX / BLEND, then packs (x, y, z, argb) (obj2voxel.cpp:279-297);
+//       k_emit_max             direct MAX path: turns the 64-bit max grid into the records
+//   plan k_zhist               o2v_hip_plan_slabs: predicted hits per z layer -> work-balanced slabs for N GPUs
+// With the direct MAX path the host looks at the counters once after K2 and launches only the stages that have work.
 //
 // Compile with -ffp-contract=off (see o2v_math.h).
 #include "o2v_math.h"

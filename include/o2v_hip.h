@@ -121,7 +121,9 @@ int o2v_hip_get_stats(const o2v_hip_ctx *ctx, o2v_hip_stats *out);
 int o2v_hip_get_transform(const o2v_hip_ctx *ctx, float out12[12]);
 
 /* Debugging aid for parity work: hit records of one output cell of the last run, 6 words each
- * (keyhi = sub-voxel<<29 | triangle, keylo = leaf order key, w, u, v as float bits, pool index). */
+ * (keyhi = sub-voxel<<29 | triangle, keylo = leaf order key, w, u, v as float bits, pool index).  The two debug calls
+ * need the hit lists, which the direct MAX path does not keep: they return O2V_HIP_ERR_BAD_ARGUMENT after such a run
+ * (set O2V_NO_DIRECT_MAX=1 in the environment to route every hit through the lists). */
 int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t *out, uint32_t max_records,
                             uint32_t *out_count);
 

@@ -115,6 +115,7 @@ struct o2v_hip_ctx {
 
     // results of the last run
     uint64_t n_vox = 0;
+    bool last_direct = false;  // the last run used the 64-bit max grid: occ[] / sorted[] do not describe every voxel
     o2v_hip_timings timings = {};
     o2v_hip_stats stats = {};
     float xform[12] = {};
@@ -727,6 +728,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->maxgrid_dirty = false;
             const bool direct = p.direct_max && h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
             const uint64_t n_final = direct ? h.n_out : h.n_vox;
+            ctx->last_direct = direct;
             ctx->n_vox = n_final;
             ctx->stats.leaves = h.n_leaves;
             ctx->stats.tiles = h.n_tiles;
@@ -861,6 +863,10 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
 {
     if (!ctx || !out || !out_count) return O2V_HIP_ERR_BAD_ARGUMENT;
     *out_count = 0;
+    if (ctx->last_direct) {
+        ctx->err = "hit lists are not kept on the direct MAX path: run with O2V_NO_DIRECT_MAX=1 to inspect them";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
     O2V_CHECK(hipSetDevice(ctx->device));
     std::vector<Occ> occ(ctx->n_vox);
     std::vector<uint4> vox(ctx->n_vox);
@@ -897,6 +903,10 @@ int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32)
     if (!ctx || !out32) return O2V_HIP_ERR_BAD_ARGUMENT;
     for (int i = 0; i < 32; ++i) out32[i] = 0;
     if (!ctx->n_vox) return O2V_HIP_OK;
+    if (ctx->last_direct) {
+        ctx->err = "hit lists are not kept on the direct MAX path: run with O2V_NO_DIRECT_MAX=1 to inspect them";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
     O2V_CHECK(hipSetDevice(ctx->device));
     std::vector<Occ> occ(ctx->n_vox);
     O2V_CHECK(hipMemcpy(occ.data(), ctx->d_occ, occ.size() * sizeof(Occ), hipMemcpyDeviceToHost));

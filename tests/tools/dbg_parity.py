@@ -1,4 +1,6 @@
 """Developer tool: compare device vs oracle on a case and dump the hit lists of the first mismatching voxel."""
+import os
+os.environ.setdefault("O2V_NO_DIRECT_MAX", "1")  # the hit lists are only kept on the sort-and-replay route
 import ctypes as C
 import struct
 import sys

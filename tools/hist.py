@@ -1,4 +1,6 @@
 """Developer tool: hits-per-cell histogram of the bench workload."""
+import os
+os.environ.setdefault("O2V_NO_DIRECT_MAX", "1")  # the hit lists are only kept on the sort-and-replay route
 import ctypes as C
 import sys
 sys.path.insert(0, '.')

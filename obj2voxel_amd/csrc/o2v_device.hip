@@ -584,13 +584,23 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->d_dirty_max = nullptr;
             ctx->d_dirty_list_max = nullptr;
             ctx->maxgrid_cells = 0;
-            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_maxgrid), cells * sizeof(unsigned long long)));
-            ctx->maxgrid_cells = cells;
-            ctx->maxgrid_brick_cap = (n_bricks + 15u) & ~15ull;
-            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), ctx->maxgrid_brick_cap));
-            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), ctx->maxgrid_brick_cap * sizeof(uint32_t)));
-            ctx->maxgrid_dirty = true;
+            // 8 bytes per cell on top of the counter grid's 4: if that does not fit (4096^3 on one GPU), every hit takes
+            // the sort-and-replay route instead
+            if (hipMalloc(reinterpret_cast<void **>(&ctx->d_maxgrid), cells * sizeof(unsigned long long)) != hipSuccess) {
+                (void) hipGetLastError();
+                ctx->d_maxgrid = nullptr;
+                p.direct_max = 0;
+            }
+            else {
+                ctx->maxgrid_cells = cells;
+                ctx->maxgrid_brick_cap = (n_bricks + 15u) & ~15ull;
+                O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), ctx->maxgrid_brick_cap));
+                O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), ctx->maxgrid_brick_cap * sizeof(uint32_t)));
+                ctx->maxgrid_dirty = true;
+            }
         }
+    }
+    if (p.direct_max) {
         if (ctx->maxgrid_dirty) {
             O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
             O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_brick_cap, ctx->stream));

@@ -167,86 +167,117 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
     if (use_zrange)
         for (int i = 0; i < 12; ++i) use_zrange &= __float_as_uint(zrange_xform[i]) == __float_as_uint(c->xform[i]);
 
+    // One reservation (a handful of global atomics on the same few addresses, which serialise at ~88 per us) per
+    // kRootBatch sub-batches of 256 triangles: the sub-batches are classified twice - first only to count what they
+    // emit, then, with the slots known, to write it.
+    constexpr uint32_t kRootBatch = 4;
     const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
-    for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t n_super = (n_blocks + kRootBatch - 1) / kRootBatch;
+
+    // stages sub-batch `blk` and classifies this lane's triangle of it; false if the whole sub-batch is skipped
+    auto classify = [&](uint64_t blk, Sub &s, Emit &e, LeafPlan &pl, float &area, bool &as_leaf, bool &as_node) -> bool {
+        e = Emit{0, 0, 0, 0};
+        as_leaf = as_node = false;
+        if (blk >= n_blocks) return false;
         if (use_zrange) {
             // every triangle of the block fails misses_slab()'s z test (floor_u32 is monotonic), so none is read
             const float2 r = zrange[blk];
-            if (r.y < 1e9f && (floor_u32(r.y) + 1u <= p.zs0 || floor_u32(r.x) >= p.zs1)) continue;
+            if (r.y < 1e9f && (floor_u32(r.y) + 1u <= p.zs0 || floor_u32(r.x) >= p.zs1)) return false;
         }
         const uint64_t base = blk * kBlock;
         const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
         __syncthreads();
-        if (threadIdx.x == 0) s_cand = 0;
         // coalesced staging of this block's vertices / uvs through LDS
         for (uint32_t i = threadIdx.x; i < n_here * 9; i += kBlock) s_v[i] = verts[base * 9 + i];
         if (p.has_uv)
             for (uint32_t i = threadIdx.x; i < n_here * 6; i += kBlock) s_t[i] = uvs[base * 6 + i];
         __syncthreads();
+        if (threadIdx.x >= n_here) return true;
+        const float *q = &s_v[threadIdx.x * 9];
+        s.v0 = affine_apply(xf, V3{q[0], q[1], q[2]});
+        s.v1 = affine_apply(xf, V3{q[3], q[4], q[5]});
+        s.v2 = affine_apply(xf, V3{q[6], q[7], q[8]});
+        if (p.has_uv) {
+            const float *r = &s_t[threadIdx.x * 6];
+            s.t0 = {r[0], r[1]};
+            s.t1 = {r[2], r[3]};
+            s.t2 = {r[4], r[5]};
+        }
+        if (misses_slab(s, p)) return true;
+        area = tri_area(s.v0, s.v1, s.v2);
+        if (roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit) {
+            pl = plan_leaf(s, p);
+            if (pl.count >> 32) {
+                atomicOr(&c->err_flags, kErrLeafTooLarge);
+            }
+            else if (pl.ntiles) {
+                as_leaf = true;
+                e.n_leaf = 1;
+                e.n_tile = pl.ntiles;
+                e.n_big = pl.ntiles > kInlineTiles ? 1u : 0u;
+            }
+        }
+        else {
+            as_node = true;
+            e.n_node = 1;
+        }
+        return true;
+    };
 
-        const bool live = threadIdx.x < n_here;
+    for (uint64_t sblk = blockIdx.x; sblk < n_super; sblk += gridDim.x) {
         Sub s{};
-        Emit e{0, 0, 0, 0};
+        Emit e{0, 0, 0, 0}, sum{0, 0, 0, 0};
         LeafPlan pl{};
         float area = 0;
         bool as_leaf = false, as_node = false;
-        if (live) {
-            const float *q = &s_v[threadIdx.x * 9];
-            s.v0 = affine_apply(xf, V3{q[0], q[1], q[2]});
-            s.v1 = affine_apply(xf, V3{q[3], q[4], q[5]});
-            s.v2 = affine_apply(xf, V3{q[6], q[7], q[8]});
-            if (p.has_uv) {
-                const float *r = &s_t[threadIdx.x * 6];
-                s.t0 = {r[0], r[1]};
-                s.t1 = {r[2], r[3]};
-                s.t2 = {r[4], r[5]};
-            }
-            if (!misses_slab(s, p)) {
-                area = tri_area(s.v0, s.v1, s.v2);
-                if (roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit) {
-                    pl = plan_leaf(s, p);
-                    if (pl.count >> 32) {
-                        atomicOr(&c->err_flags, kErrLeafTooLarge);
-                    }
-                    else if (pl.ntiles) {
-                        as_leaf = true;
-                        e.n_leaf = 1;
-                        e.n_tile = pl.ntiles;
-                        e.n_big = pl.ntiles > kInlineTiles ? 1u : 0u;
-                    }
-                }
-                else {
-                    as_node = true;
-                    e.n_node = 1;
-                }
-            }
+        // pass 1: what this lane's (up to) four triangles emit
+        for (uint32_t k = 0; k < kRootBatch; ++k) {
+            classify(sblk * kRootBatch + k, s, e, pl, area, as_leaf, as_node);
+            sum.n_leaf += e.n_leaf;
+            sum.n_tile += e.n_tile;
+            sum.n_big += e.n_big;
+            sum.n_node += e.n_node;
         }
-        // a block whose triangles all miss this GPU's slab has nothing to reserve (the common case on the other
+        // a super-block whose triangles all miss this GPU's slab has nothing to reserve (the common case on the other
         // ranks of a multi-GPU run, where every rank filters the whole triangle list)
-        if (!__syncthreads_or((int) (as_leaf || as_node))) continue;
-        BlockSlots slot = reserve_slots(e, c, 0, s_wave, s_base);
-        if (as_leaf) {
-            if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, (uint32_t) (base + threadIdx.x), 0u, area, pl);
-            write_tiles(tiles, big, slot.leaf, slot.tile, pl.ntiles, slot.big, p);
-            atomicAdd(&s_cand, pl.count);
-        }
-        if (as_node && slot.node < p.cap_nodes) {
-            Node n;
-            n.v[0] = s.v0.x; n.v[1] = s.v0.y; n.v[2] = s.v0.z;
-            n.v[3] = s.v1.x; n.v[4] = s.v1.y; n.v[5] = s.v1.z;
-            n.v[6] = s.v2.x; n.v[7] = s.v2.y; n.v[8] = s.v2.z;
-            n.t[0] = s.t0.x; n.t[1] = s.t0.y; n.t[2] = s.t1.x; n.t[3] = s.t1.y; n.t[4] = s.t2.x; n.t[5] = s.t2.y;
-            n.tri = (uint32_t) (base + threadIdx.x);
-            n.pathkey = 0;
-            n.depth = 0;
-            n.area = area;
-            n.pad = 0;
-            nodes_out[slot.node] = n;
+        if (!__syncthreads_or((int) (sum.n_leaf | sum.n_node))) continue;
+        BlockSlots slot = reserve_slots(sum, c, 0, s_wave, s_base);
+        if (threadIdx.x == 0) s_cand = 0;
+        // pass 2: the same triangles again, now written to their slots
+        for (uint32_t k = 0; k < kRootBatch; ++k) {
+            const uint64_t blk = sblk * kRootBatch + k;
+            if (!classify(blk, s, e, pl, area, as_leaf, as_node)) continue;
+            const uint32_t tri = (uint32_t) (blk * kBlock + threadIdx.x);
+            if (as_leaf) {
+                if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, tri, 0u, area, pl);
+                write_tiles(tiles, big, slot.leaf, slot.tile, pl.ntiles, slot.big, p);
+                atomicAdd(&s_cand, pl.count);
+                slot.leaf += 1;
+                slot.tile += pl.ntiles;
+                slot.big += e.n_big;
+            }
+            if (as_node) {
+                if (slot.node < p.cap_nodes) {
+                    Node n;
+                    n.v[0] = s.v0.x; n.v[1] = s.v0.y; n.v[2] = s.v0.z;
+                    n.v[3] = s.v1.x; n.v[4] = s.v1.y; n.v[5] = s.v1.z;
+                    n.v[6] = s.v2.x; n.v[7] = s.v2.y; n.v[8] = s.v2.z;
+                    n.t[0] = s.t0.x; n.t[1] = s.t0.y; n.t[2] = s.t1.x; n.t[3] = s.t1.y; n.t[4] = s.t2.x; n.t[5] = s.t2.y;
+                    n.tri = tri;
+                    n.pathkey = 0;
+                    n.depth = 0;
+                    n.area = area;
+                    n.pad = 0;
+                    nodes_out[slot.node] = n;
+                }
+                slot.node += 1;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
     }
 }
+
 
 // One breadth-first round of forEachSubdividedTriangle (voxelization.cpp:349-379).  The reference pops a LIFO
 // stack: after subdivide4 the centre piece (index 0) replaces the parent and pieces 1,2,3 are pushed, so the

@@ -138,10 +138,25 @@ __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ vert
     Affine a;
     for (int i = 0; i < 3; ++i) a.m[i] = {c->xform[i * 3], c->xform[i * 3 + 1], c->xform[i * 3 + 2]};
     a.t = {c->xform[9], c->xform[10], c->xform[11]};
-    for (uint64_t base = (uint64_t) blockIdx.x * kBlock; base < p.n_tris; base += (uint64_t) gridDim.x * kBlock) {
+    // software pipeline: the next batch's vertices are already on their way (nine loads per lane, in registers) while
+    // this batch is processed from LDS
+    float pre[9];
+    auto prefetch = [&](uint64_t base) {
+        const uint32_t n_f = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock) * 9u;
+#pragma unroll
+        for (uint32_t k = 0; k < 9; ++k) {
+            const uint32_t idx = threadIdx.x + k * kBlock;
+            pre[k] = idx < n_f ? verts[base * 9 + idx] : 0.f;
+        }
+    };
+    const uint64_t first = (uint64_t) blockIdx.x * kBlock, step = (uint64_t) gridDim.x * kBlock;
+    if (first < p.n_tris) prefetch(first);
+    for (uint64_t base = first; base < p.n_tris; base += step) {
         __syncthreads();
         const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
-        for (uint32_t k = threadIdx.x; k < n_here * 9; k += kBlock) s_v[k] = verts[base * 9 + k];
+#pragma unroll
+        for (uint32_t k = 0; k < 9; ++k) s_v[threadIdx.x + k * kBlock] = pre[k];
+        if (base + step < p.n_tris) prefetch(base + step);
         __syncthreads();
         const bool live = threadIdx.x < n_here;
         const float *q = &s_v[(live ? threadIdx.x : 0u) * 9];

@@ -174,23 +174,56 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
     const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
     const uint64_t n_super = (n_blocks + kRootBatch - 1) / kRootBatch;
 
-    // stages sub-batch `blk` and classifies this lane's triangle of it; false if the whole sub-batch is skipped
-    auto classify = [&](uint64_t blk, Sub &s, Emit &e, LeafPlan &pl, float &area, bool &as_leaf, bool &as_node) -> bool {
-        e = Emit{0, 0, 0, 0};
-        as_leaf = as_node = false;
-        if (blk >= n_blocks) return false;
+    // Vertex (and uv) staging is software-pipelined: while one sub-batch is classified from LDS, the loads of the next
+    // one in the sequence are already in flight (15 registers per lane).
+    float pre_v[9], pre_t[6];
+    uint64_t pre_blk = ~0ull;  // the sub-batch whose data is in pre_v / pre_t (block-uniform)
+    auto skipped = [&](uint64_t blk) -> bool {
+        if (blk >= n_blocks) return true;
         if (use_zrange) {
             // every triangle of the block fails misses_slab()'s z test (floor_u32 is monotonic), so none is read
             const float2 r = zrange[blk];
-            if (r.y < 1e9f && (floor_u32(r.y) + 1u <= p.zs0 || floor_u32(r.x) >= p.zs1)) return false;
+            if (r.y < 1e9f && (floor_u32(r.y) + 1u <= p.zs0 || floor_u32(r.x) >= p.zs1)) return true;
         }
+        return false;
+    };
+    auto prefetch = [&](uint64_t blk) {
+        pre_blk = ~0ull;
+        if (skipped(blk)) return;
+        const uint64_t base = blk * kBlock;
+        const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
+#pragma unroll
+        for (uint32_t k = 0; k < 9; ++k) {
+            const uint32_t idx = threadIdx.x + k * kBlock;
+            pre_v[k] = idx < n_here * 9u ? verts[base * 9 + idx] : 0.f;
+        }
+        if (p.has_uv) {
+#pragma unroll
+            for (uint32_t k = 0; k < 6; ++k) {
+                const uint32_t idx = threadIdx.x + k * kBlock;
+                pre_t[k] = idx < n_here * 6u ? uvs[base * 6 + idx] : 0.f;
+            }
+        }
+        pre_blk = blk;
+    };
+
+    // stages sub-batch `blk` (prefetching `next`) and classifies this lane's triangle of it; false if the whole
+    // sub-batch is skipped
+    auto classify = [&](uint64_t blk, uint64_t next, Sub &s, Emit &e, LeafPlan &pl, float &area, bool &as_leaf, bool &as_node) -> bool {
+        e = Emit{0, 0, 0, 0};
+        as_leaf = as_node = false;
+        if (skipped(blk)) return false;
+        if (pre_blk != blk) prefetch(blk);
         const uint64_t base = blk * kBlock;
         const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
         __syncthreads();
-        // coalesced staging of this block's vertices / uvs through LDS
-        for (uint32_t i = threadIdx.x; i < n_here * 9; i += kBlock) s_v[i] = verts[base * 9 + i];
-        if (p.has_uv)
-            for (uint32_t i = threadIdx.x; i < n_here * 6; i += kBlock) s_t[i] = uvs[base * 6 + i];
+#pragma unroll
+        for (uint32_t k = 0; k < 9; ++k) s_v[threadIdx.x + k * kBlock] = pre_v[k];
+        if (p.has_uv) {
+#pragma unroll
+            for (uint32_t k = 0; k < 6; ++k) s_t[threadIdx.x + k * kBlock] = pre_t[k];
+        }
+        prefetch(next);
         __syncthreads();
         if (threadIdx.x >= n_here) return true;
         const float *q = &s_v[threadIdx.x * 9];
@@ -232,7 +265,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         bool as_leaf = false, as_node = false;
         // pass 1: what this lane's (up to) four triangles emit
         for (uint32_t k = 0; k < kRootBatch; ++k) {
-            classify(sblk * kRootBatch + k, s, e, pl, area, as_leaf, as_node);
+            const uint64_t blk = sblk * kRootBatch + k;
+            // after the last sub-batch of this pass comes the first one again (pass 2)
+            classify(blk, k + 1 < kRootBatch ? blk + 1 : sblk * kRootBatch, s, e, pl, area, as_leaf, as_node);
             sum.n_leaf += e.n_leaf;
             sum.n_tile += e.n_tile;
             sum.n_big += e.n_big;
@@ -246,7 +281,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         // pass 2: the same triangles again, now written to their slots
         for (uint32_t k = 0; k < kRootBatch; ++k) {
             const uint64_t blk = sblk * kRootBatch + k;
-            if (!classify(blk, s, e, pl, area, as_leaf, as_node)) continue;
+            // ... and after the last one of pass 2 the first sub-batch of this workgroup's next super-block
+            const uint64_t next = k + 1 < kRootBatch ? blk + 1 : (sblk + gridDim.x) * kRootBatch;
+            if (!classify(blk, next, s, e, pl, area, as_leaf, as_node)) continue;
             const uint32_t tri = (uint32_t) (blk * kBlock + threadIdx.x);
             if (as_leaf) {
                 if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, tri, 0u, area, pl);

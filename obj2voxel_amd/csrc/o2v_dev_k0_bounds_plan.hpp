@@ -25,6 +25,7 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float *__restrict__ ver
     float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
     const uint64_t n_groups = n_floats / 12;
     const float4 *v4 = reinterpret_cast<const float4 *>(verts);
+#pragma unroll 4
     for (uint64_t g = (uint64_t) blockIdx.x * kBlock + threadIdx.x; g < n_groups; g += (uint64_t) gridDim.x * kBlock) {
         const float4 a = v4[g * 3], b = v4[g * 3 + 1], d = v4[g * 3 + 2];
         const float e[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w};

@@ -243,6 +243,12 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     bool run_general = true, run_emit = false;
     if (p.direct_max) {
         O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        // listing the dirty bricks of the 64-bit grid does not depend on the decision (k_voxelize flags them for pooled
+        // hits too), so it runs while the host waits for the counters
+        const uint32_t max_flag_groups = (p.n_bricks + 15u) / 16u;
+        hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (max_flag_groups + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, p);
+        O2V_STAGE("k_scan_flags (max)");
         O2V_CHECK(hipStreamSynchronize(s));
         const Counters &h = *ctx->h_ctr;
         run_emit = h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
@@ -324,10 +330,6 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     {
         if (run_emit) {
             // every voxel's winner is in the 64-bit grid now (k_voxelize: unsplit triangles, resolve: the rest)
-            const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
-            hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),
-                               dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, p);
-            O2V_STAGE("k_scan_flags (max)");
             hipLaunchKernelGGL(k_emit_max, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
                                ctx->d_out, p);
             O2V_STAGE("k_emit_max");

@@ -55,6 +55,11 @@ struct __attribute__((aligned(16))) HitRec {  // 32 B: one (leaf, voxel) hit as 
     uint32_t pad;
 };
 constexpr uint32_t kHoleBrick = 0xffffffffu;
+struct PickRec {  // 24 B: {cell lo, cell hi, keyhi, weight bits, argb, 0}
+    uint32_t w[6];
+};
+constexpr uint32_t kPickRecord = 1u;  // HitRec::pad of a direct hit's {cell, key, argb (in keylo)} record (textured MAX)
+constexpr unsigned long long kPickTag = 1ull << 63;  // a max-grid cell that already holds its final argb (low word)
 constexpr uint32_t kMaxRank = 1u << 24;
 
 struct __attribute__((aligned(8))) SortedRec {  // 24 B: the same hit, placed contiguously with its cell's other hits
@@ -90,6 +95,14 @@ struct DevTexture {
     uint32_t width, height, channels, wrap;
 };
 
+struct Materials {
+    const uint32_t *types;   // nullable: all MATERIALLESS
+    const float *colors;     // nullable
+    const int32_t *texids;   // nullable: all 0
+    const DevTexture *textures;
+    uint32_t n_textures;
+};
+
 struct Counters {
     uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
     uint32_t n_vox, batch_cursor, err_flags, n_lane16;
@@ -100,7 +113,8 @@ struct Counters {
     uint32_t n_w64, n_dirty_max, n_out;
     unsigned long long n_candidates, n_hits;
     uint32_t bounds_enc[6];
-    uint32_t n_root_leaves, pad2;  // root triangles that became leaves as they are (the others are in n_nodes[0])
+    uint32_t n_root_leaves, pad2;  // root triangles that became leaves as they are (the others are in n_nodes[0]);
+                                   // pad2: k_tri_extent's result at upload time, pick records of the replay tiers in a pass
     unsigned long long n_direct;
     float xform[12];
 };
@@ -129,6 +143,11 @@ struct Params {
     // Direct MAX path (MAX strategy, no textured triangle; section 4 of DESIGN.md): one 64-bit cell per output voxel that
     // holds max over {weight bits << 32 | ~(sub-voxel << 29 | triangle)}, and its own dirty-brick map.
     uint32_t direct_max;
+    // ... with textured triangles ("pick" variant): k_voxelize also samples the colour of a direct hit and keeps a
+    // {cell, key, argb} record; k_pick later gives every cell whose winner it was that colour.
+    uint32_t pick_max;
+    Materials mat;
+    uint32_t *pick_extra;  // the same records for the winners of cells resolved by replay: 6 words each, cap_vox of them
     unsigned long long *maxgrid;
     uint8_t *dirty_max;
 };
@@ -202,3 +221,45 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wave /*
     total = tot;
     return base + inc - v;
 }
+
+// colorAt_f, triangle.hpp:181-194 (+ texture get, triangle.hpp:161-166; getPixel semantics: see DESIGN.md)
+__device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float u, float v, float &r, float &g, float &b)
+{
+    const uint32_t type = m.types ? m.types[tri] : (uint32_t) kTriMaterialless;
+    if (type == kTriMaterialless) {
+        r = g = b = 1.f;
+    }
+    else if (type == kTriUntextured) {
+        r = m.colors ? m.colors[(size_t) tri * 3 + 0] : 0.f;
+        g = m.colors ? m.colors[(size_t) tri * 3 + 1] : 0.f;
+        b = m.colors ? m.colors[(size_t) tri * 3 + 2] : 0.f;
+    }
+    else if (type == kTriTextured && m.n_textures) {
+        uint32_t id = m.texids ? (uint32_t) m.texids[tri] : 0u;
+        if (id >= m.n_textures) id = 0;
+        const DevTexture tx = m.textures[id];
+        float tu = u, tv = 1 - v;
+        if (tx.wrap) {
+            tu = tu - floor_f(tu);
+            tv = tv - floor_f(tv);
+        }
+        else {
+            tu = tu < 0.f ? 0.f : (tu > 1.f ? 1.f : tu);
+            tv = tv < 0.f ? 0.f : (tv > 1.f ? 1.f : tv);
+        }
+        uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
+        if (px >= tx.width) px = tx.width - 1;
+        if (py >= tx.height) py = tx.height - 1;
+        const uint8_t *q = tx.pixels + ((size_t) py * tx.width + px) * tx.channels;
+        const uint32_t o = tx.channels == 4 ? 1u : 0u;
+        r = (float) q[o] / 255.f;
+        g = (float) q[o + 1] / 255.f;
+        b = (float) q[o + 2] / 255.f;
+    }
+    else {
+        r = 1.f;
+        g = 0.f;
+        b = 1.f;
+    }
+}
+

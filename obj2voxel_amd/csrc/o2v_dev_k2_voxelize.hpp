@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits, s_direct;
 
     if (expand_overflowed(c, p)) return;
-    const bool use_direct = !UV && direct_active(c, p);
+    const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
     // Batch size: about six batches per workgroup, between one tile per wavefront and what the LDS staging holds.  Few
     // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
@@ -396,7 +396,8 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 // this (sub-)voxel, so it competes at once - one 64-bit atomic max on the cell, no hit record.  Hits of
                 // subdivided triangles still go through the pool (their leaves' weights must be added up in order first).
                 const bool direct = d_valid && use_direct && s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u;
-                const bool pooled = d_valid && !direct;
+                // with textures a direct hit still leaves a record behind: {cell, key, colour} for k_pick
+                const bool pooled = d_valid && (UV || !direct);
                 const unsigned long long mask = __ballot(pooled);
                 const uint32_t cnt = (uint32_t) __popcll(mask);
                 const uint32_t leader = mask ? (uint32_t) __ffsll((long long) mask) - 1u : 0u;
@@ -425,6 +426,13 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                     if (direct) {
                         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
                         p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
+                        if (UV && mine < p.cap_hits) {
+                            // moveUvBufferIntoVoxels' colour of this (triangle, voxel) pair (voxelization.cpp:513-526); the
+                            // triangle is unsplit, so (d_u, d_v) already is its whole uv mean in this voxel
+                            float cr, cg, cb;
+                            color_at(p.mat, lf[18], d_u, d_v, cr, cg, cb);
+                            pool[mine] = HitRec{brick, ((uint32_t) cell & 255u) << 24, keyhi, pack_argb(cr, cg, cb), d_w, 0.f, 0.f, kPickRecord};
+                        }
                     }
                     else if (mine < p.cap_hits) {
                         // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets

@@ -5,55 +5,6 @@
 
 // ---- K3: resolve ---------------------------------------------------------------------------------------------
 
-struct Materials {
-    const uint32_t *types;   // nullable: all MATERIALLESS
-    const float *colors;     // nullable
-    const int32_t *texids;   // nullable: all 0
-    const DevTexture *textures;
-    uint32_t n_textures;
-};
-
-// colorAt_f, triangle.hpp:181-194 (+ texture get, triangle.hpp:161-166; getPixel semantics: see DESIGN.md)
-__device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float u, float v, float &r, float &g, float &b)
-{
-    const uint32_t type = m.types ? m.types[tri] : (uint32_t) kTriMaterialless;
-    if (type == kTriMaterialless) {
-        r = g = b = 1.f;
-    }
-    else if (type == kTriUntextured) {
-        r = m.colors ? m.colors[(size_t) tri * 3 + 0] : 0.f;
-        g = m.colors ? m.colors[(size_t) tri * 3 + 1] : 0.f;
-        b = m.colors ? m.colors[(size_t) tri * 3 + 2] : 0.f;
-    }
-    else if (type == kTriTextured && m.n_textures) {
-        uint32_t id = m.texids ? (uint32_t) m.texids[tri] : 0u;
-        if (id >= m.n_textures) id = 0;
-        const DevTexture tx = m.textures[id];
-        float tu = u, tv = 1 - v;
-        if (tx.wrap) {
-            tu = tu - floor_f(tu);
-            tv = tv - floor_f(tv);
-        }
-        else {
-            tu = tu < 0.f ? 0.f : (tu > 1.f ? 1.f : tu);
-            tv = tv < 0.f ? 0.f : (tv > 1.f ? 1.f : tv);
-        }
-        uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
-        if (px >= tx.width) px = tx.width - 1;
-        if (py >= tx.height) py = tx.height - 1;
-        const uint8_t *q = tx.pixels + ((size_t) py * tx.width + px) * tx.channels;
-        const uint32_t o = tx.channels == 4 ? 1u : 0u;
-        r = (float) q[o] / 255.f;
-        g = (float) q[o + 1] / 255.f;
-        b = (float) q[o + 2] / 255.f;
-    }
-    else {
-        r = 1.f;
-        g = 0.f;
-        b = 1.f;
-    }
-}
-
 // ---- ordered replay of one cell's hits --------------------------------------------------------------------------
 // The hits of a cell arrive in arbitrary order; the reference's result is a sequential fold, so they are
 // replayed in the reference's order, i.e. ascending in the key (sub-voxel, triangle index, leaf order):
@@ -123,6 +74,19 @@ __device__ __forceinline__ void emit_cell(const Occ &o, uint32_t argb, float w, 
     if (direct_active(c, p)) {
         const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(w) << 32) | (0xffffffffu - keyhi));
+        if (p.pick_max) {
+            // textured mesh: the colour is known here, the winner of the cell only later (k_pick)
+            const uint32_t slot = atomicAdd(const_cast<uint32_t *>(&c->pad2), 1u);
+            if (slot < p.cap_vox) {
+                uint32_t *q = p.pick_extra + (size_t) slot * 6u;
+                q[0] = o.cell_lo;
+                q[1] = o.cell_hi;
+                q[2] = keyhi;
+                q[3] = __float_as_uint(w);
+                q[4] = argb;
+                q[5] = 0u;
+            }
+        }
     }
     else {
         out[i] = cell_record(o, argb, p);
@@ -609,6 +573,29 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
 // unsplit triangles, the resolve kernels add the summed-up subdivided ones, and this kernel turns every non-zero
 // cell of the dirty bricks into its (x, y, z, argb) record and zeroes it again (moveUvBufferIntoVoxels + the pack of
 // obj2voxel.cpp:279-297).  Records are staged in LDS so that a workgroup reserves output space once per ~2048 voxels.
+// Textured MAX: every record {cell, key, argb} - left by k_voxelize for direct hits (in the hit pool) and by the replay
+// tiers for the cells they resolved - is compared with the final maximum of its cell; the one that won replaces it by
+// its colour.  Keys are unique per cell, so exactly one record matches and nothing races.
+__global__ __launch_bounds__(kBlock) void k_pick(const HitRec *__restrict__ pool, const Counters *c, Params p)
+{
+    if (!direct_active(c, p)) return;
+    const uint32_t n = c->n_hits_reserved < p.cap_hits ? c->n_hits_reserved : p.cap_hits;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const HitRec r = pool[i];
+        if (r.brick == kHoleBrick || r.pad != kPickRecord) continue;
+        const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
+        const unsigned long long key = ((unsigned long long) __float_as_uint(r.w) << 32) | (0xffffffffu - r.keyhi);
+        if (p.maxgrid[cell] == key) p.maxgrid[cell] = kPickTag | r.keylo;
+    }
+    const uint32_t n2 = c->pad2 < p.cap_vox ? c->pad2 : p.cap_vox;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {
+        const uint32_t *q = p.pick_extra + (size_t) i * 6u;
+        const uint64_t cell = ((uint64_t) q[1] << 32) | q[0];
+        const unsigned long long key = ((unsigned long long) q[3] << 32) | (0xffffffffu - q[2]);
+        if (p.maxgrid[cell] == key) p.maxgrid[cell] = kPickTag | q[4];
+    }
+}
+
 constexpr uint32_t kEmitBricksPerWave = 2;
 constexpr uint32_t kEmitBricksPerRound = (kBlock / 64) * kEmitBricksPerWave;
 constexpr uint32_t kEmitFlushAt = 2048;
@@ -664,12 +651,19 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
                 for (uint32_t e = 0; e < 4; ++e) {
                     if (v4[e]) {
                         const uint32_t local = lane * 4u + e;
-                        const uint32_t keyhi = 0xffffffffu - (uint32_t) v4[e];
-                        float cr, cg, cb;
-                        color_at(m, keyhi & 0x1fffffffu, 0.f, 0.f, cr, cg, cb);
+                        uint32_t argb;
+                        if (v4[e] & kPickTag) {
+                            argb = (uint32_t) v4[e];  // textured mesh: k_pick already put the winner's colour here
+                        }
+                        else {
+                            const uint32_t keyhi = 0xffffffffu - (uint32_t) v4[e];
+                            float cr, cg, cb;
+                            color_at(m, keyhi & 0x1fffffffu, 0.f, 0.f, cr, cg, cb);
+                            argb = pack_argb(cr, cg, cb);
+                        }
                         const uint32_t slot = atomicAdd(&s_n, 1u);
                         s_rec[slot] = make_uint4(bx * kBrickX + (local & 15u), by * kBrickY + ((local >> 4) & 3u),
-                                                 bz * kBrickZ + (local >> 6) + p.zo0, pack_argb(cr, cg, cb));
+                                                 bz * kBrickZ + (local >> 6) + p.zo0, argb);
                     }
                 }
                 // leave the cells clean for the next run

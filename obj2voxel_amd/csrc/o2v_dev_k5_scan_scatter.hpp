@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ p
     const uint32_t lo = xcd * per, hi = lo + per < n ? lo + per : n;
     for (uint32_t i = lo + local_block * kBlock + threadIdx.x; i < hi; i += blocks_per_xcd * kBlock) {
         const HitRec r = pool[i];
-        if (r.brick == kHoleBrick) continue;
+        if (r.brick == kHoleBrick || r.pad == kPickRecord) continue;
         const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
         const uint32_t pos = grid[cell] + (r.local_rank & (kMaxRank - 1u));
         if (pos < p.cap_hits) {

@@ -105,6 +105,8 @@ struct o2v_hip_ctx {
     uint64_t grid_cells = 0;      // allocated
     uint8_t *d_brick_dirty = nullptr;   // one flag per brick (padded to 16 bytes)
     uint32_t *d_dirty_list = nullptr;   // dirty brick ids of the current run
+    uint32_t cap_pick_extra = 0;
+    PickRec *d_pick_extra = nullptr;  // textured MAX: {cell, key, argb} of the cells resolved by replay (6 words, cap_vox of them)
     unsigned long long *d_maxgrid = nullptr;  // direct MAX path: one 64-bit cell per output voxel (same bricked layout)
     uint8_t *d_dirty_max = nullptr;           // ... its dirty-brick flags and list
     uint32_t *d_dirty_list_max = nullptr;
@@ -252,7 +254,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         O2V_CHECK(hipStreamSynchronize(s));
         const Counters &h = *ctx->h_ctr;
         run_emit = h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
-        run_general = !run_emit || h.n_hits_reserved != 0;
+        run_general = !run_emit || h.n_hits != h.n_direct;  // some hit took the pool -> sort -> replay route
     }
 
     if (run_general) {
@@ -328,6 +330,10 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             }
     }
     {
+        if (run_emit && p.pick_max) {
+            hipLaunchKernelGGL(k_pick, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_ctr, p);
+            O2V_STAGE("k_pick");
+        }
         if (run_emit) {
             // every voxel's winner is in the 64-bit grid now (k_voxelize: unsplit triangles, resolve: the rest)
             hipLaunchKernelGGL(k_emit_max, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
@@ -403,7 +409,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
                     ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid,
                     ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
-                    ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max};
+                    ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
     for (uint8_t *q : ctx->d_texpix)
@@ -576,7 +582,9 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     // Direct MAX path: MAX strategy and no textured triangle
     {
         const char *off = std::getenv("O2V_NO_DIRECT_MAX");
-        p.direct_max = (params->strategy == 0u && !use_uv && !(off && off[0] == '1')) ? 1u : 0u;
+        p.direct_max = (params->strategy == 0u && !(off && off[0] == '1')) ? 1u : 0u;
+        p.pick_max = (p.direct_max && use_uv) ? 1u : 0u;  // textured: the winner's colour is picked afterwards (k_pick)
+        p.mat = Materials{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
     }
     if (p.direct_max) {
         if (cells > ctx->maxgrid_cells || !ctx->d_maxgrid) {
@@ -592,6 +600,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
                 (void) hipGetLastError();
                 ctx->d_maxgrid = nullptr;
                 p.direct_max = 0;
+                p.pick_max = 0;
             }
             else {
                 ctx->maxgrid_cells = cells;
@@ -682,6 +691,12 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
+        if (p.pick_max) {
+            uint32_t cap_px = ctx->cap_pick_extra;
+            if ((rc = grow(ctx, ctx->d_pick_extra, cap_px, want_vox))) return rc;
+            ctx->cap_pick_extra = cap_px;
+            p.pick_extra = reinterpret_cast<uint32_t *>(ctx->d_pick_extra);
+        }
         for (uint32_t **lp : {&ctx->d_list_lane16, &ctx->d_list_w64, &ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
             uint32_t cap_l = ctx->cap_vox;
             if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;

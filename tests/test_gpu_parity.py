@@ -419,3 +419,28 @@ def test_direct_max_path_mixes_whole_and_subdivided_triangles(dv, oracle, supers
     got, want = _run_both(dv, oracle, v, 96, **kw)
     _compare(got, want)
     assert dv.stats()["direct_hits"] == 0
+
+
+@pytest.mark.parametrize("supersampling,wrap", [(1, 1), (2, 0)])
+def test_direct_max_path_with_textures(dv, oracle, supersampling, wrap):
+    """MAX strategy with textured triangles: direct hits also leave a {cell, key, colour} record and k_pick gives every
+    cell the colour of the record that won. A fine textured sphere (unsplit triangles) mixed with a few large textured
+    and coloured triangles (subdivided: their winners come from the replay tiers)."""
+    from obj2voxel_amd import hip
+    rng = np.random.default_rng(5)
+    v, uv = meshes.uv_sphere(48, with_uv=True)
+    big = (rng.random((5, 9)) * 1.6 - 0.8).astype(np.float32)
+    big_uv = rng.random((5, 6)).astype(np.float32)
+    verts = np.concatenate([np.reshape(v, (-1, 9)), big])
+    uvs = np.concatenate([np.reshape(uv, (-1, 6)), big_uv])
+    T = len(verts)
+    types = np.full(T, hip.TRI_TEXTURED, np.uint32)
+    types[::7] = hip.TRI_UNTEXTURED
+    types[-2] = hip.TRI_MATERIALLESS
+    kw = dict(uvs=uvs, types=types, colors=rng.random((T, 3)).astype(np.float32), texids=(np.arange(T) % 2).astype(np.int32),
+              textures=[(meshes.checker_texture(64, 8), wrap), (rng.integers(0, 256, (9, 5, 4)).astype(np.uint8), 1 - wrap)],
+              strategy=0, supersampling=supersampling)
+    got, want = _run_both(dv, oracle, verts, 112, **kw)
+    _compare(got, want)
+    st = dv.stats()
+    assert 0 < st["direct_hits"] < st["hits"]

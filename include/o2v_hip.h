@@ -78,7 +78,7 @@ typedef struct {
     uint64_t bricks;      /* bricks of the slab */
     uint64_t dirty_bricks;/* bricks that received at least one hit */
     uint64_t pool_slots;  /* hit-pool slots reserved (hits + chunk slack) */
-    uint64_t direct_hits; /* hits that went straight into the 64-bit max grid (MAX strategy, no textured triangle) */
+    uint64_t direct_hits; /* hits that went straight into the 64-bit max grid (MAX strategy, unsplit triangles) */
 } o2v_hip_stats;
 
 int o2v_hip_device_count(void);

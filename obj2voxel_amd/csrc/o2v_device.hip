@@ -13,7 +13,7 @@
 //       k_expand_big           tiles of <= 256 candidate voxels for large leaves
 //   K2  k_voxelize<UV>         AABB walk + plane cull (voxelization.cpp:426-472) + six-plane clip by triangle
 //                              splitting (voxelization.cpp:175-331,383-424).  A hit either goes straight into the
-//                              64-bit max grid (MAX strategy, no textures, unsplit triangle: one atomicMax) or is
+//                              64-bit max grid (MAX strategy, unsplit triangle: one atomicMax) or is
 //                              appended to the hit pool and counted in its cell (atomicAdd on the dense grid -> rank)
 //   K5  k_scan_flags/_bricks   reads the dirty bricks of the dense grid, compacts occupied cells, turns the
 //                              per-cell counts into offsets (counting sort); k_scatter places the pooled hits
@@ -21,7 +21,7 @@
 //                              (sub-voxel, triangle index, leaf order), replays insertWeighted
 //                              (voxelization.cpp:56-63,466-468) and moveUvBufferIntoVoxels (:513-526) with
 //                              MAX / BLEND, then packs (x, y, z, argb) (obj2voxel.cpp:279-297);
-//       k_emit_max             direct MAX path: turns the 64-bit max grid into the records
+//       k_pick / k_emit_max    direct MAX path: winner colours of textured meshes; the 64-bit max grid -> records
 //   plan k_zhist               o2v_hip_plan_slabs: predicted hits per z layer -> work-balanced slabs for N GPUs
 // With the direct MAX path the host looks at the counters once after K2 and launches only the stages that have work.
 //
@@ -579,7 +579,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
         ctx->grid_dirty = false;
     }
-    // Direct MAX path: MAX strategy and no textured triangle
+    // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
     {
         const char *off = std::getenv("O2V_NO_DIRECT_MAX");
         p.direct_max = (params->strategy == 0u && !(off && off[0] == '1')) ? 1u : 0u;

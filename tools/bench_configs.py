@@ -58,6 +58,8 @@ def main():
     T = len(v)
     run(dv, "config4: room+sphere (%d tris) @2048 x2 supersampling textured BLEND" % T, v, 2048, uvs=uv,
         types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32), textures=tex, strategy=1, supersampling=2, steps=3)
+    run(dv, "config4 with MAX: room+sphere (%d tris) @2048 x2 supersampling textured MAX" % T, v, 2048, uvs=uv,
+        types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32), textures=tex, strategy=0, supersampling=2, steps=3)
 
 
 if __name__ == "__main__":

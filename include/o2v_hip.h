@@ -130,6 +130,10 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
 /* Debugging aid: log2 histogram of hits per occupied cell of the last run (32 buckets; bucket b: 2^(b-1) < hits <= 2^b). */
 int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32);
 
+/* Debugging aid for kernel work: 16 event counters of the clip loop of the last run.  All zero unless the library was
+ * built with -DO2V_INSTRUMENT (make INSTR=1, tools/instrument.sh); the meaning of each slot is documented there. */
+int o2v_hip_debug_counters(const o2v_hip_ctx *ctx, uint64_t *out16);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,9 +26,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("O2V_LIB") or LIB_PATH  # O2V_LIB: a developer build (e.g. the instrumented library)
+        if not os.path.exists(path):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(obj2voxel_amd has no CPU fallback)")
-        _lib = C.CDLL(LIB_PATH)
+        _lib = C.CDLL(path)
     return _lib

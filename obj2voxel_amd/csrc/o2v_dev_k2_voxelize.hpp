@@ -254,6 +254,9 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
+#ifdef O2V_INSTRUMENT
+    uint32_t dbgc[16] = {};
+#endif
     if (threadIdx.x == 0) {
         s_hits = 0;
         s_direct = 0;
@@ -451,7 +454,13 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 }
                 d_valid = false;
             };
+#ifdef O2V_INSTRUMENT
+#define O2V_EV(i, cond) do { if (cond) dbgc[i] += 1u; } while (0)
+#else
+#define O2V_EV(i, cond) do { } while (0)
+#endif
             for (;;) {
+                O2V_EV(0, lane == 0);
                 // pop a pending sibling, or fetch the next survivor
                 if (!active) {
                     if (pending) {
@@ -514,6 +523,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                         }
                     }
                 }
+                O2V_EV(1, active);
                 if (active) {
                     // Skip ahead: a piece whose vertices all satisfy v >= plane (lower planes) or v < plane (upper
                     // planes) is the loSum == 0 / loSum == 3 case of splitTriangle (voxelization.cpp:194-205) and
@@ -527,7 +537,40 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                     fail |= (mx.y < fy + 1.0f) ? 0u : 16u;
                     fail |= (mx.z < fz + 1.0f) ? 0u : 32u;
                     fail &= ~((1u << level) - 1u);
+#ifdef O2V_INSTRUMENT
+                    // the same test with a margin: planes the piece clears by more than kTrivialMargin
+                    uint32_t failm = 0;
+                    failm |= (mn.x >= fx + 0.02f) ? 0u : 1u;
+                    failm |= (mn.y >= fy + 0.02f) ? 0u : 2u;
+                    failm |= (mn.z >= fz + 0.02f) ? 0u : 4u;
+                    failm |= (mx.x <= fx + 0.98f) ? 0u : 8u;
+                    failm |= (mx.y <= fy + 0.98f) ? 0u : 16u;
+                    failm |= (mx.z <= fz + 0.98f) ? 0u : 32u;
+                    auto dbg_fail = [&](const Piece<UV> &q, uint32_t from) {
+                        const V3 qn = tri_min(q.a, q.b, q.c), qx = tri_max(q.a, q.b, q.c);
+                        uint32_t f = 0;
+                        f |= (qn.x >= fx) ? 0u : 1u;
+                        f |= (qn.y >= fy) ? 0u : 2u;
+                        f |= (qn.z >= fz) ? 0u : 4u;
+                        f |= (qx.x < fx + 1.0f) ? 0u : 8u;
+                        f |= (qx.y < fy + 1.0f) ? 0u : 16u;
+                        f |= (qx.z < fz + 1.0f) ? 0u : 32u;
+                        return f & ~((1u << from) - 1u);
+                    };
+                    auto dbg_out = [&](const Piece<UV> &q, uint32_t from) {  // wholly on the discard side of a later plane
+                        const V3 qn = tri_min(q.a, q.b, q.c), qx = tri_max(q.a, q.b, q.c);
+                        uint32_t f = 0;
+                        f |= (qx.x < fx - 0.02f) ? 1u : 0u;
+                        f |= (qx.y < fy - 0.02f) ? 2u : 0u;
+                        f |= (qx.z < fz - 0.02f) ? 4u : 0u;
+                        f |= (qn.x > fx + 1.02f) ? 8u : 0u;
+                        f |= (qn.y > fy + 1.02f) ? 16u : 0u;
+                        f |= (qn.z > fz + 1.02f) ? 32u : 0u;
+                        return f & ~((1u << from) - 1u);
+                    };
+#endif
                     if (fail == 0) {
+                        O2V_EV(2, true);
                         accumulate_piece<UV>(cur, area, w, u, v);  // inside all remaining planes
                         active = false;
                     }
@@ -540,18 +583,34 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                         if ((cls & kClsModeMask) == 0u) {
                             // whole triangle to one side (all-lo/all-hi or one of the planar special cases)
                             if (((cls & kClsSideLo) != 0) == keep_lo) {
+                                O2V_EV(3, level < 5u);
+                                O2V_EV(10, level < 5u && (fail >> (level + 1u)) == 0u);
                                 level += 1u;
                                 if (level == 6u) {
+                                    O2V_EV(4, true);
                                     accumulate_piece<UV>(cur, area, w, u, v);
                                     active = false;
                                 }
                             }
                             else {
+                                O2V_EV(5, true);
                                 active = false;  // discarded
                             }
                         }
                         else {
+                            O2V_EV(6, level == 5u);
+                            O2V_EV(7, level < 5u);
+                            O2V_EV(8, level < 5u && (failm >> (level + 1u)) == 0u);
                             const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo);
+                            O2V_EV(9, level < 5u && n == 2);
+#ifdef O2V_INSTRUMENT
+                            if (level < 5u && (failm >> (level + 1u)) != 0u) {
+                                O2V_EV(11, dbg_fail(cur, level + 1u) == 0u);
+                                O2V_EV(12, n == 2 && dbg_fail(sec, level + 1u) == 0u);
+                                O2V_EV(13, dbg_out(cur, level + 1u) != 0u);
+                                O2V_EV(14, n == 2 && dbg_out(sec, level + 1u) != 0u);
+                            }
+#endif
                             if (level == 5u) {
                                 accumulate_piece<UV>(cur, area, w, u, v);
                                 if (n == 2) accumulate_piece<UV>(sec, area, w, u, v);
@@ -593,6 +652,13 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     // the unused tail of this wavefront's last chunk holds no hits
     for (uint32_t k = chunk_used + lane; k < kHitChunk; k += 64)
         if (chunk_used != kHitChunk && chunk_base + k < p.cap_hits) pool[chunk_base + k].brick = kHoleBrick;
+#ifdef O2V_INSTRUMENT
+    for (uint32_t k = 0; k < 16; ++k) {
+        uint32_t t = dbgc[k];
+        for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+        if (lane == 0 && t) atomicAdd(&c->dbg[k], (unsigned long long) t);
+    }
+#endif
     __syncthreads();
     if (threadIdx.x == 0 && s_hits) atomicAdd(&c->n_hits, (unsigned long long) s_hits);
     if (threadIdx.x == 0 && s_direct) atomicAdd(&c->n_direct, (unsigned long long) s_direct);

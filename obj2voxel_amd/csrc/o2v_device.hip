@@ -121,6 +121,7 @@ struct o2v_hip_ctx {
     o2v_hip_timings timings = {};
     o2v_hip_stats stats = {};
     float xform[12] = {};
+    uint64_t dbg[16] = {};  // Counters::dbg of the last run (instrumented builds only)
 };
 
 namespace {
@@ -767,6 +768,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->stats.dirty_bricks = direct ? h.n_dirty_max : h.n_dirty;
             ctx->stats.pool_slots = h.n_hits_reserved;
             std::memcpy(ctx->xform, h.xform, sizeof(ctx->xform));
+            for (int i = 0; i < 16; ++i) ctx->dbg[i] = h.dbg[i];
             float ms[5];
             for (int i = 0; i < 5; ++i) O2V_CHECK(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
             ctx->timings.bounds_ms = ms[0];
@@ -942,6 +944,13 @@ int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32)
         while ((1u << b) < o.count && b < 31) ++b;
         out32[b]++;
     }
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_debug_counters(const o2v_hip_ctx *ctx, uint64_t *out16)
+{
+    if (!ctx || !out16) return O2V_HIP_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < 16; ++i) out16[i] = ctx->dbg[i];
     return O2V_HIP_OK;
 }
 

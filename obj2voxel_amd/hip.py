@@ -54,6 +54,7 @@ def _bind():
     L.o2v_hip_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     L.o2v_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.o2v_hip_get_transform.argtypes = [C.c_void_p, C.c_void_p]
+    L.o2v_hip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
     L.o2v_hip_plan_slabs.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_void_p]
     return L
 
@@ -161,6 +162,11 @@ class DeviceVoxelizer:
         s = Stats()
         self._L.o2v_hip_get_stats(self._ctx, C.byref(s))
         return s.as_dict()
+
+    def debug_counters(self):
+        out = np.zeros(16, dtype=np.uint64)
+        self._L.o2v_hip_debug_counters(self._ctx, _ptr(out))
+        return out
 
     def transform(self):
         out = np.zeros(12, dtype=np.float32)

@@ -808,8 +808,17 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
             /* voxelizeChunk for every chunk, obj2voxel.cpp:254-314,503-505 */
             size_t n_work = 0;
             size_t *work = (size_t *) malloc(sizeof(size_t) * (nchunks ? nchunks : 1));
-            for (size_t c = 0; c < nchunks; ++c)
-                if (chunk_start[c] != chunk_start[c + 1]) work[n_work++] = c;
+            for (size_t c = 0; c < nchunks; ++c) {
+                if (chunk_start[c] == chunk_start[c + 1]) continue;
+                if (zlo != zhi) {
+                    /* a chunk whose output layers all lie outside the slab would only produce filtered-out voxels
+                     * (chunks are independent, obj2voxel.cpp:254-314), so it is not voxelized at all */
+                    const uint32_t cz = (uint32_t) (c / ((size_t) chunks_per_axis * chunks_per_axis));
+                    const uint32_t oz0 = cz * O2V_CHUNK / supersampling, oz1 = (cz * O2V_CHUNK + O2V_CHUNK - 1u) / supersampling;
+                    if (oz1 < zlo || oz0 >= zhi) continue;
+                }
+                work[n_work++] = c;
+            }
 #pragma omp parallel num_threads(g_threads)
             {
                 voxelizer *vz = voxelizer_new();

@@ -1,0 +1,117 @@
+"""BASELINE.json configs[2], [3] and [4] at FULL size on their own workloads: the HIP path against the CPU oracle,
+bit for bit (sorted (x, y, z, argb) arrays equal).  The path compared is the reference's per-chunk loop
+src/obj2voxel.cpp:254-314 over Voxelizer::voxelize, src/voxelization.cpp:480-526.
+
+The assets BASELINE.json names are not in the reference tree (no network); the stand-ins are SURVEY.md section 8d's:
+  configs[2]  "Stanford Dragon (~870k tris) at 1024^3"            uv_sphere(467): 870 488 triangles
+  configs[3]  "Sponza textured (~260k tris) at 2048^3, 2x SS"     box room of 16x16 textured quads per wall + a textured
+                                                                   sphere nv=255: 262 092 triangles, 4096^3 samples
+  configs[4]  "50M-tri tessellated sphere at 4096^3, 8 z-slabs"   uv_sphere(3536): 49 999 040 triangles; the 8 planned slabs
+                                                                   run one after the other on this GPU
+The oracle runs chunk-parallel on every host core (results do not depend on the thread count).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dv():
+    from obj2voxel_amd import hip
+    d = hip.DeviceVoxelizer(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture()
+def all_cores(oracle):
+    oracle.set_threads(os.cpu_count() or 1)
+    yield oracle
+    oracle.set_threads(1)
+
+
+def _equal(got, want):
+    got, want = meshes.sorted_voxels(got), meshes.sorted_voxels(want)
+    assert got.shape == want.shape, f"voxel count {got.shape[0]} != oracle {want.shape[0]}"
+    assert np.array_equal(got[:, :3], want[:, :3]), "occupancy differs"
+    bad = np.flatnonzero(got[:, 3] != want[:, 3])
+    assert len(bad) == 0, f"{len(bad)} colours differ, first: {got[bad[0]]} vs {want[bad[0]]}"
+
+
+def test_config2_dragon_standin_1024_materialless_max(dv, all_cores):
+    """The bench workload itself: 870 488 MATERIALLESS triangles at 1024^3, MAX (every hit takes the direct MAX path)."""
+    v = meshes.uv_sphere(467)
+    dv.set_triangles(v)
+    got = dv.voxelize(1024)
+    st = dv.stats()
+    assert st["direct_hits"] == st["hits"] > 12_000_000
+    _equal(got, all_cores.voxelize(v, 1024))
+    assert len(got) == 4_936_186
+
+
+def test_config2_dragon_standin_1024_coloured_blend(dv, all_cores):
+    """The same mesh with per-triangle colours and BLEND: pool -> counting sort -> ordered replay for every hit."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(467)
+    T = len(v)
+    kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T))
+    dv.set_triangles(v, **kw)
+    got = dv.voxelize(1024, strategy=hip.STRATEGY_BLEND)
+    assert dv.stats()["direct_hits"] == 0
+    _equal(got, all_cores.voxelize(v, 1024, strategy=1, **kw))
+
+
+def _sponza_standin():
+    from obj2voxel_amd import hip
+    room = meshes.box_room(16)
+    sph, suv = meshes.uv_sphere(255, radius=0.3, center=(0.5, 0.45, 0.55), with_uv=True)
+    v = np.concatenate([room, sph])
+    uv = np.concatenate([np.tile(np.array([0, 0, 1, 0, 1, 1], np.float32), (len(room), 1)), suv])
+    T = len(v)
+    return v, dict(uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32), texids=np.zeros(T, np.int32)), \
+        [(meshes.checker_texture(1024, 32), 1)]
+
+
+@pytest.mark.parametrize("strategy", [1, 0])
+def test_config3_sponza_standin_2048_ss2_textured(dv, all_cores, strategy):
+    """262 092 textured triangles (large axis-aligned quads: aligned fast path and u32 volume wrap; a sphere whose
+    triangles are ~15 samples wide: subdivision) at 2048^3 with 2x supersampling (4096^3 samples), BLEND and MAX."""
+    v, kw, tex = _sponza_standin()
+    assert 260_000 < len(v) < 264_000
+    dv.set_textures(tex)
+    dv.set_triangles(v, **kw)
+    got = dv.voxelize(2048, supersampling=2, strategy=strategy)
+    want = all_cores.voxelize(v, 2048, supersampling=2, strategy=strategy, textures=tex, **kw)
+    _equal(got, want)
+    assert len(got) > 30_000_000
+
+
+def test_config4_50m_sphere_4096_eight_planned_slabs(dv, all_cores):
+    """configs[4]: every one of the 8 work-balanced z-slabs (what each GPU of the node computes) equals the oracle's
+    voxels of that slab; the slabs tile the grid, so their union is the whole model."""
+    from obj2voxel_amd import hip
+    res, n = 4096, 8
+    v = meshes.uv_sphere(3536)
+    assert 49_900_000 < len(v) < 50_100_000
+    want = meshes.sorted_voxels(all_cores.voxelize(v, res))
+    d = dv  # the module's context: its dense grids are re-allocated for the slab (two contexts would not fit in HBM)
+    d.set_triangles(v)
+    cuts, bnd = d.plan_slabs(res, n)
+    assert cuts[0] == 0 and cuts[-1] == res and all(a < b for a, b in zip(cuts, cuts[1:]))
+    hits, total = [], 0
+    for r in range(n):
+        got = meshes.sorted_voxels(d.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd))
+        hits.append(d.stats()["hits"])
+        # `want` is sorted by (z, y, x): a slab is one contiguous run of it
+        lo, hi = np.searchsorted(want[:, 2], [cuts[r], cuts[r + 1]])
+        assert len(got) == hi - lo, f"slab {r}: {len(got)} voxels, oracle {hi - lo}"
+        assert np.array_equal(got, want[lo:hi]), f"slab {r} differs from the oracle"
+        total += len(got)
+        del got
+    assert total == len(want) > 70_000_000
+    assert max(hits) < 1.05 * sum(hits) / n, (cuts, hits)   # the plan balances the predicted work

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Developer tool: event counts of k_voxelize's clip loop on the bench workload, from the instrumented library
+(make -C obj2voxel_amd/csrc instr -> libobj2voxel_amd_instr.so, loaded through O2V_LIB).
+usage: O2V_LIB=obj2voxel_amd/libobj2voxel_amd_instr.so python tools/instrument.py [nv res [textured]]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, '.')
+import numpy as np
+from obj2voxel_amd import hip, meshes
+
+NAMES = ["wave_iterations", "lane_events", "acc_passes_all", "whole_keep", "whole_keep_final", "whole_discard",
+         "cut_last_level", "cut", "cut_trivial(no later plane fails, margin)", "cut_two_pieces(push)",
+         "whole_keep_then_passes_all", "after_cut_cur_passes_all", "after_cut_sec_passes_all",
+         "after_cut_cur_outside_later_plane", "after_cut_sec_outside_later_plane", "-"]
+nv = int(sys.argv[1]) if len(sys.argv) > 1 else 467
+res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+textured = len(sys.argv) > 3
+dv = hip.DeviceVoxelizer(0)
+if textured:
+    v, uv = meshes.uv_sphere(nv, with_uv=True)
+    T = len(v)
+    dv.set_textures([(meshes.checker_texture(1024, 32), 1)])
+    dv.set_triangles(v, uvs=uv, types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32))
+else:
+    dv.set_triangles(meshes.uv_sphere(nv))
+dv.voxelize(res, read=False)
+n = dv.voxelize(res, read=False)
+c = dv.debug_counters()
+st = dv.stats()
+out = {"voxels": int(n), "hits": st["hits"], "candidates": st["candidates"], "timings": dv.timings()}
+out["events"] = {NAMES[i]: int(c[i]) for i in range(15)}
+print(json.dumps(out, indent=1))

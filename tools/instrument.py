@@ -10,10 +10,9 @@ sys.path.insert(0, '.')
 import numpy as np
 from obj2voxel_amd import hip, meshes
 
-NAMES = ["wave_iterations", "lane_events", "acc_passes_all", "whole_keep", "whole_keep_final", "whole_discard",
-         "cut_last_level", "cut", "cut_trivial(no later plane fails, margin)", "cut_two_pieces(push)",
-         "whole_keep_then_passes_all", "after_cut_cur_passes_all", "after_cut_sec_passes_all",
-         "after_cut_cur_outside_later_plane", "after_cut_sec_outside_later_plane", "-"]
+NAMES = ["wave_iterations", "lane_events", "acc_passes_all(event)", "whole_keep(event)", "-", "whole_discard(event)",
+         "-", "cut(event)", "cut: first piece final", "cut: first piece dropped", "cut: second piece final",
+         "cut: second piece dropped", "cut: second piece pushed", "-", "-", "-"]
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 467
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 textured = len(sys.argv) > 3

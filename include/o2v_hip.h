@@ -63,6 +63,10 @@ typedef struct {
     float resolve_ms;    /* K3  per-cell ordered replay (MAX / BLEND), colour lookup, ARGB pack; emission of the max grid */
     float total_ms;      /* first event to last event */
     uint32_t passes;     /* 1, or more if a device buffer had to grow and the pipeline was re-run */
+    float plan_ms;       /* o2v_hip_voxelize_sharded only: sharded bounds + work histogram passes incl. their collectives
+                            (host wall time; not part of total_ms) */
+    float collective_ms; /* ... of which inside the collectives (all-reduce of bounds and histogram, all-gather of the
+                            block extents and of the slab counts) */
 } o2v_hip_timings;
 
 /* Work counters of the last o2v_hip_voxelize call. */
@@ -112,6 +116,15 @@ int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t 
 /* Copies voxels [first, first+count) of the last result to host memory as (x, y, z, argb) uint32 quadruples,
  * the layout of the reference's voxel callback (include/obj2voxel.h:35,200-209).  Order is unspecified. */
 int o2v_hip_read_voxels(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count);
+/* The same copy in two steps, for overlapping it with the consumer of the previous batch: _async starts the copy on the
+ * context's stream (`out` should be pinned memory, see o2v_hip_alloc_pinned), _wait returns when it has landed. */
+int o2v_hip_read_voxels_async(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count);
+int o2v_hip_read_voxels_wait(o2v_hip_ctx *ctx);
+/* Page-locked host memory (hipHostMalloc / hipHostFree): transfers from and to it run asynchronously at link rate. */
+void *o2v_hip_alloc_pinned(size_t bytes);
+void o2v_hip_free_pinned(void *p);
+/* Releases the device session that obj2voxel_voxelize() keeps between calls (contexts, dense grids, staging memory). */
+void o2v_release_cached_device_memory(void);
 /* Device pointer to the same records (valid until the next voxelize/destroy). */
 int o2v_hip_voxels_device_ptr(o2v_hip_ctx *ctx, const uint32_t **out_ptr, uint64_t *out_count);
 
@@ -129,6 +142,83 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
 
 /* Debugging aid: log2 histogram of hits per occupied cell of the last run (32 buckets; bucket b: 2^(b-1) < hits <= 2^b). */
 int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32);
+
+/* ---- multi-GPU: the grid sharded by z-slab over the GPUs of one node --------------------------
+ *
+ * Every rank (one per GPU) holds the whole triangle list, like every 64^3 chunk of the reference sees every triangle
+ * that overlaps it (src/obj2voxel.cpp:226-243), and voxelizes only its own z-slab (walk clamped as in
+ * src/voxelization.cpp:440-444).  Voxel data never crosses GPUs: each output voxel is owned by exactly one slab and the
+ * union of the slabs is bit-identical to the single-GPU result.  What the ranks exchange is planning data, with RCCL over
+ * xGMI: the passes over the triangle list that find the mesh bounds and the z histogram of predicted work are SHARDED
+ * (rank r streams triangles [r, r+1) * T / N only) and combined with an all-reduce (min/max of 6 floats; sum of 2048 u64),
+ * the z extent of every block of 256 triangles is all-gathered (so that each rank can skip the blocks that miss its slab
+ * without reading them), and the per-slab voxel counts are all-gathered (output offsets for the sink).
+ *
+ * Two ways to use it:
+ *   one process per GPU   o2v_hip_comm_unique_id on rank 0 -> ship the 128 bytes to every rank (MPI, torch.distributed,
+ *                         a file) -> o2v_hip_comm_create_rccl on every rank -> o2v_hip_voxelize_sharded, collectively.
+ *   one process, N GPUs   o2v_hip_group_*: one context and one host thread per GPU; obj2voxel_voxelize() uses this when
+ *                         the environment names more than one device (O2V_DEVICES=0,1,2,3 or O2V_DEVICES=all).
+ */
+#define O2V_HIP_COMM_ID_BYTES 128
+typedef struct o2v_hip_comm o2v_hip_comm;
+
+/* Collectives supplied by the embedding program, on HOST memory, in place; every rank calls them in the same order.
+ * Return 0 on success.  Used where RCCL cannot be (tests with a gloo group; two ranks sharing one GPU). */
+typedef struct {
+    void *user;
+    int (*allreduce_min_u32)(void *user, uint32_t *buf, size_t n);
+    int (*allreduce_max_u32)(void *user, uint32_t *buf, size_t n);
+    int (*allreduce_sum_u64)(void *user, uint64_t *buf, size_t n);
+    int (*allgather)(void *user, void *buf, size_t bytes_per_rank); /* rank r's part sits at buf + r * bytes_per_rank */
+    int (*broadcast)(void *user, void *buf, size_t bytes, int root);
+} o2v_hip_comm_callbacks;
+
+int o2v_hip_comm_unique_id(uint8_t id[O2V_HIP_COMM_ID_BYTES]); /* ncclGetUniqueId; call on one rank */
+int o2v_hip_comm_create_rccl(const uint8_t id[O2V_HIP_COMM_ID_BYTES], int rank, int world, int device, o2v_hip_comm **out);
+int o2v_hip_comm_create_callbacks(const o2v_hip_comm_callbacks *callbacks, int rank, int world, o2v_hip_comm **out);
+void o2v_hip_comm_destroy(o2v_hip_comm *comm);
+const char *o2v_hip_comm_kind(const o2v_hip_comm *comm); /* "rccl" or "callbacks" */
+const char *o2v_hip_comm_last_error(const o2v_hip_comm *comm);
+
+/* Collective over `comm`: every rank calls it with the same triangles (o2v_hip_set_triangles) and the same params
+ * (z_begin / z_end are ignored).  Plans work-balanced slabs from the sharded passes, voxelizes this rank's slab and
+ * gathers the slab counts.  out_count: this rank's voxels (read them with o2v_hip_read_voxels); out_counts_all (optional):
+ * world entries; out_cuts (optional): world + 1 ascending z cuts, rank r owns [out_cuts[r], out_cuts[r + 1]).
+ * With a world of 1 this is o2v_hip_voxelize. */
+int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip_params *params, uint64_t *out_count,
+                             uint64_t *out_counts_all, uint32_t *out_cuts);
+
+/* In-process group: N contexts (one per listed device; a device may be listed more than once, which only makes sense
+ * for tests on a single-GPU machine) driven by N host threads.  The ranks talk through RCCL when every device is listed
+ * once and librccl can be loaded, otherwise through shared host memory. */
+typedef struct o2v_hip_group o2v_hip_group;
+enum {
+    O2V_HIP_UPLOAD_H2D = 0,       /* every GPU copies the triangles from host memory over its own PCIe link, in parallel */
+    O2V_HIP_UPLOAD_BROADCAST = 1, /* one H2D copy to the first GPU, then an RCCL broadcast over xGMI */
+    O2V_HIP_UPLOAD_PEER = 2       /* one H2D copy to the first GPU, then hipMemcpyPeerAsync to each of the others */
+};
+int o2v_hip_group_create(const int *devices, uint32_t n_devices, o2v_hip_group **out);
+void o2v_hip_group_destroy(o2v_hip_group *group);
+uint32_t o2v_hip_group_size(const o2v_hip_group *group);
+o2v_hip_ctx *o2v_hip_group_ctx(o2v_hip_group *group, uint32_t rank); /* for read_voxels / timings / stats of one rank */
+const char *o2v_hip_group_comm_kind(const o2v_hip_group *group);      /* "rccl" or "callbacks" */
+const char *o2v_hip_group_last_error(const o2v_hip_group *group);
+int o2v_hip_group_set_triangles(o2v_hip_group *group, const float *verts, const float *uvs, const uint32_t *types,
+                                const float *colors, const int32_t *texids, uint64_t count, int upload_mode);
+int o2v_hip_group_set_textures(o2v_hip_group *group, const o2v_hip_texture *textures, uint32_t count);
+/* out_counts: n_devices entries; out_cuts (optional): n_devices + 1 entries */
+int o2v_hip_group_voxelize(o2v_hip_group *group, const o2v_hip_params *params, uint64_t *out_counts, uint32_t *out_cuts);
+
+/* Host-only pieces of the above, exported so that they can be tested without a GPU:
+ * the cuts for n_slabs slabs of equal predicted work from a z histogram of n_bins bins of bin_layers output layers each
+ * (out_z: n_slabs + 1 entries); a self-test that drives every callback of a callbacks table with known patterns from
+ * this rank and checks what comes back (0 = all collectives behave as specified); and the same for the shared-memory
+ * exchange between the threads of an in-process group. */
+void o2v_hip_cuts_from_histogram(const uint64_t *hist, uint32_t n_bins, uint32_t bin_layers, uint32_t resolution,
+                                 uint32_t n_slabs, uint32_t *out_z);
+int o2v_hip_comm_callbacks_selftest(const o2v_hip_comm_callbacks *callbacks, int rank, int world);
+int o2v_hip_group_exchange_selftest(uint32_t n_threads);
 
 /* Debugging aid for kernel work: 16 event counters of the clip loop of the last run.  All zero unless the library was
  * built with -DO2V_INSTRUMENT (make INSTR=1, tools/instrument.sh); the meaning of each slot is documented there. */

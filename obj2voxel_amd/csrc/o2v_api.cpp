@@ -57,8 +57,17 @@ namespace o2v {
 void log_message(int level, const std::string &msg)
 {
     if (level > g_log_level) return;
-    std::lock_guard<std::mutex> lock{g_log_mutex};
-    if (g_log_callback && g_log_callback(g_log_callback_data, msg.c_str(), (obj2voxel_enum_t) level)) return;
+    obj2voxel_log_callback *callback;
+    void *callback_data;
+    {
+        // the callback runs outside the lock: it may itself call obj2voxel_set_log_callback
+        std::lock_guard<std::mutex> lock{g_log_mutex};
+        callback = g_log_callback;
+        callback_data = g_log_callback_data;
+    }
+    if (callback && callback(callback_data, msg.c_str(), (obj2voxel_enum_t) level)) return;
+    static std::mutex print_mutex;
+    std::lock_guard<std::mutex> lock{print_mutex};
     static const char *names[] = {"", "ERROR", "WARNING", "INFO", "DEBUG"};
     std::fprintf(level <= OBJ2VOXEL_LOG_LEVEL_WARNING ? stderr : stdout, "[obj2voxel] [%s] %s\n",
                  names[level < 0 || level > 4 ? 0 : level], msg.c_str());
@@ -224,74 +233,130 @@ struct MeshArrays {
     }
 };
 
-// ---- process-wide device context cache ---------------------------------------------------------------------
-struct CachedContext {
-    o2v_hip_ctx *ctx;
-    int device;
-    bool from_cache;
-};
-std::mutex g_ctx_mutex;
-o2v_hip_ctx *g_cached_ctx = nullptr;  // intentionally never destroyed at exit (HIP may already be torn down)
-int g_cached_device = -1;
-bool g_cached_busy = false;
+// ---- device sessions -----------------------------------------------------------------------------------------------
+// What one obj2voxel_voxelize call drives: one GPU (a context), or - if the environment names several devices
+// (O2V_DEVICES=0,1,2,3 or O2V_DEVICES=all) - an in-process group of GPUs with the grid sharded by z-slab
+// (include/o2v_hip.h, multi-GPU section), where the reference hands its chunks to a worker pool
+// (src/obj2voxel.cpp:467-520).
+struct Session {
+    std::vector<int> devices;
+    o2v_hip_ctx *ctx = nullptr;      // one device
+    o2v_hip_group *group = nullptr;  // several
+    uint32_t *pinned[2] = {nullptr, nullptr};  // read-back staging (pinned: D2H runs at link rate and asynchronously)
+    uint64_t pinned_records = 0;
 
-CachedContext acquire_context(int device)
-{
+    uint32_t ranks() const { return group ? o2v_hip_group_size(group) : 1u; }
+    o2v_hip_ctx *rank_ctx(uint32_t r) { return group ? o2v_hip_group_ctx(group, r) : ctx; }
+    const char *last_error() const { return group ? o2v_hip_group_last_error(group) : o2v_hip_last_error(ctx); }
+    ~Session()
     {
-        std::lock_guard<std::mutex> lock{g_ctx_mutex};
-        if (g_cached_ctx && !g_cached_busy && g_cached_device == device) {
-            g_cached_busy = true;
-            return {g_cached_ctx, device, true};
+        for (uint32_t *p : pinned)
+            if (p) o2v_hip_free_pinned(p);
+        if (group) o2v_hip_group_destroy(group);
+        if (ctx) o2v_hip_destroy(ctx);
+    }
+};
+
+std::vector<int> requested_devices()
+{
+    std::vector<int> devices;
+    if (const char *env = std::getenv("O2V_DEVICES")) {
+        if (std::strcmp(env, "all") == 0) {
+            for (int d = 0; d < o2v_hip_device_count(); ++d) devices.push_back(d);
+        }
+        else {
+            for (const char *q = env; *q;) {
+                char *end = nullptr;
+                const long d = std::strtol(q, &end, 10);
+                if (end == q) break;
+                devices.push_back((int) d);
+                q = *end == ',' ? end + 1 : end;
+            }
         }
     }
-    o2v_hip_ctx *ctx = nullptr;
-    if (o2v_hip_create(device, &ctx) != O2V_HIP_OK) return {nullptr, device, false};
-    return {ctx, device, false};
+    if (devices.empty()) {
+        int device = 0;
+        if (const char *env = std::getenv("O2V_DEVICE")) device = std::atoi(env);
+        devices.push_back(device);
+    }
+    return devices;
 }
 
-void release_context(CachedContext c)
+// Instances are single-use (reference obj2voxel.cpp:604-606,635) but device sessions are not: one per process is kept and
+// reused, so repeated voxelizations do not pay for creating contexts and allocating the dense grids again.  It holds on
+// to device memory (4 + 8 bytes per cell of the largest grid so far); o2v_release_cached_device_memory() (o2v_hip.h) or
+// O2V_CONTEXT_CACHE=0 give it back.
+std::mutex g_session_mutex;
+Session *g_cached_session = nullptr;  // intentionally never destroyed at exit (HIP may already be torn down)
+bool g_cached_busy = false;
+
+Session *acquire_session(const std::vector<int> &devices, bool &from_cache)
 {
-    if (!c.ctx) return;
-    std::lock_guard<std::mutex> lock{g_ctx_mutex};
-    if (c.from_cache) {
-        g_cached_busy = false;
-        return;
+    {
+        std::lock_guard<std::mutex> lock{g_session_mutex};
+        if (g_cached_session && !g_cached_busy && g_cached_session->devices == devices) {
+            g_cached_busy = true;
+            from_cache = true;
+            return g_cached_session;
+        }
     }
-    if (!g_cached_ctx) {  // first finished voxelization donates its context to the cache
-        g_cached_ctx = c.ctx;
-        g_cached_device = c.device;
-        g_cached_busy = false;
-        return;
+    from_cache = false;
+    Session *s = new Session;
+    s->devices = devices;
+    const int rc = devices.size() > 1 ? o2v_hip_group_create(devices.data(), (uint32_t) devices.size(), &s->group)
+                                      : o2v_hip_create(devices[0], &s->ctx);
+    if (rc != O2V_HIP_OK) {
+        delete s;
+        return nullptr;
     }
-    o2v_hip_destroy(c.ctx);  // a concurrent voxelization on another thread used a temporary context
+    return s;
+}
+
+void release_session(Session *s, bool from_cache)
+{
+    if (!s) return;
+    const char *cache = std::getenv("O2V_CONTEXT_CACHE");
+    const bool keep = !(cache && cache[0] == '0');
+    {
+        std::lock_guard<std::mutex> lock{g_session_mutex};
+        if (from_cache) {
+            g_cached_busy = false;
+            if (keep) return;
+            g_cached_session = nullptr;
+        }
+        else if (keep && !g_cached_session) {  // the first finished voxelization donates its session to the cache
+            g_cached_session = s;
+            g_cached_busy = false;
+            return;
+        }
+    }
+    delete s;  // caching is off, or a concurrent voxelization on another thread used a temporary session
 }
 
 // The GPU leg of voxelize_specialized (reference obj2voxel.cpp:467-520): bounds, transform, per-triangle
-// voxelization, colour combine and packing all happen on the device; the host only moves data.
+// voxelization, colour combine and packing all happen on the device(s); the host only moves data.
 obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, MeshArrays &mesh)
 {
     const uint64_t T = mesh.n;
     const std::vector<const obj2voxel_texture *> &tex_list = mesh.tex_list;
     PhaseClock clock;
 
-    int device = 0;
-    if (const char *env = std::getenv("O2V_DEVICE")) device = std::atoi(env);
-    // Instances are single-use (reference obj2voxel.cpp:604-606,635) but the device context is not: one context per
-    // process is kept and reused, so repeated voxelizations do not pay for re-allocating the dense grid.
-    CachedContext cached = acquire_context(device);
-    o2v_hip_ctx *ctx = cached.ctx;
-    if (!ctx) {
+    const std::vector<int> devices = requested_devices();
+    bool from_cache = false;
+    Session *session = acquire_session(devices, from_cache);
+    if (!session) {
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device: the GPU voxelization path cannot run "
                                                "and this library has no CPU fallback");
         return OBJ2VOXEL_ERR_DEVICE;
     }
     struct Guard {
-        CachedContext c;
-        ~Guard() { release_context(c); }
-    } guard{cached};
+        Session *s;
+        bool from_cache;
+        ~Guard() { release_session(s, from_cache); }
+    } guard{session, from_cache};
 
     auto device_error = [&](const char *what) {
-        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, std::string(what) + ": " + o2v_hip_last_error(ctx));
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, std::string(what) + ": " + session->last_error());
         return OBJ2VOXEL_ERR_DEVICE;
     };
 
@@ -299,13 +364,25 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, MeshArrays &mesh)
     for (const obj2voxel_texture *t : tex_list)
         tex_desc.push_back(o2v_hip_texture{t->pixels.data(), (uint32_t) t->width, (uint32_t) t->height,
                                            (uint32_t) t->channels, t->wrap});
-    if (!tex_desc.empty() && o2v_hip_set_textures(ctx, tex_desc.data(), (uint32_t) tex_desc.size()) != O2V_HIP_OK)
-        return device_error("uploading textures failed");
-    if (o2v_hip_set_triangles(ctx, mesh.verts.data(), mesh.uvs.empty() ? nullptr : mesh.uvs.data(),
-                              mesh.types.empty() ? nullptr : mesh.types.data(),
-                              mesh.colors.empty() ? nullptr : mesh.colors.data(),
-                              mesh.texids.empty() ? nullptr : mesh.texids.data(), T) != O2V_HIP_OK)
-        return device_error("uploading triangles failed");
+    const float *uvs = mesh.uvs.empty() ? nullptr : mesh.uvs.data();
+    const uint32_t *types = mesh.types.empty() ? nullptr : mesh.types.data();
+    const float *colors = mesh.colors.empty() ? nullptr : mesh.colors.data();
+    const int32_t *texids = mesh.texids.empty() ? nullptr : mesh.texids.data();
+    if (session->group) {
+        int upload = O2V_HIP_UPLOAD_H2D;
+        if (const char *env = std::getenv("O2V_UPLOAD"))
+            upload = std::strcmp(env, "broadcast") == 0 ? O2V_HIP_UPLOAD_BROADCAST : std::strcmp(env, "peer") == 0 ? O2V_HIP_UPLOAD_PEER : O2V_HIP_UPLOAD_H2D;
+        if (!tex_desc.empty() && o2v_hip_group_set_textures(session->group, tex_desc.data(), (uint32_t) tex_desc.size()) != O2V_HIP_OK)
+            return device_error("uploading textures failed");
+        if (o2v_hip_group_set_triangles(session->group, mesh.verts.data(), uvs, types, colors, texids, T, upload) != O2V_HIP_OK)
+            return device_error("uploading triangles failed");
+    }
+    else {
+        if (!tex_desc.empty() && o2v_hip_set_textures(session->ctx, tex_desc.data(), (uint32_t) tex_desc.size()) != O2V_HIP_OK)
+            return device_error("uploading textures failed");
+        if (o2v_hip_set_triangles(session->ctx, mesh.verts.data(), uvs, types, colors, texids, T) != O2V_HIP_OK)
+            return device_error("uploading triangles failed");
+    }
     mesh = MeshArrays{};  // the device holds the triangles now
     const double ms_upload = clock.lap_ms();
 
@@ -318,30 +395,61 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, MeshArrays &mesh)
     for (int i = 0; i < 6; ++i) params.bounds[i] = inst.mesh_bounds[i];
     params.z_begin = params.z_end = 0;
 
-    uint64_t count = 0;
-    if (o2v_hip_voxelize(ctx, &params, &count) != O2V_HIP_OK) return device_error("device voxelization failed");
+    const uint32_t n_ranks = session->ranks();
+    std::vector<uint64_t> counts(n_ranks, 0);
+    if (session->group) {
+        if (o2v_hip_group_voxelize(session->group, &params, counts.data(), nullptr) != O2V_HIP_OK)
+            return device_error("device voxelization failed");
+    }
+    else if (o2v_hip_voxelize(session->ctx, &params, &counts[0]) != O2V_HIP_OK) {
+        return device_error("device voxelization failed");
+    }
     const double ms_device = clock.lap_ms();
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        o2v_hip_timings tm{};
+        o2v_hip_get_timings(session->rank_ctx(r), &tm);
+        log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "device " + std::to_string(devices[r]) + " pipeline: " + std::to_string(tm.total_ms) + " ms, " +
+                                                   std::to_string(counts[r]) + " voxels, " + std::to_string(tm.passes) + " pass(es)" +
+                                                   (n_ranks > 1 ? ", plan " + std::to_string(tm.plan_ms) + " ms (collectives " +
+                                                                      std::to_string(tm.collective_ms) + " ms)"
+                                                                : std::string()));
+    }
 
-    o2v_hip_timings tm{};
-    o2v_hip_get_timings(ctx, &tm);
-    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "device pipeline: " + std::to_string(tm.total_ms) + " ms, " +
-                                               std::to_string(count) + " voxels, " + std::to_string(tm.passes) + " pass(es)");
-
-    // hand the (x, y, z, argb) records to the sink in batches (reference obj2voxel.cpp:298-303; the callback
-    // may be invoked any number of times, in any order)
+    // Hand the (x, y, z, argb) records to the sink in batches (reference obj2voxel.cpp:298-303; the callback may be
+    // invoked any number of times, in any order), rank by rank.  Two pinned staging buffers: while the sink consumes one
+    // batch the next one is already on its way from the device.
     constexpr uint64_t kBatch = 1u << 20;
-    std::vector<uint32_t> buffer(std::min<uint64_t>(count, kBatch) * 4);
-    for (uint64_t first = 0; first < count; first += kBatch) {
-        const uint64_t n = std::min<uint64_t>(kBatch, count - first);
+    if (session->pinned_records < kBatch) {
+        for (uint32_t *&p : session->pinned) {
+            if (p) o2v_hip_free_pinned(p);
+            p = static_cast<uint32_t *>(o2v_hip_alloc_pinned(kBatch * 16));
+        }
+        session->pinned_records = session->pinned[0] && session->pinned[1] ? kBatch : 0;
+        if (!session->pinned_records) return device_error("allocating read-back staging failed");
+    }
+    struct Batch {
+        uint32_t rank;
+        uint64_t first, n;
+    };
+    std::vector<Batch> batches;
+    for (uint32_t r = 0; r < n_ranks; ++r)
+        for (uint64_t first = 0; first < counts[r]; first += kBatch) batches.push_back({r, first, std::min<uint64_t>(kBatch, counts[r] - first)});
+    auto start_read = [&](size_t k) {
+        const Batch &b = batches[k];
+        return o2v_hip_read_voxels_async(session->rank_ctx(b.rank), session->pinned[k & 1], b.first, b.n) == O2V_HIP_OK;
+    };
+    if (!batches.empty() && !start_read(0)) return device_error("reading voxels failed");
+    for (size_t k = 0; k < batches.size(); ++k) {
         if (!inst.sink->can_write()) break;
-        if (o2v_hip_read_voxels(ctx, buffer.data(), first, n) != O2V_HIP_OK) return device_error("reading voxels failed");
-        inst.sink->write(buffer.data(), n);
+        if (o2v_hip_read_voxels_wait(session->rank_ctx(batches[k].rank)) != O2V_HIP_OK) return device_error("reading voxels failed");
+        if (k + 1 < batches.size() && !start_read(k + 1)) return device_error("reading voxels failed");
+        inst.sink->write(session->pinned[k & 1], batches[k].n);
     }
     if (!inst.sink->can_write()) {
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "Voxelization failed because of IO error");
         return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
     }
-    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: context + upload " + std::to_string(ms_upload) + " ms, device call " +
+    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: session + upload " + std::to_string(ms_upload) + " ms, device call " +
                                                std::to_string(ms_device) + " ms, read back + sink " +
                                                std::to_string(clock.lap_ms()) + " ms");
     log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Voxelized " + std::to_string(T) + " triangles, writing any buffered voxels ...");
@@ -679,6 +787,21 @@ uint32_t obj2voxel_get_worker_count(obj2voxel_instance *instance)
 }
 
 }  // extern "C"
+
+// Extension (declared in include/o2v_hip.h): gives the cached device session - contexts, dense grids, work buffers,
+// staging memory - back to the system.  The next obj2voxel_voxelize call creates a new one.
+extern "C" void o2v_release_cached_device_memory(void)
+{
+    Session *s = nullptr;
+    {
+        std::lock_guard<std::mutex> lock{g_session_mutex};
+        if (g_cached_session && !g_cached_busy) {
+            s = g_cached_session;
+            g_cached_session = nullptr;
+        }
+    }
+    delete s;
+}
 
 // texture accessors for o2v_io.cpp (OBJ loader creates textures it owns)
 namespace o2v {

@@ -1,0 +1,284 @@
+// o2v_comm.cpp -- RCCL-backed and callback-backed implementations of o2v_hip_comm (see o2v_comm.hpp).
+#include "o2v_comm.hpp"
+
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+// ---- librccl, loaded on first use ------------------------------------------------------------------------------
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // A process that already carries an RCCL must keep using that one: torch ships its own copy under the plain
+        // name "librccl.so", and dlopen by that name returns the loaded object.  RTLD_LOCAL: the symbols of whatever is
+        // loaded here must not capture the nccl* references of libraries loaded later.
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) {
+            api.err = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "unknown error");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(api.handle, n);
+            if (!p) {
+                ok = false;
+                api.err = std::string("librccl lacks ") + n;
+            }
+            return p;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!ok) {
+            dlclose(api.handle);
+            api.handle = nullptr;
+        }
+    });
+    return api.handle ? &api : nullptr;
+}
+
+struct RcclComm final : o2v_hip_comm {
+    RcclApi *api = nullptr;
+    ncclComm_t comm = nullptr;
+    int device = 0;
+
+    ~RcclComm() override
+    {
+        if (comm) {
+            (void) hipSetDevice(device);
+            (void) api->CommDestroy(comm);
+        }
+    }
+    const char *kind() const override { return "rccl"; }
+    int check(ncclResult_t r, const char *what)
+    {
+        if (r == ncclSuccess) return O2V_HIP_OK;
+        err = std::string(what) + ": " + api->GetErrorString(r);
+        return O2V_HIP_ERR_HIP;
+    }
+    int allreduce_min_u32(uint32_t *d, size_t n, hipStream_t s) override
+    {
+        return check(api->AllReduce(d, d, n, ncclUint32, ncclMin, comm, s), "ncclAllReduce(min)");
+    }
+    int allreduce_max_u32(uint32_t *d, size_t n, hipStream_t s) override
+    {
+        return check(api->AllReduce(d, d, n, ncclUint32, ncclMax, comm, s), "ncclAllReduce(max)");
+    }
+    int allreduce_sum_u64(unsigned long long *d, size_t n, hipStream_t s) override
+    {
+        return check(api->AllReduce(d, d, n, ncclUint64, ncclSum, comm, s), "ncclAllReduce(sum)");
+    }
+    int allgather(void *d, size_t bytes_per_rank, hipStream_t s) override
+    {
+        // in place: the send buffer is this rank's part of the receive buffer
+        const char *mine = static_cast<const char *>(d) + (size_t) rank * bytes_per_rank;
+        return check(api->AllGather(mine, d, bytes_per_rank, ncclUint8, comm, s), "ncclAllGather");
+    }
+    int broadcast(void *d, size_t bytes, int root, hipStream_t s) override
+    {
+        return check(api->Broadcast(d, d, bytes, ncclUint8, root, comm, s), "ncclBroadcast");
+    }
+};
+
+// ---- host callbacks ------------------------------------------------------------------------------------------------
+struct CallbackComm final : o2v_hip_comm {
+    o2v_hip_comm_callbacks cb{};
+    std::vector<unsigned char> host;
+
+    const char *kind() const override { return "callbacks"; }
+    template <typename F>
+    int staged(void *d, size_t bytes, hipStream_t s, const char *what, F &&op)
+    {
+        host.resize(bytes);
+        if (hipMemcpyAsync(host.data(), d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            err = std::string(what) + ": device to host copy failed";
+            return O2V_HIP_ERR_HIP;
+        }
+        if (op(host.data()) != 0) {
+            err = std::string(what) + ": the collective callback failed";
+            return O2V_HIP_ERR_HIP;
+        }
+        if (hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            err = std::string(what) + ": host to device copy failed";
+            return O2V_HIP_ERR_HIP;
+        }
+        return O2V_HIP_OK;
+    }
+    int allreduce_min_u32(uint32_t *d, size_t n, hipStream_t s) override
+    {
+        return staged(d, n * 4, s, "allreduce_min_u32", [&](void *h) { return cb.allreduce_min_u32(cb.user, static_cast<uint32_t *>(h), n); });
+    }
+    int allreduce_max_u32(uint32_t *d, size_t n, hipStream_t s) override
+    {
+        return staged(d, n * 4, s, "allreduce_max_u32", [&](void *h) { return cb.allreduce_max_u32(cb.user, static_cast<uint32_t *>(h), n); });
+    }
+    int allreduce_sum_u64(unsigned long long *d, size_t n, hipStream_t s) override
+    {
+        return staged(d, n * 8, s, "allreduce_sum_u64", [&](void *h) { return cb.allreduce_sum_u64(cb.user, static_cast<uint64_t *>(h), n); });
+    }
+    int allgather(void *d, size_t bytes_per_rank, hipStream_t s) override
+    {
+        return staged(d, bytes_per_rank * (size_t) world, s, "allgather", [&](void *h) { return cb.allgather(cb.user, h, bytes_per_rank); });
+    }
+    int broadcast(void *d, size_t bytes, int root, hipStream_t s) override
+    {
+        return staged(d, bytes, s, "broadcast", [&](void *h) { return cb.broadcast(cb.user, h, bytes, root); });
+    }
+};
+
+}  // namespace
+
+namespace o2v {
+
+bool rccl_unique_id(uint8_t id[O2V_HIP_COMM_ID_BYTES], std::string &err)
+{
+    static_assert(sizeof(ncclUniqueId) == O2V_HIP_COMM_ID_BYTES, "unique id size");
+    RcclApi *api = rccl_api();
+    if (!api) {
+        err = rccl_api() ? "" : "librccl is not available";
+        return false;
+    }
+    ncclUniqueId uid;
+    const ncclResult_t r = api->GetUniqueId(&uid);
+    if (r != ncclSuccess) {
+        err = std::string("ncclGetUniqueId: ") + api->GetErrorString(r);
+        return false;
+    }
+    std::memcpy(id, &uid, sizeof(uid));
+    return true;
+}
+
+o2v_hip_comm *make_rccl_comm(const uint8_t id[O2V_HIP_COMM_ID_BYTES], int rank, int world, int device, std::string &err)
+{
+    RcclApi *api = rccl_api();
+    if (!api) {
+        err = "librccl is not available";
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        err = "hipSetDevice failed";
+        return nullptr;
+    }
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    RcclComm *c = new RcclComm;
+    c->api = api;
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    const ncclResult_t r = api->CommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        err = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
+        c->comm = nullptr;
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+o2v_hip_comm *make_callback_comm(const o2v_hip_comm_callbacks &cb, int rank, int world)
+{
+    CallbackComm *c = new CallbackComm;
+    c->cb = cb;
+    c->rank = rank;
+    c->world = world;
+    return c;
+}
+
+}  // namespace o2v
+
+extern "C" {
+
+int o2v_hip_comm_unique_id(uint8_t id[O2V_HIP_COMM_ID_BYTES])
+{
+    std::string err;
+    if (!id) return O2V_HIP_ERR_BAD_ARGUMENT;
+    return o2v::rccl_unique_id(id, err) ? O2V_HIP_OK : O2V_HIP_ERR_HIP;
+}
+
+int o2v_hip_comm_create_rccl(const uint8_t id[O2V_HIP_COMM_ID_BYTES], int rank, int world, int device, o2v_hip_comm **out)
+{
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return O2V_HIP_ERR_BAD_ARGUMENT;
+    std::string err;
+    *out = o2v::make_rccl_comm(id, rank, world, device, err);
+    if (!*out) std::fprintf(stderr, "[o2v] RCCL communicator: %s\n", err.c_str());
+    return *out ? O2V_HIP_OK : O2V_HIP_ERR_HIP;
+}
+
+int o2v_hip_comm_create_callbacks(const o2v_hip_comm_callbacks *cb, int rank, int world, o2v_hip_comm **out)
+{
+    if (!cb || !out || world < 1 || rank < 0 || rank >= world || !cb->allreduce_min_u32 || !cb->allreduce_max_u32 ||
+        !cb->allreduce_sum_u64 || !cb->allgather || !cb->broadcast)
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out = o2v::make_callback_comm(*cb, rank, world);
+    return O2V_HIP_OK;
+}
+
+// Drives every callback with patterns whose result is known in closed form (host memory only: no GPU needed).
+int o2v_hip_comm_callbacks_selftest(const o2v_hip_comm_callbacks *cb, int rank, int world)
+{
+    if (!cb || world < 1 || rank < 0 || rank >= world) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const uint32_t W = (uint32_t) world, R = (uint32_t) rank;
+    // min / max of uint32 values with the top bit set (the order-preserving float encoding has it for positive floats)
+    uint32_t mn[3] = {0x80000000u + R, 0xfffffff0u - R, 7u + R}, mx[3] = {0x80000000u + R, 0xfffffff0u - R, 7u + R};
+    if (cb->allreduce_min_u32(cb->user, mn, 3) || cb->allreduce_max_u32(cb->user, mx, 3)) return 1;
+    if (mn[0] != 0x80000000u || mn[1] != 0xfffffff0u - (W - 1) || mn[2] != 7u) return 2;
+    if (mx[0] != 0x80000000u + (W - 1) || mx[1] != 0xfffffff0u || mx[2] != 7u + (W - 1)) return 3;
+    std::vector<uint64_t> sum(2048);
+    for (size_t i = 0; i < sum.size(); ++i) sum[i] = (uint64_t) i * 1000003ull + R + (i == 5 ? (1ull << 40) : 0);
+    if (cb->allreduce_sum_u64(cb->user, sum.data(), sum.size())) return 4;
+    for (size_t i = 0; i < sum.size(); ++i)
+        if (sum[i] != W * ((uint64_t) i * 1000003ull + (i == 5 ? (1ull << 40) : 0)) + (uint64_t) W * (W - 1) / 2) return 5;
+    const size_t per = 24;
+    std::vector<unsigned char> gather(per * W, 0xee);
+    for (size_t i = 0; i < per; ++i) gather[R * per + i] = (unsigned char) (R * 31 + i);
+    if (cb->allgather(cb->user, gather.data(), per)) return 6;
+    for (uint32_t r = 0; r < W; ++r)
+        for (size_t i = 0; i < per; ++i)
+            if (gather[r * per + i] != (unsigned char) (r * 31 + i)) return 7;
+    const int root = world - 1;
+    std::vector<unsigned char> bc(1000);
+    for (size_t i = 0; i < bc.size(); ++i) bc[i] = (unsigned char) (rank == root ? i * 7 : 0);
+    if (cb->broadcast(cb->user, bc.data(), bc.size(), root)) return 8;
+    for (size_t i = 0; i < bc.size(); ++i)
+        if (bc[i] != (unsigned char) (i * 7)) return 9;
+    return 0;
+}
+
+void o2v_hip_comm_destroy(o2v_hip_comm *comm) { delete comm; }
+const char *o2v_hip_comm_kind(const o2v_hip_comm *comm) { return comm ? comm->kind() : "none"; }
+const char *o2v_hip_comm_last_error(const o2v_hip_comm *comm) { return comm ? comm->err.c_str() : "null communicator"; }
+
+}  // extern "C"

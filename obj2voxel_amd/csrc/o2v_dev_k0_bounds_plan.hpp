@@ -129,8 +129,10 @@ __global__ void k_setup(Counters *c, Params p)
 constexpr uint32_t kPlanBins = 2048;
 __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ verts, const Counters *__restrict__ c,
                                                    unsigned long long *hist, float2 *zrange, float *zrange_xform,
-                                                   Params p, uint32_t bin_h)
+                                                   Params p, uint32_t bin_h, uint64_t tri_begin, uint64_t tri_end)
 {
+    // [tri_begin, tri_end): this rank's share of the triangle list (a multiple of 256 at the lower end); a single GPU
+    // takes the whole list
     __shared__ unsigned long long s_hist[kPlanBins];
     __shared__ float s_v[kBlock * 9];
     __shared__ float s_zr[2][kBlock / 64];
@@ -143,21 +145,21 @@ __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ vert
     // this batch is processed from LDS
     float pre[9];
     auto prefetch = [&](uint64_t base) {
-        const uint32_t n_f = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock) * 9u;
+        const uint32_t n_f = (uint32_t) (tri_end - base < kBlock ? tri_end - base : kBlock) * 9u;
 #pragma unroll
         for (uint32_t k = 0; k < 9; ++k) {
             const uint32_t idx = threadIdx.x + k * kBlock;
             pre[k] = idx < n_f ? verts[base * 9 + idx] : 0.f;
         }
     };
-    const uint64_t first = (uint64_t) blockIdx.x * kBlock, step = (uint64_t) gridDim.x * kBlock;
-    if (first < p.n_tris) prefetch(first);
-    for (uint64_t base = first; base < p.n_tris; base += step) {
+    const uint64_t first = tri_begin + (uint64_t) blockIdx.x * kBlock, step = (uint64_t) gridDim.x * kBlock;
+    if (first < tri_end) prefetch(first);
+    for (uint64_t base = first; base < tri_end; base += step) {
         __syncthreads();
-        const uint32_t n_here = (uint32_t) (p.n_tris - base < kBlock ? p.n_tris - base : kBlock);
+        const uint32_t n_here = (uint32_t) (tri_end - base < kBlock ? tri_end - base : kBlock);
 #pragma unroll
         for (uint32_t k = 0; k < 9; ++k) s_v[threadIdx.x + k * kBlock] = pre[k];
-        if (base + step < p.n_tris) prefetch(base + step);
+        if (base + step < tri_end) prefetch(base + step);
         __syncthreads();
         const bool live = threadIdx.x < n_here;
         const float *q = &s_v[(live ? threadIdx.x : 0u) * 9];

@@ -29,10 +29,13 @@
 #include "o2v_math.h"
 
 #include "../../include/o2v_hip.h"
+#include "o2v_comm.hpp"
+#include "o2v_device_internal.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +63,9 @@ struct o2v_hip_ctx {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
+    hipEvent_t ev_coll[2] = {};                 // sharded planning: around the collectives
+    unsigned long long *d_counts = nullptr, *h_counts = nullptr;  // per-rank voxel counts (all-gathered), world entries
+    uint32_t cap_counts = 0;
     std::string err;
 
     // inputs
@@ -67,6 +73,7 @@ struct o2v_hip_ctx {
     uint32_t *d_types = nullptr;
     int32_t *d_texids = nullptr;
     uint64_t n_tris = 0;
+    uint64_t cap_tri_bytes[5] = {0, 0, 0, 0, 0};  // allocated bytes of d_verts, d_uvs, d_types, d_colors, d_texids
     bool any_textured = false;
     DevTexture *d_textures = nullptr;
     std::vector<uint8_t *> d_texpix;
@@ -151,17 +158,26 @@ int grow(o2v_hip_ctx *ctx, T *&ptr, uint32_t &cap, uint64_t want)
     return O2V_HIP_OK;
 }
 
+// (re)allocates a device array only when it has to grow: repeated uploads of similar meshes reuse the allocation
 template <typename T>
-int upload(o2v_hip_ctx *ctx, T *&dptr, const T *host, uint64_t count)
+int ensure_array(o2v_hip_ctx *ctx, T *&dptr, uint64_t &cap_bytes, uint64_t count, bool wanted)
 {
+    if (!wanted || !count) {
+        // an absent optional array must read as null in the kernels (all MATERIALLESS / zero uvs / texture 0)
+        if (dptr) O2V_CHECK(hipFree(dptr));
+        dptr = nullptr;
+        cap_bytes = 0;
+        return O2V_HIP_OK;
+    }
+    const uint64_t bytes = count * sizeof(T);
+    if (dptr && bytes <= cap_bytes) return O2V_HIP_OK;
     if (dptr) O2V_CHECK(hipFree(dptr));
     dptr = nullptr;
-    if (!host || !count) return O2V_HIP_OK;
-    O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&dptr), count * sizeof(T)));
-    O2V_CHECK(hipMemcpy(dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+    cap_bytes = 0;
+    O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&dptr), bytes));
+    cap_bytes = bytes;
     return O2V_HIP_OK;
 }
-
 
 // O2V_DEBUG_SYNC=1: synchronise and log after every launch (locates a faulting or hanging kernel); the resolve tiers
 // then run on one stream.  O2V_DEBUG_SYNC=2: the same, but the tiers keep their own streams (device-wide sync).
@@ -351,6 +367,78 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 
 }  // namespace
 
+namespace o2v {
+
+hipStream_t ctx_stream(o2v_hip_ctx *ctx) { return ctx->stream; }
+int ctx_device(const o2v_hip_ctx *ctx) { return ctx->device; }
+
+int ctx_alloc_triangles(o2v_hip_ctx *ctx, uint64_t count, bool uvs, bool types, bool colors, bool texids)
+{
+    if (count >= (1ull << 29)) {
+        ctx->err = "triangle count must be below 2^29";
+        return O2V_HIP_ERR_LIMIT;
+    }
+    O2V_CHECK(hipSetDevice(ctx->device));
+    O2V_CHECK(hipStreamSynchronize(ctx->stream));  // nothing may still read the arrays that are about to be replaced
+    int rc;
+    if ((rc = ensure_array(ctx, ctx->d_verts, ctx->cap_tri_bytes[0], count * 9, true))) return rc;
+    if ((rc = ensure_array(ctx, ctx->d_uvs, ctx->cap_tri_bytes[1], count * 6, uvs))) return rc;
+    if ((rc = ensure_array(ctx, ctx->d_types, ctx->cap_tri_bytes[2], count, types))) return rc;
+    if ((rc = ensure_array(ctx, ctx->d_colors, ctx->cap_tri_bytes[3], count * 3, colors))) return rc;
+    if ((rc = ensure_array(ctx, ctx->d_texids, ctx->cap_tri_bytes[4], count, texids))) return rc;
+    ctx->n_tris = count;
+    ctx->tri_generation += 1;
+    ctx->max_tri_extent = -1.f;
+    ctx->any_textured = false;
+    return O2V_HIP_OK;
+}
+
+TriBuffers ctx_tri_buffers(o2v_hip_ctx *ctx)
+{
+    return TriBuffers{ctx->d_verts, ctx->d_uvs, ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->n_tris};
+}
+
+TriHints ctx_tri_hints(const o2v_hip_ctx *ctx)
+{
+    TriHints h;
+    h.any_textured = ctx->any_textured;
+    for (int i = 0; i < 6; ++i) h.bounds[i] = ctx->mesh_bounds_hint[i];
+    h.max_tri_extent = ctx->max_tri_extent;
+    return h;
+}
+
+// After the arrays are filled (on ctx's stream): records whether any triangle is textured and the launch-configuration
+// hints (mesh bounds and largest triangle extent, see k_tri_extent) - taken from `hints` if another rank already
+// computed them for the same triangles, else computed here.  Waits for the stream.
+int ctx_finish_triangles(o2v_hip_ctx *ctx, bool any_textured, const TriHints *hints)
+{
+    O2V_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t count = ctx->n_tris;
+    ctx->any_textured = any_textured;
+    if (hints) {
+        for (int i = 0; i < 6; ++i) ctx->mesh_bounds_hint[i] = hints->bounds[i];
+        ctx->max_tri_extent = hints->max_tri_extent;
+        ctx->any_textured = hints->any_textured;
+    }
+    else if (count) {
+        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count * 9 / 12 + kBlock) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
+        hipLaunchKernelGGL(k_tri_extent, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_verts, count, &ctx->d_ctr->pad2);
+        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+        O2V_CHECK(hipStreamSynchronize(s));
+        for (int i = 0; i < 6; ++i) ctx->mesh_bounds_hint[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
+        ctx->max_tri_extent = ord2f_host(ctx->h_ctr->pad2);
+        return O2V_HIP_OK;
+    }
+    O2V_CHECK(hipStreamSynchronize(s));
+    return O2V_HIP_OK;
+}
+
+}  // namespace o2v
+
 extern "C" {
 
 int o2v_hip_device_count(void)
@@ -420,6 +508,10 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->d_zrange) (void) hipFree(ctx->d_zrange);
     if (ctx->d_zrange_xform) (void) hipFree(ctx->d_zrange_xform);
     if (ctx->h_zhist) (void) hipHostFree(ctx->h_zhist);
+    if (ctx->d_counts) (void) hipFree(ctx->d_counts);
+    if (ctx->h_counts) (void) hipHostFree(ctx->h_counts);
+    for (auto &e : ctx->ev_coll)
+        if (e) (void) hipEventDestroy(e);
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
     if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
@@ -437,41 +529,25 @@ int o2v_hip_set_triangles(o2v_hip_ctx *ctx, const float *verts, const float *uvs
                           const float *colors, const int32_t *texids, uint64_t count)
 {
     if (!ctx || (count && !verts)) return O2V_HIP_ERR_BAD_ARGUMENT;
-    if (count >= (1ull << 29)) {
-        ctx->err = "triangle count must be below 2^29";
-        return O2V_HIP_ERR_LIMIT;
-    }
-    O2V_CHECK(hipSetDevice(ctx->device));
     int rc;
-    if ((rc = upload(ctx, ctx->d_verts, verts, count * 9))) return rc;
-    if ((rc = upload(ctx, ctx->d_uvs, uvs, count * 6))) return rc;
-    if ((rc = upload(ctx, ctx->d_types, types, count))) return rc;
-    if ((rc = upload(ctx, ctx->d_colors, colors, count * 3))) return rc;
-    if ((rc = upload(ctx, ctx->d_texids, texids, count))) return rc;
-    ctx->n_tris = count;
-    ctx->tri_generation += 1;
-    ctx->max_tri_extent = -1.f;
+    if ((rc = o2v::ctx_alloc_triangles(ctx, count, uvs != nullptr, types != nullptr, colors != nullptr, texids != nullptr))) return rc;
     if (count) {
-        // launch-configuration hint for later voxelizations (see k_tri_extent); the bounds themselves are recomputed there
         hipStream_t s = ctx->stream;
-        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
-        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count * 9 / 12 + kBlock) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
-        hipLaunchKernelGGL(k_tri_extent, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_verts, count, &ctx->d_ctr->pad2);
-        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        O2V_CHECK(hipStreamSynchronize(s));
-        for (int i = 0; i < 6; ++i) ctx->mesh_bounds_hint[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
-        ctx->max_tri_extent = ord2f_host(ctx->h_ctr->pad2);
+        O2V_CHECK(hipMemcpyAsync(ctx->d_verts, verts, count * 9 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (uvs) O2V_CHECK(hipMemcpyAsync(ctx->d_uvs, uvs, count * 6 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (types) O2V_CHECK(hipMemcpyAsync(ctx->d_types, types, count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        if (colors) O2V_CHECK(hipMemcpyAsync(ctx->d_colors, colors, count * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (texids) O2V_CHECK(hipMemcpyAsync(ctx->d_texids, texids, count * sizeof(int32_t), hipMemcpyHostToDevice, s));
     }
-    ctx->any_textured = false;
+    // (the host scan overlaps the copies)
+    bool any_textured = false;
     if (types)
         for (uint64_t i = 0; i < count; ++i)
             if (types[i] == O2V_HIP_TRI_TEXTURED) {
-                ctx->any_textured = true;
+                any_textured = true;
                 break;
             }
-    return O2V_HIP_OK;
+    return o2v::ctx_finish_triangles(ctx, any_textured, nullptr);
 }
 
 int o2v_hip_set_textures(o2v_hip_ctx *ctx, const o2v_hip_texture *textures, uint32_t count)
@@ -785,20 +861,20 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     return O2V_HIP_ERR_LIMIT;
 }
 
-int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t n_slabs, uint32_t *out_z,
-                       float *out_bounds)
+}  // extern "C"
+
+namespace {
+
+// The triangle passes of the slab plan over the triangles [tri_begin, tri_end) - this rank's share; a single GPU takes the
+// whole list: mesh bounds (unless given: reference findMeshBounds, src/obj2voxel.cpp:180-200), transform, the z
+// histogram of predicted work and the z extent of every block of 256 triangles.  With a communicator the partial results
+// are combined over the ranks: min / max of the bounds, sum of the histogram, all-gather of the block extents
+// (`blocks_per_rank` blocks each).  Afterwards the histogram is in ctx->h_zhist and the counters in ctx->h_ctr.
+int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_begin, uint64_t tri_end, o2v_hip_comm *comm,
+                uint64_t blocks_per_rank, uint32_t &n_bins, uint32_t &bin_out, float *collective_ms)
 {
-    if (!ctx || !params || !out_z || n_slabs == 0) return O2V_HIP_ERR_BAD_ARGUMENT;
     const uint32_t ss = params->supersampling ? params->supersampling : 1u;
     const uint32_t G = params->resolution;
-    if (G == 0 || ss > 2 || (uint64_t) G * ss > 65535u || n_slabs > G) {
-        ctx->err = "plan_slabs: resolution must be non-zero and below 65536 samples, 1 <= n_slabs <= resolution";
-        return O2V_HIP_ERR_BAD_ARGUMENT;
-    }
-    for (uint32_t k = 0; k <= n_slabs; ++k) out_z[k] = (uint32_t) ((uint64_t) G * k / n_slabs);  // equal heights
-    if (out_bounds)
-        for (int i = 0; i < 6; ++i) out_bounds[i] = params->bounds_known ? params->bounds[i] : 0.f;
-    if (ctx->n_tris == 0) return O2V_HIP_OK;
     O2V_CHECK(hipSetDevice(ctx->device));
     if (!ctx->d_zhist) {
         O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zhist), kPlanBins * sizeof(unsigned long long)));
@@ -813,41 +889,85 @@ int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t 
     for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
     for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];
     // sample layers per bin: a whole number of output layers, at most kPlanBins bins
-    const uint32_t bin_out = (G + kPlanBins - 1) / kPlanBins;
-    const uint32_t n_bins = (G + bin_out - 1) / bin_out;
+    bin_out = (G + kPlanBins - 1) / kPlanBins;
+    n_bins = (G + bin_out - 1) / bin_out;
+    const uint64_t n_range = tri_end > tri_begin ? tri_end - tri_begin : 0;
 
     hipStream_t s = ctx->stream;
+    float coll_ms = 0.f;
+    auto timed = [&](auto &&collectives) -> int {
+        O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s));
+        const int rc = collectives();
+        if (rc) return rc;
+        O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s));
+        O2V_CHECK(hipEventSynchronize(ctx->ev_coll[1]));
+        float ms = 0.f;
+        O2V_CHECK(hipEventElapsedTime(&ms, ctx->ev_coll[0], ctx->ev_coll[1]));
+        coll_ms += ms;
+        return O2V_HIP_OK;
+    };
+    auto comm_failed = [&](int rc) {
+        ctx->err = std::string("collective failed: ") + comm->err;
+        return rc;
+    };
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
-    if (!p.bounds_known)
-        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
+    if (!p.bounds_known) {
+        if (n_range)
+            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (n_range * 9 / 12 + kBlock) / kBlock)),
+                               dim3(kBlock), 0, s, ctx->d_verts + tri_begin * 9, n_range * 9, ctx->d_ctr);
+        O2V_STAGE("k_bounds");
+        if (comm) {
+            int rc = timed([&]() -> int {
+                int r = comm->allreduce_min_u32(ctx->d_ctr->bounds_enc, 3, s);
+                if (!r) r = comm->allreduce_max_u32(ctx->d_ctr->bounds_enc + 3, 3, s);
+                return r;
+            });
+            if (rc) return comm_failed(rc);
+        }
+    }
     hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
     O2V_CHECK(hipMemsetAsync(ctx->d_zhist, 0, kPlanBins * sizeof(unsigned long long), s));
     {
+        const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
         int rc;
-        if ((rc = grow(ctx, ctx->d_zrange, ctx->cap_zrange, (p.n_tris + kBlock - 1) / kBlock))) return rc;
+        if ((rc = grow(ctx, ctx->d_zrange, ctx->cap_zrange, std::max<uint64_t>(comm ? blocks_per_rank * (uint64_t) comm->world : n_blocks, 1))))
+            return rc;
         if (!ctx->d_zrange_xform) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zrange_xform), 12 * sizeof(float)));
     }
     ctx->zrange_generation = ~0ull;
-    hipLaunchKernelGGL(k_zhist, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 6u, (p.n_tris + kBlock - 1) / kBlock)),
+    hipLaunchKernelGGL(k_zhist, dim3((uint32_t) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) ctx->num_cus * 6u, (n_range + kBlock - 1) / kBlock))),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_ctr, ctx->d_zhist, ctx->d_zrange, ctx->d_zrange_xform, p,
-                       bin_out * ss);
+                       bin_out * ss, tri_begin, tri_end);
     O2V_STAGE("k_zhist");
+    if (comm) {
+        int rc = timed([&]() -> int {
+            int r = comm->allreduce_sum_u64(ctx->d_zhist, kPlanBins, s);
+            if (!r) r = comm->allgather(ctx->d_zrange, blocks_per_rank * sizeof(float2), s);
+            return r;
+        });
+        if (rc) return comm_failed(rc);
+    }
     O2V_CHECK(hipMemcpyAsync(ctx->h_zhist, ctx->d_zhist, n_bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipStreamSynchronize(s));
     O2V_CHECK(hipGetLastError());
     ctx->zrange_generation = ctx->tri_generation;  // k_expand_roots may use the extents (it checks the transform)
-    if (out_bounds && !params->bounds_known)
-        for (int i = 0; i < 6; ++i) out_bounds[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
+    if (collective_ms) *collective_ms = coll_ms;
+    return O2V_HIP_OK;
+}
 
+// Cuts the histogram into n_slabs parts of equal predicted work (whole bins; every slab keeps at least one layer).
+void cuts_from_histogram(const unsigned long long *hist, uint32_t n_bins, uint32_t bin_out, uint32_t G, uint32_t n_slabs,
+                         uint32_t *out_z)
+{
+    for (uint32_t k = 0; k <= n_slabs; ++k) out_z[k] = (uint32_t) ((uint64_t) G * k / n_slabs);  // equal heights
     unsigned __int128 total = 0;
-    for (uint32_t b = 0; b < n_bins; ++b) total += ctx->h_zhist[b];
-    if (total == 0) return O2V_HIP_OK;
+    for (uint32_t b = 0; b < n_bins; ++b) total += hist[b];
+    if (total == 0) return;
     unsigned __int128 before = 0;
     uint32_t k = 1;
     for (uint32_t b = 0; b < n_bins && k < n_slabs; ++b) {
-        const unsigned __int128 after = before + ctx->h_zhist[b];
+        const unsigned __int128 after = before + hist[b];
         while (k < n_slabs && after * n_slabs >= total * k) {
             // the k-th cut falls inside bin b: take whichever end of the bin is closer to the target
             const unsigned __int128 target_n = total * k;  // compare in units of 1/n_slabs
@@ -861,6 +981,142 @@ int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t 
     // every slab keeps at least one layer
     for (uint32_t j = 1; j < n_slabs; ++j) out_z[j] = std::max(out_z[j], out_z[j - 1] + 1);
     for (uint32_t j = n_slabs - 1; j >= 1; --j) out_z[j] = std::min(out_z[j], out_z[j + 1] - 1);
+}
+
+bool plan_params_ok(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t n_slabs)
+{
+    const uint32_t ss = params->supersampling ? params->supersampling : 1u;
+    const uint32_t G = params->resolution;
+    if (G == 0 || ss > 2 || (uint64_t) G * ss > 65535u || n_slabs == 0 || n_slabs > G) {
+        ctx->err = "slab plan: resolution must be non-zero and below 65536 samples, 1 <= n_slabs <= resolution";
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t n_slabs, uint32_t *out_z,
+                       float *out_bounds)
+{
+    if (!ctx || !params || !out_z || n_slabs == 0) return O2V_HIP_ERR_BAD_ARGUMENT;
+    if (!plan_params_ok(ctx, params, n_slabs)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const uint32_t G = params->resolution;
+    for (uint32_t k = 0; k <= n_slabs; ++k) out_z[k] = (uint32_t) ((uint64_t) G * k / n_slabs);  // equal heights
+    if (out_bounds)
+        for (int i = 0; i < 6; ++i) out_bounds[i] = params->bounds_known ? params->bounds[i] : 0.f;
+    if (ctx->n_tris == 0) return O2V_HIP_OK;
+    uint32_t n_bins = 0, bin_out = 0;
+    int rc;
+    if ((rc = plan_passes(ctx, params, 0, ctx->n_tris, nullptr, 0, n_bins, bin_out, nullptr))) return rc;
+    if (out_bounds && !params->bounds_known)
+        for (int i = 0; i < 6; ++i) out_bounds[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
+    cuts_from_histogram(ctx->h_zhist, n_bins, bin_out, G, n_slabs, out_z);
+    return O2V_HIP_OK;
+}
+
+void o2v_hip_cuts_from_histogram(const uint64_t *hist, uint32_t n_bins, uint32_t bin_layers, uint32_t resolution,
+                                 uint32_t n_slabs, uint32_t *out_z)
+{
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "histogram word");
+    if (!hist || !out_z || !n_slabs || !bin_layers) return;
+    cuts_from_histogram(reinterpret_cast<const unsigned long long *>(hist), n_bins, bin_layers, resolution, n_slabs, out_z);
+}
+
+int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip_params *params, uint64_t *out_count,
+                             uint64_t *out_counts_all, uint32_t *out_cuts)
+{
+    if (!ctx || !params) return O2V_HIP_ERR_BAD_ARGUMENT;
+    if (out_count) *out_count = 0;
+    const uint32_t world = comm ? (uint32_t) comm->world : 1u, rank = comm ? (uint32_t) comm->rank : 0u;
+    // test hook: a world of one normally needs no collective; O2V_TEST_FORCE_COLLECTIVES=1 runs them anyway (this is how
+    // the RCCL code path is exercised on a single-GPU machine)
+    const char *force = std::getenv("O2V_TEST_FORCE_COLLECTIVES");
+    if (world == 1 && !(comm && force && force[0] == '1')) {
+        o2v_hip_params whole = *params;
+        whole.z_begin = whole.z_end = 0;
+        uint64_t n = 0;
+        const int rc = o2v_hip_voxelize(ctx, &whole, &n);
+        if (rc) return rc;
+        if (out_count) *out_count = n;
+        if (out_counts_all) out_counts_all[0] = n;
+        if (out_cuts) {
+            out_cuts[0] = 0;
+            out_cuts[1] = params->resolution;
+        }
+        return O2V_HIP_OK;
+    }
+    if (!plan_params_ok(ctx, params, world)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->ev_coll[0])
+        for (auto &e : ctx->ev_coll) O2V_CHECK(hipEventCreate(&e));
+    if (ctx->cap_counts < world) {
+        if (ctx->d_counts) O2V_CHECK(hipFree(ctx->d_counts));
+        if (ctx->h_counts) O2V_CHECK(hipHostFree(ctx->h_counts));
+        ctx->d_counts = ctx->h_counts = nullptr;
+        ctx->cap_counts = 0;
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), world * sizeof(unsigned long long)));
+        O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts), world * sizeof(unsigned long long), hipHostMallocDefault));
+        ctx->cap_counts = world;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    // this rank's share of the triangle list, in whole blocks of 256 (the unit of the block extents)
+    const uint64_t T = ctx->n_tris, n_blocks = (T + kBlock - 1) / kBlock;
+    const uint64_t bpr = std::max<uint64_t>(1, (n_blocks + world - 1) / world);
+    const uint64_t b0 = std::min<uint64_t>(n_blocks, (uint64_t) rank * bpr), b1 = std::min<uint64_t>(n_blocks, (uint64_t) (rank + 1) * bpr);
+    const uint64_t tri_begin = b0 * kBlock, tri_end = std::min<uint64_t>(T, b1 * kBlock);
+    uint32_t n_bins = 0, bin_out = 0;
+    float coll_ms = 0.f;
+    int rc = plan_passes(ctx, params, tri_begin, tri_end, comm, bpr, n_bins, bin_out, &coll_ms);
+    if (rc) return rc;
+    std::vector<uint32_t> cuts(world + 1);
+    cuts_from_histogram(ctx->h_zhist, n_bins, bin_out, params->resolution, world, cuts.data());
+    o2v_hip_params mine = *params;
+    if (!params->bounds_known) {
+        mine.bounds_known = 1;
+        for (int i = 0; i < 6; ++i) mine.bounds[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
+    }
+    mine.z_begin = cuts[rank];
+    mine.z_end = cuts[rank + 1];
+    const float plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    uint64_t n = 0;
+    const int rc_vox = o2v_hip_voxelize(ctx, &mine, &n);
+    // Every rank takes part in the exchange of the counts, also one whose voxelization failed (it reports ~0), so that no
+    // rank is left waiting in a collective.
+    hipStream_t s = ctx->stream;
+    ctx->h_counts[rank] = rc_vox ? ~0ull : n;
+    const std::string vox_err = ctx->err;
+    O2V_CHECK(hipMemcpyAsync(ctx->d_counts + rank, ctx->h_counts + rank, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+    O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s));
+    rc = comm->allgather(ctx->d_counts, sizeof(unsigned long long), s);
+    if (rc) {
+        ctx->err = std::string("collective failed: ") + comm->err;
+        return rc;
+    }
+    O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s));
+    O2V_CHECK(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, world * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    O2V_CHECK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    O2V_CHECK(hipEventElapsedTime(&ms, ctx->ev_coll[0], ctx->ev_coll[1]));
+    ctx->timings.plan_ms = plan_ms;
+    ctx->timings.collective_ms = coll_ms + ms;
+    if (rc_vox) {
+        ctx->err = vox_err;
+        return rc_vox;
+    }
+    for (uint32_t r = 0; r < world; ++r)
+        if (ctx->h_counts[r] == ~0ull) {
+            ctx->err = "the voxelization failed on rank " + std::to_string(r);
+            return O2V_HIP_ERR_HIP;
+        }
+    if (out_count) *out_count = n;
+    if (out_counts_all)
+        for (uint32_t r = 0; r < world; ++r) out_counts_all[r] = ctx->h_counts[r];
+    if (out_cuts)
+        for (uint32_t r = 0; r <= world; ++r) out_cuts[r] = cuts[r];
     return O2V_HIP_OK;
 }
 
@@ -875,6 +1131,39 @@ int o2v_hip_read_voxels(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_
     O2V_CHECK(hipSetDevice(ctx->device));
     O2V_CHECK(hipMemcpy(out, ctx->d_out + first, count * sizeof(uint4), hipMemcpyDeviceToHost));
     return O2V_HIP_OK;
+}
+
+int o2v_hip_read_voxels_async(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count)
+{
+    if (!ctx || (!out && count)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    if (first + count > ctx->n_vox) {
+        ctx->err = "voxel range out of bounds";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
+    if (!count) return O2V_HIP_OK;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    O2V_CHECK(hipMemcpyAsync(out, ctx->d_out + first, count * sizeof(uint4), hipMemcpyDeviceToHost, ctx->stream));
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_read_voxels_wait(o2v_hip_ctx *ctx)
+{
+    if (!ctx) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    O2V_CHECK(hipStreamSynchronize(ctx->stream));
+    return O2V_HIP_OK;
+}
+
+void *o2v_hip_alloc_pinned(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void o2v_hip_free_pinned(void *p)
+{
+    if (p) (void) hipHostFree(p);
 }
 
 int o2v_hip_voxels_device_ptr(o2v_hip_ctx *ctx, const uint32_t **out_ptr, uint64_t *out_count)

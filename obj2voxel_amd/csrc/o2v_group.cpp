@@ -1,0 +1,283 @@
+// o2v_group.cpp -- one process, N GPUs: a context and a host thread per GPU, the grid sharded by z-slab.
+//
+// This is what one obj2voxel_voxelize() call does when more than one device is named (O2V_DEVICES), where the reference
+// hands its 64^3 chunks to a pool of worker threads (src/obj2voxel.cpp:467-520, src/threading.hpp): the "workers" are
+// GPUs, each owning one z-slab, and the per-rank work is o2v_hip_voxelize_sharded (o2v_device.hip).  The ranks combine
+// their planning data with RCCL over xGMI; if RCCL cannot be used (a device listed twice - only sensible for tests on
+// a single-GPU machine - or librccl missing) the same collectives run over shared host memory between the threads.
+#include "o2v_comm.hpp"
+#include "o2v_device_internal.hpp"
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// Collectives between the threads of one process over host memory: every rank deposits its buffer, the last one to
+// arrive reduces, everybody copies the result out.  Two barrier phases per collective.
+struct SharedExchange {
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t world = 1, arrived = 0, generation = 0;
+    std::vector<void *> bufs;
+
+    // calls `last` on exactly one thread once all ranks have deposited `buf`; returns after it has run
+    void rendezvous(uint32_t rank, void *buf, const std::function<void(std::vector<void *> &)> &last)
+    {
+        std::unique_lock<std::mutex> lock{m};
+        bufs[rank] = buf;
+        const uint32_t gen = generation;
+        if (++arrived == world) {
+            last(bufs);
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        }
+        else {
+            cv.wait(lock, [&] { return generation != gen; });
+        }
+    }
+};
+
+struct RankLink {
+    SharedExchange *x;
+    uint32_t rank;
+};
+
+template <typename T, typename Op>
+int shared_allreduce(void *user, T *buf, size_t n, Op op)
+{
+    RankLink *l = static_cast<RankLink *>(user);
+    l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
+        T *first = static_cast<T *>(bufs[0]);
+        for (uint32_t r = 1; r < l->x->world; ++r)
+            for (size_t i = 0; i < n; ++i) first[i] = op(first[i], static_cast<T *>(bufs[r])[i]);
+        for (uint32_t r = 1; r < l->x->world; ++r) std::memcpy(bufs[r], first, n * sizeof(T));
+    });
+    return 0;
+}
+int shared_min_u32(void *u, uint32_t *b, size_t n) { return shared_allreduce(u, b, n, [](uint32_t a, uint32_t c) { return std::min(a, c); }); }
+int shared_max_u32(void *u, uint32_t *b, size_t n) { return shared_allreduce(u, b, n, [](uint32_t a, uint32_t c) { return std::max(a, c); }); }
+int shared_sum_u64(void *u, uint64_t *b, size_t n) { return shared_allreduce(u, b, n, [](uint64_t a, uint64_t c) { return a + c; }); }
+int shared_allgather(void *user, void *buf, size_t bytes)
+{
+    RankLink *l = static_cast<RankLink *>(user);
+    l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
+        for (uint32_t src = 0; src < l->x->world; ++src)
+            for (uint32_t dst = 0; dst < l->x->world; ++dst)
+                if (src != dst)
+                    std::memcpy(static_cast<char *>(bufs[dst]) + src * bytes, static_cast<char *>(bufs[src]) + src * bytes, bytes);
+    });
+    return 0;
+}
+int shared_broadcast(void *user, void *buf, size_t bytes, int root)
+{
+    RankLink *l = static_cast<RankLink *>(user);
+    l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
+        for (uint32_t dst = 0; dst < l->x->world; ++dst)
+            if ((int) dst != root) std::memcpy(bufs[dst], bufs[root], bytes);
+    });
+    return 0;
+}
+
+}  // namespace
+
+struct o2v_hip_group {
+    std::vector<int> devices;
+    std::vector<o2v_hip_ctx *> ctx;
+    std::vector<o2v_hip_comm *> comm;
+    SharedExchange exchange;
+    std::vector<RankLink> links;
+    bool rccl = false;
+    std::string err;
+
+    // runs fn(rank) on one thread per rank (rank 0 on the caller's) and returns the first non-zero result
+    int on_every_rank(const std::function<int(uint32_t)> &fn)
+    {
+        const uint32_t n = (uint32_t) ctx.size();
+        std::vector<int> rc(n, 0);
+        std::vector<std::thread> threads;
+        for (uint32_t r = 1; r < n; ++r) threads.emplace_back([&, r] { rc[r] = fn(r); });
+        rc[0] = fn(0);
+        for (std::thread &t : threads) t.join();
+        for (uint32_t r = 0; r < n; ++r)
+            if (rc[r]) {
+                err = "rank " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + o2v_hip_last_error(ctx[r]);
+                return rc[r];
+            }
+        return O2V_HIP_OK;
+    }
+};
+
+extern "C" {
+
+// The shared-memory exchange on its own (no GPU): n threads run the callbacks self-test against each other, several rounds.
+int o2v_hip_group_exchange_selftest(uint32_t n_threads)
+{
+    if (!n_threads) return O2V_HIP_ERR_BAD_ARGUMENT;
+    SharedExchange x;
+    x.world = n_threads;
+    x.bufs.assign(n_threads, nullptr);
+    std::vector<RankLink> links(n_threads);
+    std::vector<int> rc(n_threads, 0);
+    std::vector<std::thread> threads;
+    for (uint32_t r = 0; r < n_threads; ++r) {
+        links[r] = RankLink{&x, r};
+        threads.emplace_back([&, r] {
+            o2v_hip_comm_callbacks cb{&links[r], shared_min_u32, shared_max_u32, shared_sum_u64, shared_allgather, shared_broadcast};
+            for (int round = 0; round < 20 && !rc[r]; ++round) rc[r] = o2v_hip_comm_callbacks_selftest(&cb, (int) r, (int) n_threads);
+        });
+    }
+    for (std::thread &t : threads) t.join();
+    for (int v : rc)
+        if (v) return v;
+    return 0;
+}
+
+int o2v_hip_group_create(const int *devices, uint32_t n_devices, o2v_hip_group **out)
+{
+    if (!devices || !n_devices || !out) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    o2v_hip_group *g = new o2v_hip_group;
+    g->devices.assign(devices, devices + n_devices);
+    g->ctx.assign(n_devices, nullptr);
+    g->comm.assign(n_devices, nullptr);
+    for (uint32_t r = 0; r < n_devices; ++r) {
+        const int rc = o2v_hip_create(devices[r], &g->ctx[r]);
+        if (rc) {
+            o2v_hip_group_destroy(g);
+            return rc;
+        }
+    }
+    // RCCL wants every rank on its own device
+    const bool distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == n_devices;
+    const char *force = std::getenv("O2V_GROUP_COMM");  // "host": shared host memory even where RCCL would work
+    if (n_devices > 1 && distinct && !(force && std::strcmp(force, "host") == 0)) {
+        uint8_t id[O2V_HIP_COMM_ID_BYTES];
+        std::string err;
+        if (o2v::rccl_unique_id(id, err)) {
+            // ncclCommInitRank blocks until every rank has joined: one thread per rank
+            std::vector<std::string> errs(n_devices);
+            std::vector<std::thread> threads;
+            for (uint32_t r = 0; r < n_devices; ++r)
+                threads.emplace_back([&, r] { g->comm[r] = o2v::make_rccl_comm(id, (int) r, (int) n_devices, devices[r], errs[r]); });
+            for (std::thread &t : threads) t.join();
+            g->rccl = std::all_of(g->comm.begin(), g->comm.end(), [](o2v_hip_comm *c) { return c != nullptr; });
+            if (!g->rccl) {
+                for (o2v_hip_comm *&c : g->comm) {
+                    delete c;
+                    c = nullptr;
+                }
+                std::fprintf(stderr, "[o2v] RCCL communicators could not be created (%s); the ranks exchange through host memory\n",
+                             errs[0].c_str());
+            }
+        }
+        else {
+            std::fprintf(stderr, "[o2v] %s; the ranks exchange through host memory\n", err.c_str());
+        }
+    }
+    if (!g->rccl) {
+        g->exchange.world = n_devices;
+        g->exchange.bufs.assign(n_devices, nullptr);
+        g->links.resize(n_devices);
+        for (uint32_t r = 0; r < n_devices; ++r) {
+            g->links[r] = RankLink{&g->exchange, r};
+            o2v_hip_comm_callbacks cb{&g->links[r], shared_min_u32, shared_max_u32, shared_sum_u64, shared_allgather, shared_broadcast};
+            g->comm[r] = o2v::make_callback_comm(cb, (int) r, (int) n_devices);
+        }
+    }
+    *out = g;
+    return O2V_HIP_OK;
+}
+
+void o2v_hip_group_destroy(o2v_hip_group *g)
+{
+    if (!g) return;
+    for (o2v_hip_comm *c : g->comm) delete c;
+    for (o2v_hip_ctx *c : g->ctx)
+        if (c) o2v_hip_destroy(c);
+    delete g;
+}
+
+uint32_t o2v_hip_group_size(const o2v_hip_group *g) { return g ? (uint32_t) g->ctx.size() : 0u; }
+o2v_hip_ctx *o2v_hip_group_ctx(o2v_hip_group *g, uint32_t rank) { return g && rank < g->ctx.size() ? g->ctx[rank] : nullptr; }
+const char *o2v_hip_group_comm_kind(const o2v_hip_group *g) { return g && !g->comm.empty() && g->comm[0] ? g->comm[0]->kind() : "none"; }
+const char *o2v_hip_group_last_error(const o2v_hip_group *g) { return g ? g->err.c_str() : "null group"; }
+
+int o2v_hip_group_set_triangles(o2v_hip_group *g, const float *verts, const float *uvs, const uint32_t *types,
+                                const float *colors, const int32_t *texids, uint64_t count, int upload_mode)
+{
+    if (!g || (count && !verts)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const uint32_t n = (uint32_t) g->ctx.size();
+    if (upload_mode == O2V_HIP_UPLOAD_H2D || n == 1 || count == 0) {
+        // every GPU pulls the arrays over its own PCIe link, all at once
+        return g->on_every_rank([&](uint32_t r) { return o2v_hip_set_triangles(g->ctx[r], verts, uvs, types, colors, texids, count); });
+    }
+    // one host-to-device copy, then GPU to GPU over xGMI
+    int rc = o2v_hip_set_triangles(g->ctx[0], verts, uvs, types, colors, texids, count);
+    if (rc) {
+        g->err = std::string("rank 0: ") + o2v_hip_last_error(g->ctx[0]);
+        return rc;
+    }
+    const o2v::TriHints hints = o2v::ctx_tri_hints(g->ctx[0]);
+    const o2v::TriBuffers src = o2v::ctx_tri_buffers(g->ctx[0]);
+    return g->on_every_rank([&](uint32_t r) -> int {
+        o2v_hip_ctx *c = g->ctx[r];
+        if (r != 0) {
+            const int rc2 = o2v::ctx_alloc_triangles(c, count, uvs != nullptr, types != nullptr, colors != nullptr, texids != nullptr);
+            if (rc2) return rc2;
+        }
+        (void) hipSetDevice(o2v::ctx_device(c));
+        const o2v::TriBuffers dst = o2v::ctx_tri_buffers(c);
+        hipStream_t s = o2v::ctx_stream(c);
+        struct Part {
+            void *dst;
+            const void *src;
+            size_t bytes;
+        } parts[5] = {{dst.verts, src.verts, count * 36}, {dst.uvs, src.uvs, count * 24}, {dst.types, src.types, count * 4},
+                      {dst.colors, src.colors, count * 12}, {dst.texids, src.texids, count * 4}};
+        for (const Part &p : parts) {
+            if (!p.src) continue;
+            if (upload_mode == O2V_HIP_UPLOAD_BROADCAST) {
+                // rank 0's buffer is the root's send buffer, every other rank's its receive buffer (collective: all ranks call)
+                if (g->comm[r]->broadcast(p.dst, p.bytes, 0, s)) return O2V_HIP_ERR_HIP;
+            }
+            else if (r != 0) {
+                if (hipMemcpyPeerAsync(p.dst, o2v::ctx_device(c), p.src, g->devices[0], p.bytes, s) != hipSuccess) return O2V_HIP_ERR_HIP;
+            }
+        }
+        return r == 0 ? (hipStreamSynchronize(s) == hipSuccess ? O2V_HIP_OK : O2V_HIP_ERR_HIP) : o2v::ctx_finish_triangles(c, hints.any_textured, &hints);
+    });
+}
+
+int o2v_hip_group_set_textures(o2v_hip_group *g, const o2v_hip_texture *textures, uint32_t count)
+{
+    if (!g) return O2V_HIP_ERR_BAD_ARGUMENT;
+    return g->on_every_rank([&](uint32_t r) { return o2v_hip_set_textures(g->ctx[r], textures, count); });
+}
+
+int o2v_hip_group_voxelize(o2v_hip_group *g, const o2v_hip_params *params, uint64_t *out_counts, uint32_t *out_cuts)
+{
+    if (!g || !params || !out_counts) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const uint32_t n = (uint32_t) g->ctx.size();
+    std::vector<uint64_t> counts((size_t) n * n);
+    std::vector<uint32_t> cuts((size_t) n * (n + 1));
+    const int rc = g->on_every_rank([&](uint32_t r) {
+        uint64_t mine = 0;
+        return o2v_hip_voxelize_sharded(g->ctx[r], n > 1 ? g->comm[r] : nullptr, params, &mine, &counts[(size_t) r * n], &cuts[(size_t) r * (n + 1)]);
+    });
+    if (rc) return rc;
+    for (uint32_t r = 0; r < n; ++r) out_counts[r] = counts[r];  // every rank gathered the same list; rank 0's copy
+    if (out_cuts)
+        for (uint32_t r = 0; r <= n; ++r) out_cuts[r] = cuts[r];
+    return O2V_HIP_OK;
+}
+
+}  // extern "C"

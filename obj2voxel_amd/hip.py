@@ -22,7 +22,8 @@ class _Texture(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("bounds_ms", C.c_float), ("expand_ms", C.c_float), ("voxelize_ms", C.c_float),
-                ("scan_ms", C.c_float), ("resolve_ms", C.c_float), ("total_ms", C.c_float), ("passes", C.c_uint32)]
+                ("scan_ms", C.c_float), ("resolve_ms", C.c_float), ("total_ms", C.c_float), ("passes", C.c_uint32),
+                ("plan_ms", C.c_float), ("collective_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -55,6 +56,28 @@ def _bind():
     L.o2v_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.o2v_hip_get_transform.argtypes = [C.c_void_p, C.c_void_p]
     L.o2v_hip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+    L.o2v_hip_comm_unique_id.argtypes = [C.c_void_p]
+    L.o2v_hip_comm_create_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.o2v_hip_comm_create_callbacks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.o2v_hip_comm_destroy.argtypes = [C.c_void_p]
+    L.o2v_hip_comm_kind.argtypes = [C.c_void_p]
+    L.o2v_hip_comm_kind.restype = C.c_char_p
+    L.o2v_hip_comm_last_error.argtypes = [C.c_void_p]
+    L.o2v_hip_comm_last_error.restype = C.c_char_p
+    L.o2v_hip_voxelize_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Params), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]
+    L.o2v_hip_group_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.o2v_hip_group_destroy.argtypes = [C.c_void_p]
+    L.o2v_hip_group_size.argtypes = [C.c_void_p]
+    L.o2v_hip_group_size.restype = C.c_uint32
+    L.o2v_hip_group_ctx.argtypes = [C.c_void_p, C.c_uint32]
+    L.o2v_hip_group_ctx.restype = C.c_void_p
+    L.o2v_hip_group_comm_kind.argtypes = [C.c_void_p]
+    L.o2v_hip_group_comm_kind.restype = C.c_char_p
+    L.o2v_hip_group_last_error.argtypes = [C.c_void_p]
+    L.o2v_hip_group_last_error.restype = C.c_char_p
+    L.o2v_hip_group_set_triangles.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint64, C.c_int]
+    L.o2v_hip_group_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.o2v_hip_group_voxelize.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_void_p, C.c_void_p]
     L.o2v_hip_plan_slabs.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_void_p]
     return L
 
@@ -70,8 +93,12 @@ def _ptr(a):
 class DeviceVoxelizer:
     """Owns one GPU's dense grid slab and work buffers; reusable across voxelize() calls."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed_ctx=None):
         self._L = _bind()
+        self._owned = _borrowed_ctx is None
+        if _borrowed_ctx is not None:       # a rank of a DeviceGroup: the group owns the context
+            self._ctx = C.c_void_p(_borrowed_ctx)
+            return
         self._ctx = C.c_void_p()
         rc = self._L.o2v_hip_create(device, C.byref(self._ctx))
         if rc != 0:
@@ -79,9 +106,9 @@ class DeviceVoxelizer:
         self._keep = []
 
     def close(self):
-        if self._ctx:
+        if self._ctx and self._owned:
             self._L.o2v_hip_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        self._ctx = C.c_void_p()
 
     def __del__(self):
         try:
@@ -147,6 +174,19 @@ class DeviceVoxelizer:
             return self.count
         return self.read_voxels()
 
+    def voxelize_sharded(self, comm, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
+                         read=True):
+        """o2v_hip_voxelize_sharded: collective over `comm` (a Comm); this rank voxelizes its planned z-slab.
+        Returns (voxels or count of this rank, counts of all ranks, z cuts)."""
+        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0))
+        n = C.c_uint64(0)
+        counts = np.zeros(comm.world, dtype=np.uint64)
+        cuts = np.zeros(comm.world + 1, dtype=np.uint32)
+        self._check(self._L.o2v_hip_voxelize_sharded(self._ctx, comm.handle, C.byref(p), C.byref(n), _ptr(counts), _ptr(cuts)),
+                    "o2v_hip_voxelize_sharded")
+        self.count = n.value
+        return (self.read_voxels() if read else self.count), [int(c) for c in counts], [int(z) for z in cuts]
+
     def read_voxels(self):
         out = np.empty((self.count, 4), dtype=np.uint32)
         if self.count:
@@ -172,3 +212,154 @@ class DeviceVoxelizer:
         out = np.zeros(12, dtype=np.float32)
         self._L.o2v_hip_get_transform(self._ctx, _ptr(out))
         return out
+
+
+class _Callbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p),
+                ("allreduce_min_u32", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t)),
+                ("allreduce_max_u32", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_size_t)),
+                ("allreduce_sum_u64", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t)),
+                ("allgather", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("broadcast", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int))]
+
+
+class Comm:
+    """The collectives of the sharded voxelization (include/o2v_hip.h, multi-GPU section) for one rank."""
+
+    def __init__(self, handle, rank, world, keep=None):
+        self._L = _bind()
+        self.handle, self.rank, self.world, self._keep = handle, rank, world, keep
+
+    @property
+    def kind(self):
+        return self._L.o2v_hip_comm_kind(self.handle).decode()
+
+    def close(self):
+        if self.handle:
+            self._L.o2v_hip_comm_destroy(self.handle)
+            self.handle = None
+
+    @staticmethod
+    def unique_id():
+        """ncclGetUniqueId through the library: 128 bytes that rank 0 ships to every rank."""
+        buf = (C.c_uint8 * 128)()
+        if _bind().o2v_hip_comm_unique_id(buf) != 0:
+            raise DeviceError("o2v_hip_comm_unique_id failed: librccl is not available")
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, unique_id, rank, world, device):
+        """RCCL over xGMI: every rank calls this with rank 0's unique id (blocks until all have joined)."""
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = _bind().o2v_hip_comm_create_rccl(buf, rank, world, device, C.byref(h))
+        if rc != 0:
+            raise DeviceError(f"o2v_hip_comm_create_rccl failed with code {rc}")
+        return cls(h, rank, world)
+
+    @classmethod
+    def torch_distributed(cls, dist):
+        """Host-memory collectives over an initialised torch.distributed group (gloo): for the CPU-side tests of the
+        N > 1 path and for ranks that share one GPU, where RCCL cannot be used."""
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def array(ptr, n, ctype):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
+
+        def allreduce(op, ctype):
+            def fn(user, buf, n):
+                a = array(buf, n, ctype)
+                t = torch.from_numpy(a.astype(np.int64))  # gloo has no unsigned reductions; the values fit int64
+                dist.all_reduce(t, op=op)
+                a[:] = t.numpy().astype(a.dtype)
+                return 0
+            return fn
+
+        def allgather(user, buf, bytes_per_rank):
+            a = array(buf, bytes_per_rank * world, C.c_uint8)
+            parts = [torch.empty(bytes_per_rank, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(a[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy()))
+            a[:] = torch.cat(parts).numpy()
+            return 0
+
+        def broadcast(user, buf, n, root):
+            a = array(buf, n, C.c_uint8)
+            t = torch.from_numpy(a.copy())
+            dist.broadcast(t, src=root)
+            a[:] = t.numpy()
+            return 0
+
+        F = dict(_Callbacks._fields_)
+        cb = _Callbacks(None,
+                        F["allreduce_min_u32"](allreduce(dist.ReduceOp.MIN, C.c_uint32)),
+                        F["allreduce_max_u32"](allreduce(dist.ReduceOp.MAX, C.c_uint32)),
+                        F["allreduce_sum_u64"](allreduce(dist.ReduceOp.SUM, C.c_uint64)),
+                        F["allgather"](allgather), F["broadcast"](broadcast))
+        h = C.c_void_p()
+        rc = _bind().o2v_hip_comm_create_callbacks(C.byref(cb), rank, world, C.byref(h))
+        if rc != 0:
+            raise DeviceError(f"o2v_hip_comm_create_callbacks failed with code {rc}")
+        return cls(h, rank, world, keep=cb)
+
+
+class DeviceGroup:
+    """o2v_hip_group: one process, one context and host thread per listed GPU, grid sharded by z-slab."""
+
+    UPLOAD_H2D, UPLOAD_BROADCAST, UPLOAD_PEER = 0, 1, 2
+
+    def __init__(self, devices):
+        self._L = _bind()
+        self._g = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self._L.o2v_hip_group_create(arr, len(devices), C.byref(self._g))
+        if rc != 0:
+            raise DeviceError(f"o2v_hip_group_create({list(devices)}) failed with code {rc}")
+        self.size = len(devices)
+        self.ranks = [DeviceVoxelizer(_borrowed_ctx=self._L.o2v_hip_group_ctx(self._g, r)) for r in range(self.size)]
+
+    @property
+    def comm_kind(self):
+        return self._L.o2v_hip_group_comm_kind(self._g).decode()
+
+    def close(self):
+        if self._g:
+            self._L.o2v_hip_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise DeviceError(f"{what} failed with code {rc}: {self._L.o2v_hip_group_last_error(self._g).decode()}")
+
+    def set_triangles(self, verts, uvs=None, types=None, colors=None, texids=None, upload=0):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 9)
+        T = verts.shape[0]
+        uvs = None if uvs is None else np.ascontiguousarray(uvs, dtype=np.float32).reshape(T, 6)
+        types = None if types is None else np.ascontiguousarray(types, dtype=np.uint32).reshape(T)
+        colors = None if colors is None else np.ascontiguousarray(colors, dtype=np.float32).reshape(T, 3)
+        texids = None if texids is None else np.ascontiguousarray(texids, dtype=np.int32).reshape(T)
+        self._check(self._L.o2v_hip_group_set_triangles(self._g, _ptr(verts), _ptr(uvs), _ptr(types), _ptr(colors),
+                                                        _ptr(texids), T, upload), "o2v_hip_group_set_triangles")
+
+    def set_textures(self, textures):
+        arr = (_Texture * max(1, len(textures)))()
+        keep = []
+        for i, (pix, wrap) in enumerate(textures):
+            pix = np.ascontiguousarray(pix, dtype=np.uint8)
+            keep.append(pix)
+            h, w, c = pix.shape
+            arr[i] = _Texture(pix.ctypes.data, w, h, c, int(wrap))
+        self._check(self._L.o2v_hip_group_set_textures(self._g, C.cast(arr, C.c_void_p), len(textures)), "o2v_hip_group_set_textures")
+
+    def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None, read=True):
+        """Returns (list of per-rank voxel arrays, or the per-rank counts if read=False; z cuts)."""
+        p = DeviceVoxelizer._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0))
+        counts = np.zeros(self.size, dtype=np.uint64)
+        cuts = np.zeros(self.size + 1, dtype=np.uint32)
+        self._check(self._L.o2v_hip_group_voxelize(self._g, C.byref(p), _ptr(counts), _ptr(cuts)), "o2v_hip_group_voxelize")
+        for r, d in enumerate(self.ranks):
+            d.count = int(counts[r])
+        cuts = [int(z) for z in cuts]
+        if not read:
+            return [int(c) for c in counts], cuts
+        return [d.read_voxels() for d in self.ranks], cuts

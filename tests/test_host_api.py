@@ -29,7 +29,7 @@ def a():
 def _declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:obj2voxel|o2v_hip)_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:obj2voxel|o2v)_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol(a):

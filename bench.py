@@ -1,40 +1,58 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the voxelization hot path on N MI355X GPUs of one node.
 
-Metric (BASELINE.json): Mvoxels/s (output voxels / second) at a 1024^3 grid, with Mtris/s beside it.
+Metric (BASELINE.json): Mvoxels/s (output voxels / second), with Mtris/s beside it, "at 1024^3 grid; 1/2/4/8 MI355X".
 
-Workload at N=1: BASELINE.json configs[2] ("Stanford Dragon (~870k tris) at 1024^3, 1xMI355X"), which is the
-configuration the metric is quoted on ("at 1024^3 grid").  The asset is not in the reference tree and there is
-no network, so the stand-in is the deterministic UV sphere of SURVEY.md section 8d: nv = 467 -> 870 488
-triangles, MATERIALLESS, MAX strategy, resolution 1024.
+Workloads (the assets BASELINE.json names are not in the reference tree and there is no network; the stand-ins are the
+deterministic meshes of SURVEY.md section 8d):
+  N = 1      BASELINE.json configs[2] "Stanford Dragon (~870k tris) at 1024^3": uv-sphere nv = 467 -> 870 488 triangles,
+             MATERIALLESS, MAX, resolution 1024 - the configuration the metric is quoted on.
+  N = 2, 4   the same job grown with N so that triangles and output voxels per GPU stay fixed on average (weak scaling):
+             resolution 1024 * sqrt(N), nv = 467 * sqrt(N).
+  N = 8      BASELINE.json configs[4] "Synthetic 50M-tri tessellated sphere at 4096^3, z-slab split across 8xMI355X":
+             uv-sphere nv = 3536 -> 49 999 040 triangles at 4096^3.  The weak-scaling job of the N = 2, 4 series (resolution
+             2896, 6.97 M triangles) is timed in the same run and reported under "weak_scaling_companion".
+             (--workload weak|config4 overrides the choice for any N > 1.)
 
-One step = one pass of the whole device pipeline (bounds -> transform -> exact subdivision -> AABB walk + clip
--> per-voxel combine: for this workload (MAX, no textures) a 64-bit atomic max per hit and one emission pass over the
-dirty bricks) over triangles already resident in HBM, leaving the (x, y, z, argb) records in HBM.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the grid is split into N z-slabs,
-every rank voxelizes its slab from the replicated triangle list (triangles are binned to slabs on the device
-by AABB; no data-path collective is needed: SURVEY.md section 8e).  The slab cuts are work-balanced: each step
-every rank runs o2v_hip_plan_slabs (a z-histogram of predicted hits over the replicated triangles) and takes its
-own slab, so the plan's cost is inside the timed region.  Scaling is weak: the job grows with N so that triangles
-and output voxels per GPU stay fixed on average (resolution 1024*sqrt(N), nv = 467*sqrt(N)).
+One step = one pass of the whole device pipeline over triangles already resident in HBM, the (x, y, z, argb) records left
+in HBM.  N = 1: o2v_hip_voxelize (bounds -> transform -> exact subdivision -> AABB walk + clip -> per-voxel combine ->
+records).  N > 1: one process per GPU (torch.distributed; backend nccl = RCCL), every rank holding the triangle list, and
+one step = o2v_hip_voxelize_sharded: the bounds and work-histogram passes sharded over the ranks and combined with RCCL
+all-reduces, block extents and slab counts all-gathered, each rank voxelizing its work-balanced z-slab.  No voxel data
+crosses GPUs (every output voxel is owned by exactly one slab).
 """
 import argparse
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0     # wave64 VALU instructions / ns: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G/s
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "current.json")   # rocprofv3 PMC summary of this command (tools/collect_profiles.py)
 
 
-def workload_for(n_gpus):
+def workload_for(n_gpus, kind="auto"):
+    """(name, resolution, nv).  kind: auto | weak | config4"""
+    if n_gpus == 1:
+        return "config2", 1024, 467
+    if kind == "config4" or (kind == "auto" and n_gpus == 8):
+        return "config4", 4096, 3536
     s = math.sqrt(n_gpus)
-    res = int(round(1024 * s / (2 * n_gpus))) * 2 * n_gpus  # even slabs of equal height
-    nv = int(round(467 * s))
-    return res, nv
+    return "weak", int(round(1024 * s / (2 * n_gpus))) * 2 * n_gpus, int(round(467 * s))
+
+
+WORKLOAD_TEXT = {
+    "config2": "BASELINE configs[2] stand-in: uv-sphere nv={nv} ({T} tris, Stanford Dragon stand-in) at {res}^3, MATERIALLESS, MAX",
+    "config4": "BASELINE configs[4]: uv-sphere nv={nv} ({T} tris, the 50M-triangle tessellated sphere) at {res}^3, MATERIALLESS, "
+               "MAX, {n} work-balanced z-slabs",
+    "weak": "weak-scaling series of configs[2]: uv-sphere nv={nv} ({T} tris) at {res}^3, MATERIALLESS, MAX, {n} work-balanced z-slabs",
+}
 
 
 def main():
@@ -43,15 +61,17 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the N > 1 code path on a single-GPU box)")
-    ap.add_argument("--same-device", action="store_true", help="debugging: every rank uses GPU 0")
-    ap.add_argument("--equal-slabs", action="store_true", help="N > 1: equal-height z-slabs instead of the work-balanced plan")
+    ap.add_argument("--no-capi", action="store_true", help="skip the obj2voxel_voxelize() wall-time leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise "
+                    "the N > 1 code path on a single-GPU box: the collectives then run over host memory)")
+    ap.add_argument("--same-device", action="store_true", help="debugging: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--workload", default="auto", choices=["auto", "weak", "config4"])
     ap.add_argument("--resolution", type=int, default=0, help="override (debugging only; invalidates the metric)")
     ap.add_argument("--nv", type=int, default=0, help="override (debugging only; invalidates the metric)")
     args = ap.parse_args()
 
     import numpy as np
-    import torch  # first: the HIP runtime torch bundles must be the one that gets loaded
+    import torch  # first: the HIP runtime (and RCCL) torch bundles must be the copies that get loaded
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -76,131 +96,234 @@ def main():
 
     from obj2voxel_amd import hip, meshes, slab as slabs
 
-    res, nv = workload_for(n)
-    if args.resolution:
-        res = args.resolution
-    if args.nv:
-        nv = args.nv
-    verts = meshes.uv_sphere(nv)
-    T = len(verts)
-    z0, z1 = slabs.slab_range(rank, n, res)
-
     dv = hip.DeviceVoxelizer(dev_index if n > 1 else 0)
-    dv.set_triangles(verts)
+    comm = None
+    if n > 1:
+        if args.backend == "nccl":
+            # the library's own RCCL communicator, on its own stream: rank 0 makes the id, torch ships it
+            box = [hip.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = hip.Comm.rccl(box[0], rank, n, dev_index)
+        else:
+            comm = hip.Comm.torch_distributed(dist)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    def time_workload(name, res, nv, steps, warmup):
+        verts = meshes.uv_sphere(nv)
+        dv.set_triangles(verts)
         if n == 1:
-            return dv.voxelize(res, read=False)
-        if args.equal_slabs:
-            return dv.voxelize(res, zslab=(z0, z1), read=False)
-        # every rank derives the same work-balanced cuts from the replicated triangles (o2v_hip_plan_slabs, part of the
-        # timed step: a new mesh needs a new plan), then voxelizes its own slab; the plan's bounds save a second pass
-        cuts, bnd = dv.plan_slabs(res, n)
-        return dv.voxelize(res, zslab=(cuts[rank], cuts[rank + 1]), bounds=bnd, read=False)
+            step = lambda: (dv.voxelize(res, read=False), None)            # noqa: E731
+        else:
+            def step():
+                count, counts, cuts = dv.voxelize_sharded(comm, res, read=False)
+                return count, counts
+        for _ in range(warmup):
+            step()
+        names = ("bounds_ms", "expand_ms", "voxelize_ms", "scan_ms", "resolve_ms", "total_ms", "plan_ms", "collective_ms")
+        acc = {k: 0.0 for k in names}
+        barrier()
+        t0 = time.perf_counter()
+        count = 0
+        for _ in range(steps):
+            count, counts = step()
+            tm = dv.timings()
+            for k in names:
+                acc[k] += tm[k]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed,
+                                                      device="cuda" if (dist is not None and args.backend == "nccl") else None)
+        return {"name": name, "res": res, "nv": nv, "T": len(verts), "verts": verts, "voxels": total_voxels,
+                "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / steps for k in names}, "stats": dv.stats()}
 
-    for _ in range(args.warmup):
-        step()
-    stage_names = ("bounds_ms", "expand_ms", "voxelize_ms", "scan_ms", "resolve_ms", "total_ms")
-    stage_sum = {k: 0.0 for k in stage_names}
-    barrier()
-    t0 = time.perf_counter()
-    count = 0
-    for _ in range(args.steps):
-        count = step()
-        tm = dv.timings()
-        for k in stage_names:
-            stage_sum[k] += tm[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stats = dv.stats()
-
-    total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed,
-                                                  device="cuda" if (dist is not None and args.backend == "nccl") else None)
+    name, res, nv = workload_for(n, args.workload)
+    if args.resolution:
+        res = args.resolution
+    if args.nv:
+        nv = args.nv
+    main_run = time_workload(name, res, nv, args.steps, args.warmup)
+    companion = None
+    if n > 1 and name == "config4" and args.workload == "auto":
+        main_run["verts"] = None   # 1.8 GB of host memory
+        wname, wres, wnv = workload_for(n, "weak")
+        companion = time_workload(wname, wres, wnv, args.steps, args.warmup)
+        companion["verts"] = None
 
     if rank == 0:
-        ms_per_step = max_elapsed / args.steps * 1e3
-        value = total_voxels / (max_elapsed / args.steps) / 1e6
-        stage_avg = {k: stage_sum[k] / args.steps for k in stage_names}
-        # dominant kernel and its algorithmic bytes per launch (DESIGN.md section "Kernels and rooflines")
-        L, tiles, H, V = stats["leaves"], stats["tiles"], stats["hits"], stats["voxels"]
-        B, D, slots = stats["bricks"], stats["dirty_bricks"], stats["pool_slots"]
-        # algorithmic bytes per launch of each stage
-        REC = 16  # sorted record: 16 bytes for a mesh without textured triangles (this workload), else 24
-        Hd = stats["direct_hits"]  # MAX without textures: hits that went straight into the 64-bit max grid
-        Hp = H - Hd                # hits that took the pool -> counting sort -> ordered replay route
-        if Hd:
-            # direct MAX path: the dirty bricks / voxels reported belong to the 64-bit grid (2 KiB per brick)
-            alg_bytes = {
-                "expand_ms": 36 * T + 96 * L + 8 * tiles,
-                "voxelize_ms": 96 * L + 8 * tiles + (8 + 1) * Hd + (32 + 4 + 1) * Hp,
-                "scan_ms": B + 32 * slots + (4 + REC) * Hp,
-                "resolve_ms": REC * Hp + B + 2 * 2048 * D + 16 * V,
-            }
-        else:
-            alg_bytes = {
-                "expand_ms": 36 * T + 96 * L + 8 * tiles,
-                "voxelize_ms": 96 * L + 8 * tiles + (32 + 4 + 1) * H,
-                "scan_ms": B + 1024 * D + (16 + 4) * V + 32 * slots + (4 + REC) * H + 1024 * D,
-                "resolve_ms": 16 * V + REC * H + 16 * V,
-            }
-        kernel_of = {"expand_ms": "k_expand_roots+k_expand_nodes", "voxelize_ms": "k_voxelize",
-                     "scan_ms": "k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks", "resolve_ms": "k_resolve*+k_emit_max"}
-        dom = max(alg_bytes, key=lambda k: stage_avg[k])
-        achieved = alg_bytes[dom] / (stage_avg[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if n == 1 and os.path.exists(tpath):  # the committed PMC pass measured the N = 1 workload
-            try:
-                traffic = json.load(open(tpath)).get(kernel_of[dom])
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": kernel_of[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes": alg_bytes[dom], "kernel_ms": round(stage_avg[dom], 4)}
-        # the fixed whole-pipeline numerator of SURVEY.md section 8d: 8*G^3 + 16*V + 76*T
-        b_alg = 8 * res * res * res + 16 * total_voxels + 76 * T
-        pipeline = {"b_alg_bytes": b_alg, "device_ms": round(stage_avg["total_ms"], 4),
-                    "gbs": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9, 1),
-                    "frac_of_hbm_peak": round(b_alg / (stage_avg["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "stages_ms": {k: round(v, 4) for k, v in stage_avg.items()}}
-        out = {
-            "metric": "Mvoxels/sec at 1024^3 grid", "value": round(value, 2), "unit": "Mvoxels/s", "n_gpus": n,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "mtris_per_s": round(T / (max_elapsed / args.steps) / 1e6, 2),
-            "config": {"workload": f"uv-sphere nv={nv} ({T} tris, Stanford Dragon stand-in) at {res}^3, MATERIALLESS, "
-                                   f"MAX, {n} z-slab(s)", "resolution": res, "triangles": T, "voxels": total_voxels,
-                       "parallelism": f"zslab{n}"},
-            "roofline": roofline, "pipeline": pipeline,
-        }
-        if n == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(verts, res, total_voxels)
+        out = report(args, n, main_run, dv, comm)
+        if companion:
+            sec = companion["seconds_per_step"]
+            out["weak_scaling_companion"] = {
+                "workload": WORKLOAD_TEXT["weak"].format(nv=companion["nv"], T=companion["T"], res=companion["res"], n=n),
+                "metric": f"Mvoxels/sec at {companion['res']}^3 grid", "value": round(companion["voxels"] / sec / 1e6, 2),
+                "mtris_per_s": round(companion["T"] / sec / 1e6, 2), "ms_per_step": round(sec * 1e3, 4),
+                "voxels": companion["voxels"], "stages_ms_rank0": {k: round(v, 4) for k, v in companion["stages_ms"].items()}}
         print(json.dumps(out), flush=True)
     dv.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def report(args, n, run, dv, comm):
+    T, res, nv, V = run["T"], run["res"], run["nv"], run["voxels"]
+    sec = run["seconds_per_step"]
+    stages_ms, st = run["stages_ms"], run["stats"]
+    prof = None
+    if n == 1 and run["name"] == "config2" and os.path.exists(PROFILE_SUMMARY):   # the committed PMC passes measured this workload
+        try:
+            prof = json.load(open(PROFILE_SUMMARY))
+        except Exception:
+            prof = None
+    kern = (prof or {}).get("kernels", {})
+
+    # ---- per-stage accounting: algorithmic bytes per launch and measured HBM traffic (PMC) ------
+    L, tiles, H = st["leaves"], st["tiles"], st["hits"]
+    B, D, slots, Hd = st["bricks"], st["dirty_bricks"], st["pool_slots"], st["direct_hits"]
+    Vr = st["voxels"]                      # this rank's voxels
+    Hp = H - Hd                            # hits that took the pool -> counting sort -> ordered replay route
+    REC = 16                               # sorted record: 16 bytes for a mesh without textured triangles (these workloads)
+    direct = Hd > 0
+    alg = {
+        "bounds": 36 * T,
+        "expand": 36 * T + 96 * L + 8 * tiles,
+        "voxelize": 96 * L + 8 * tiles + (8 + 1) * Hd + (32 + 4 + 1) * Hp,
+        # counting sort of the pooled hits (nothing to do when every hit was direct)
+        "scan": (B + 1024 * D + (16 + 4) * Vr + 32 * slots + (4 + REC) * Hp + 1024 * D) if Hp else 0,
+        # replay of the pooled hits + emission of the 64-bit grid: flag map, the dirty bricks (2 KiB each) read, the
+        # occupied 32-byte lane groups zeroed (counted as the whole brick: an upper bound), records written
+        "resolve": (16 * Vr + REC * Hp if Hp else 0) + ((B + 2 * 2048 * D + 16 * Vr) if direct else 16 * Vr),
+    }
+    stage_kernels = {
+        "bounds": ["k_init", "k_bounds", "k_setup"],
+        "expand": ["k_expand_roots", "k_expand_nodes", "k_expand_big"],
+        "voxelize": ["k_voxelize<false>", "k_voxelize<true>"],
+        "scan": ["k_scan_flags", "k_scan_bricks", "k_scatter", "k_reset_bricks"],
+        "resolve": ["k_resolve<4>", "k_resolve<6>", "k_resolve_wave<16>", "k_resolve_wave<32>", "k_resolve_wave<64>",
+                    "k_resolve_sorted", "k_resolve_big", "k_resolve_huge", "k_pick", "k_emit_max"],
+    }
+    if direct and not Hp:   # the max grid's flag scan runs in the "scan" interval, the emission in "resolve"
+        stage_kernels["scan"] = ["k_scan_flags"]
+        stage_kernels["resolve"] = ["k_emit_max"]
+        alg["scan"] = 2 * B
+        alg["resolve"] -= B
+    bound_of = {"bounds": "hbm", "expand": "hbm", "voxelize": "valu", "scan": "hbm", "resolve": "hbm"}
+    stages = []
+    for name in ("bounds", "expand", "voxelize", "scan", "resolve"):
+        ms = stages_ms[name + "_ms"]
+        traffic = sum(kern[k]["hbm_bytes"] * kern[k].get("launches_per_step", 1) for k in stage_kernels[name] if k in kern) if kern else None
+        row = {"stage": name, "kernels": [k for k in stage_kernels[name] if not kern or k in kern], "ms": round(ms, 4), "bound": bound_of[name],
+               "algorithmic_bytes": int(alg[name]), "traffic_bytes": traffic,
+               "gbs_algorithmic": round(alg[name] / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+               "gbs_traffic": round(traffic / (ms * 1e-3) / 1e9, 1) if (traffic and ms > 0) else None}
+        stages.append(row)
+
+    # ---- roofline of the dominant kernel ----------------------------------------------------------------------------------
+    dom = max(stages, key=lambda r: r["ms"])
+    dom_kernel = "k_voxelize<false>" if dom["stage"] == "voxelize" else "+".join(dom["kernels"])
+    hbm_view = {"bound": "hbm", "kernel": dom_kernel, "achieved": dom["gbs_algorithmic"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round((dom["gbs_algorithmic"] or 0) / HBM_PEAK_GBS, 5), "traffic": dom["traffic_bytes"],
+                "algorithmic_bytes": dom["algorithmic_bytes"], "kernel_ms": dom["ms"]}
+    roofline = hbm_view
+    sq = kern.get(dom_kernel, {}).get("sq") if kern else None
+    if dom["stage"] == "voxelize" and sq and sq.get("SQ_INSTS_VALU"):
+        # The clip loop is float32 VALU work: what bounds it is the rate at which the SIMDs issue wave64 VALU instructions
+        # (one per 2 cycles per SIMD), not HBM.  Instruction count: rocprofv3 --pmc SQ_INSTS_VALU of this command
+        # (profiles/current.json); time: this run's hipEvent time of the stage.
+        ginstr = sq["SQ_INSTS_VALU"] / (dom["ms"] * 1e-3) / 1e9
+        roofline = {"bound": "valu", "kernel": dom_kernel, "achieved": round(ginstr, 1), "peak": VALU_PEAK_GINSTR,
+                    "unit": "G wave64-instr/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
+                    "active_lane_fraction": round(sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_INSTS_VALU"] / 64.0, 3) if sq.get("SQ_THREAD_CYCLES_VALU") else None,
+                    "valu_instructions_per_launch": int(sq["SQ_INSTS_VALU"]), "traffic": dom["traffic_bytes"], "kernel_ms": dom["ms"],
+                    "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU: " + (prof or {}).get("source", "profiles/current.json")}
+    measured_total = sum(r["traffic_bytes"] for r in stages if r["traffic_bytes"]) if kern else None
+    # the fixed whole-pipeline numerator of SURVEY.md section 8d (a dense 32-bit grid cleared and compacted): 8*G^3 + 16*V + 76*T.
+    # The bricked grid touches only the dirty bricks, so this is a figure of merit for the design, not a bandwidth measurement.
+    b_alg = 8 * res * res * res + 16 * V + 76 * T
+    dev_ms = stages_ms["total_ms"]
+    pipeline = {"device_ms": round(dev_ms, 4), "stages_ms": {k: round(v, 4) for k, v in stages_ms.items()},
+                "algorithmic_bytes_touched": int(sum(alg.values())), "measured_traffic_bytes": measured_total,
+                "gbs_measured_traffic": round(measured_total / (dev_ms * 1e-3) / 1e9, 1) if measured_total else None,
+                "frac_of_hbm_peak_measured": round(measured_total / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if measured_total else None,
+                "survey_numerator_bytes": b_alg, "survey_numerator_gbs": round(b_alg / (dev_ms * 1e-3) / 1e9 / n, 1),
+                "survey_numerator_frac_of_hbm_peak": round(b_alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS / n, 4)}
+
+    out = {
+        "metric": f"Mvoxels/sec at {res}^3 grid", "value": round(V / sec / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "mtris_per_s": round(T / sec / 1e6, 2),
+        "config": {"workload": WORKLOAD_TEXT[run["name"]].format(nv=nv, T=T, res=res, n=n), "resolution": res, "triangles": T,
+                   "voxels": V, "parallelism": f"zslab{n}",
+                   "collectives": None if comm is None else {"backend": comm.kind, "world": comm.world,
+                                                             "plan_ms_rank0": round(stages_ms["plan_ms"], 4),
+                                                             "collective_ms_rank0": round(stages_ms["collective_ms"], 4)}},
+        "roofline": roofline, "roofline_hbm_view": hbm_view if roofline is not hbm_view else None, "stages": stages, "pipeline": pipeline,
+    }
+    if n == 1 and not args.no_capi:
+        out["capi_wall"] = capi_wall(nv, res)
+    if n == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(run["verts"], res, V)
+    return out
+
+
+def capi_wall(nv, res):
+    """SURVEY.md section 8d metric (ii): wall time of the drop-in entry point obj2voxel_voxelize() (the only timing the
+    reference itself reports, src/main.cpp:268-269,377-379) with a C triangle callback in and a counting C voxel callback
+    out: callback pulls + H2D + device pipeline + D2H + sink calls.  PCIe-inclusive, so it is never `value`."""
+    try:
+        from tools import bench_capi
+        r = bench_capi.measure(nv, res, reps=5)
+        return {"ms": round(min(r["wall_s"][1:]) * 1e3, 3), "ms_all": [round(t * 1e3, 3) for t in r["wall_s"]],
+                "mvoxels_per_s": round(r["voxels"] / min(r["wall_s"][1:]) / 1e6, 1),
+                "what": "obj2voxel_voxelize(): triangle callback in, voxel callback out; best of the calls after the first "
+                        "(the first creates the device session and allocates the dense grids)"}
+    except Exception as e:  # the helper needs gcc; the bench line must not depend on it
+        return {"error": str(e)}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(verts, res, expect_voxels):
     """The CPU oracle (a port of the reference algorithm, oracle/o2v_oracle.c) timed on this host's cores on the
-    same workload, chunk-parallel like the reference's worker pool. Baseline only, not the optimisation target."""
+    same workload, chunk-parallel like the reference's worker pool: once with one thread (the whole workload), three
+    times with one thread per core (median).  Baseline only, not the optimisation target."""
     from oracle import oracle
     cores = os.cpu_count() or 1
     oracle.build()
-    oracle.set_threads(cores)
-    t0 = time.perf_counter()
-    vox = oracle.voxelize(verts, res)
-    dt = time.perf_counter() - t0
+
+    def once(threads):
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        vox = oracle.voxelize(verts, res)
+        return len(vox), time.perf_counter() - t0
+
+    once(cores)  # warm-up: page in the library, spawn the thread pool
+    runs = [once(cores) for _ in range(3)]
+    n_vox = runs[0][0]
+    med = statistics.median(t for _, t in runs)
+    n1, t1 = once(1)
     oracle.set_threads(1)
-    return {"value": round(len(vox) / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port",
-            "sample": f"the full workload once ({len(verts)} tris at {res}^3 -> {len(vox)} voxels, {dt:.1f} s wall, "
-                      f"{cores} threads over 64^3 chunks)", "matches_gpu_voxel_count": len(vox) == expect_voxels}
+    return {"value": round(n_vox / med / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "value_1_thread": round(n1 / t1 / 1e6, 3),
+            "runs_s": [round(t, 3) for _, t in runs], "run_1_thread_s": round(t1, 2),
+            "sample": f"the full workload ({len(verts)} tris at {res}^3 -> {n_vox} voxels): median of 3 runs with {cores} threads "
+                      f"over 64^3 chunks after one warm-up run, and one run with 1 thread",
+            "matches_gpu_voxel_count": n_vox == expect_voxels}
 
 
 if __name__ == "__main__":

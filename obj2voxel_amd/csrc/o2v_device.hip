@@ -117,7 +117,8 @@ struct o2v_hip_ctx {
     unsigned long long *d_maxgrid = nullptr;  // direct MAX path: one 64-bit cell per output voxel (same bricked layout)
     uint8_t *d_dirty_max = nullptr;           // ... its dirty-brick flags and list
     uint32_t *d_dirty_list_max = nullptr;
-    uint64_t maxgrid_cells = 0, maxgrid_brick_cap = 0;
+    uint64_t maxgrid_cells = 0, maxgrid_brick_cap = 0, maxgrid_map_bytes = 0;
+    hipEvent_t ev_k1 = nullptr;               // after K1: its counters decide which stages follow k_voxelize
     bool maxgrid_dirty = false;
     uint64_t brick_cap = 0;
     bool grid_dirty = false;
@@ -239,6 +240,12 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     hipLaunchKernelGGL(k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
     O2V_STAGE("k_expand_big");
     O2V_CHECK(hipEventRecord(ctx->ev[2], s));
+    if (p.direct_max) {
+        // K1's counters go to the host on an auxiliary stream while k_voxelize runs (see below)
+        O2V_CHECK(hipEventRecord(ctx->ev_k1, s));
+        O2V_CHECK(hipStreamWaitEvent(ctx->aux[0], ctx->ev_k1, 0));
+        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->aux[0]));
+    }
 
     {
         // persistent workgroups; residency is VGPR-bound (about 4 waves per SIMD without UVs, 3 with)
@@ -255,23 +262,23 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
 
-    // With the direct MAX path the rest of the pass depends on what k_voxelize found: a mesh whose hits all went into
-    // the 64-bit grid needs neither the counting sort nor the replay (a dozen launches that would each find nothing),
-    // one whose triangles are mostly subdivided does not use the 64-bit grid at all.  One look at the counters costs
-    // less than those launches.
+    // With the direct MAX path the rest of the pass depends on the mesh: one whose triangles are all voxelized whole needs
+    // neither the counting sort nor the replay (a dozen launches that would each find nothing), one whose triangles are
+    // mostly subdivided does not use the 64-bit grid at all.  Both follow from K1's counters, which reached the host
+    // while k_voxelize was running: the follow-up stages are enqueued behind it without the stream ever draining.
     bool run_general = true, run_emit = false;
     if (p.direct_max) {
-        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
-        // listing the dirty bricks of the 64-bit grid does not depend on the decision (k_voxelize flags them for pooled
-        // hits too), so it runs while the host waits for the counters
-        const uint32_t max_flag_groups = (p.n_bricks + 15u) / 16u;
-        hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (max_flag_groups + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, p);
-        O2V_STAGE("k_scan_flags (max)");
-        O2V_CHECK(hipStreamSynchronize(s));
+        O2V_CHECK(hipStreamSynchronize(ctx->aux[0]));
         const Counters &h = *ctx->h_ctr;
         run_emit = h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
-        run_general = !run_emit || h.n_hits != h.n_direct;  // some hit took the pool -> sort -> replay route
+        // hits are pooled only for leaves of subdivided triangles: without any, every hit goes straight into the 64-bit grid
+        run_general = !run_emit || h.n_nodes[0] != 0;
+        if (run_emit) {
+            const uint32_t groups = (p.n_bricks + 15u) / 16u;
+            hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (groups + kBlock - 1) / kBlock)),
+                               dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, p);
+            O2V_STAGE("k_scan_flags (max)");
+        }
     }
 
     if (run_general) {
@@ -469,7 +476,8 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
             delete ctx;
             return O2V_HIP_ERR_HIP;
         }
-    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_k1, hipEventDisableTiming) == hipSuccess;
     for (int j = 0; j < 3 && ok; ++j)
         ok = hipStreamCreateWithFlags(&ctx->aux[j], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming) == hipSuccess;
@@ -515,6 +523,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
     if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_k1) (void) hipEventDestroy(ctx->ev_k1);
     for (int j = 0; j < 3; ++j) {
         if (ctx->ev_join[j]) (void) hipEventDestroy(ctx->ev_join[j]);
         if (ctx->aux[j]) (void) hipStreamDestroy(ctx->aux[j]);
@@ -680,18 +689,34 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
                 p.pick_max = 0;
             }
             else {
-                ctx->maxgrid_cells = cells;
-                ctx->maxgrid_brick_cap = (n_bricks + 15u) & ~15ull;
-                O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), ctx->maxgrid_brick_cap));
-                O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), ctx->maxgrid_brick_cap * sizeof(uint32_t)));
-                ctx->maxgrid_dirty = true;
+                // all three buffers exist before the capacity is published: a context (cached process-wide by the C API)
+                // whose later allocation failed must not look ready
+                const uint64_t brick_cap = (n_bricks + 15u) & ~15ull, map_bytes = brick_cap;
+                const bool ok = hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), map_bytes) == hipSuccess &&
+                                hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), brick_cap * sizeof(uint32_t)) == hipSuccess;
+                if (!ok) {
+                    (void) hipGetLastError();
+                    for (void *q : {(void *) ctx->d_maxgrid, (void *) ctx->d_dirty_max, (void *) ctx->d_dirty_list_max})
+                        if (q) (void) hipFree(q);
+                    ctx->d_maxgrid = nullptr;
+                    ctx->d_dirty_max = nullptr;
+                    ctx->d_dirty_list_max = nullptr;
+                    p.direct_max = 0;
+                    p.pick_max = 0;
+                }
+                else {
+                    ctx->maxgrid_cells = cells;
+                    ctx->maxgrid_brick_cap = brick_cap;
+                    ctx->maxgrid_map_bytes = map_bytes;
+                    ctx->maxgrid_dirty = true;
+                }
             }
         }
     }
     if (p.direct_max) {
         if (ctx->maxgrid_dirty) {
             O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
-            O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_brick_cap, ctx->stream));
+            O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_map_bytes, ctx->stream));
             ctx->maxgrid_dirty = false;
         }
         p.maxgrid = ctx->d_maxgrid;
@@ -749,7 +774,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
             if (p.direct_max) {
                 O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
-                O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_brick_cap, ctx->stream));
+                O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_map_bytes, ctx->stream));
             }
         }
         if ((rc = grow(ctx, ctx->d_leaves, ctx->cap_leaves, want_leaves))) return rc;

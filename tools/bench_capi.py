@@ -34,13 +34,10 @@ bool count_write(void *d, uint32_t *v, size_t n) { count *c = (count *) d; (void
 '''
 
 
-def main():
+def measure(nv=467, res=1024, reps=3, debug=False):
     import numpy as np
     from obj2voxel_amd import capi, meshes
     import obj2voxel_amd
-    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 467
-    res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     tmp = tempfile.mkdtemp()
     src = os.path.join(tmp, "helper.c")
     open(src, "w").write(HELPER_SRC)
@@ -58,11 +55,12 @@ def main():
         _fields_ = [("voxels", C.c_size_t), ("calls", C.c_size_t)]
 
     verts = np.ascontiguousarray(meshes.uv_sphere(nv))
-    debug = os.environ.get("O2V_CAPI_DEBUG") == "1"   # prints the library's per-phase wall times
-    a.obj2voxel_set_log_level(4 if debug else capi.LOG_SILENT)
+    level = a.obj2voxel_get_log_level()
+    a.obj2voxel_set_log_level(4 if debug else capi.LOG_SILENT)   # 4: prints the library's per-phase wall times
     a.obj2voxel_set_input_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     a.obj2voxel_set_output_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     times = []
+    cnt = Count(0, 0)
     for _ in range(reps):
         feed = Feed(verts.ctypes.data, len(verts), 0)
         cnt = Count(0, 0)
@@ -76,11 +74,20 @@ def main():
         a.obj2voxel_free(inst)
         assert err == 0, err
         times.append(dt)
-    best = min(times)
-    print(json.dumps({"entry_point": "obj2voxel_voxelize (callback in, callback out)", "triangles": len(verts),
-                      "resolution": res, "voxels": cnt.voxels, "sink_calls": cnt.calls,
-                      "wall_s": [round(t, 4) for t in times], "best_mvoxels_per_s": round(cnt.voxels / best / 1e6, 2),
-                      "best_mtris_per_s": round(len(verts) / best / 1e6, 2)}))
+    a.obj2voxel_set_log_level(level)
+    return {"triangles": len(verts), "resolution": res, "voxels": cnt.voxels, "sink_calls": cnt.calls, "wall_s": times}
+
+
+def main():
+    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 467
+    res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    r = measure(nv, res, reps, debug=os.environ.get("O2V_CAPI_DEBUG") == "1")
+    best = min(r["wall_s"])
+    print(json.dumps({"entry_point": "obj2voxel_voxelize (callback in, callback out)", "triangles": r["triangles"],
+                      "resolution": res, "voxels": r["voxels"], "sink_calls": r["sink_calls"],
+                      "wall_s": [round(t, 4) for t in r["wall_s"]], "best_mvoxels_per_s": round(r["voxels"] / best / 1e6, 2),
+                      "best_mtris_per_s": round(r["triangles"] / best / 1e6, 2)}))
 
 
 if __name__ == "__main__":

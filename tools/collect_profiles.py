@@ -1,85 +1,100 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs that tools/profile_all.sh leaves under gpurun_out/ (prof_final, pmcf_FETCH_SIZE, pmcf_WRITE_SIZE, pmcf_sq, bench_final.json)
-into the committed summaries under profiles/<round>/ and profiles/traffic.json (read by bench.py)."""
+"""Turns the rocprofv3 outputs that tools/profile_all.sh leaves under gpurun_out/prof/ into the committed summaries under
+profiles/<round>/ and profiles/current.json (read by bench.py: measured HBM traffic and VALU instruction counts per
+kernel of the bench command).   usage: collect_profiles.py r02"""
 import collections
 import csv
+import glob
 import json
 import os
 import re
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = "gpurun_out/prof"
 out_dir = os.path.join("profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
-import glob
 
 
 def find(pattern):
     hits = sorted(glob.glob(pattern, recursive=True))
-    if not hits:
-        raise SystemExit("missing " + pattern)
-    return hits[0]
-
-
-shutil.copy(find("gpurun_out/prof_final/**/f_kernel_stats.csv"), os.path.join(out_dir, "kernel_stats.csv"))
-if os.path.exists("gpurun_out/predict_scaling_8.jsonl"):
-    shutil.copy("gpurun_out/predict_scaling_8.jsonl", os.path.join(out_dir, "predict_scaling_8.jsonl"))
-shutil.copy("gpurun_out/bench_final.json", os.path.join(out_dir, "bench_line.json"))
+    return hits[0] if hits else None
 
 
 def kname(s):
-    m = re.search(r"(k_[a-z_]+(<[^>]*>)?)", s)
-    return m.group(1) if m else None
+    m = re.search(r"(k_[a-z_0-9]+)(<[^>]*>)?", s)
+    if not m:
+        return None
+    targs = re.sub(r"[\s]|(?<=\d)u", "", m.group(2) or "").replace("(bool)1", "true").replace("(bool)0", "false")
+    return m.group(1) + targs
 
 
-res = {}
-for cname in ("FETCH_SIZE", "WRITE_SIZE"):
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(find(f"gpurun_out/pmcf_{cname}/**/p_counter_collection.csv"))):
+def counters(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not path:
+        return acc
+    for r in csv.DictReader(open(path)):
         k = kname(r["Kernel_Name"])
-        if k and r["Counter_Name"] == cname:
-            acc[k].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        res.setdefault(k, {})[cname] = sum(v) / len(v)
-out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (separate runs: --pmc FETCH_SIZE, --pmc WRITE_SIZE, with "
-                   "--kernel-trace only), bench workload (uv-sphere nv=467 @1024^3). Counters are in KiB. Correction per "
-                   "MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so "
-                   "fetch is doubled; calibrated here on k_bounds (31.3 MB read) and k_reset_bricks (1 KiB per dirty brick "
-                   "written, WRITE_SIZE exact).", "kernels": {}}
-for k, v in res.items():
-    f, w = v.get("FETCH_SIZE", 0) * 1024, v.get("WRITE_SIZE", 0) * 1024
-    out["kernels"][k] = {"fetch_size_raw_bytes": round(f), "write_size_bytes": round(w), "hbm_bytes_corrected": round(2 * f + w)}
-K = out["kernels"]
+        if k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
 
 
-def hbm(k):
-    return K.get(k, {}).get("hbm_bytes_corrected", 0)  # a kernel the workload never launches contributes nothing
-
-
-out["k_voxelize"] = hbm("k_voxelize<false>")
-out["k_scan_flags+k_scan_bricks+k_scatter+k_reset_bricks"] = sum(hbm(k) for k in ("k_scan_bricks", "k_scatter", "k_reset_bricks"))
-out["k_resolve*+k_emit_max"] = sum(hbm(k) for k in K if k.startswith("k_resolve") or k in ("k_emit_max", "k_scan_flags"))
-out["k_expand_roots+k_expand_nodes"] = hbm("k_expand_roots")
-json.dump(out, open("profiles/traffic.json", "w"), indent=1)
-json.dump(out, open(os.path.join(out_dir, "pmc_hbm_traffic.json"), "w"), indent=1)
-
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(find("gpurun_out/pmcf_sq/**/p_counter_collection.csv"))):
-    k = kname(r["Kernel_Name"])
-    if k:
-        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-sq = {"_comment": "rocprofv3 --pmc pass (8 SQ counters, --kernel-trace only), bench workload, averages per launch. "
-                  "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)."}
-for k in ("k_voxelize<false>", "k_emit_max", "k_expand_roots", "k_scatter"):
-    if k not in acc:
+summary = {}
+for w in ("config2", "config2_blend", "config1", "config3"):
+    stats = find(f"{src}/{w}_stats/**/s_kernel_stats.csv")
+    if not stats:
         continue
-    d = {c: round(sum(v) / len(v)) for c, v in acc[k].items()}
-    if d.get("SQ_INSTS_VALU"):
-        d["derived"] = {"valu_active_fraction_per_wave": round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 3),
-                        "active_lanes_per_valu_instruction": round(d["SQ_THREAD_CYCLES_VALU"] / d["SQ_INSTS_VALU"], 1)}
-    sq[k] = d
-json.dump(sq, open(os.path.join(out_dir, "sq_counters.json"), "w"), indent=1)
-for r in csv.DictReader(open(os.path.join(out_dir, "kernel_stats.csv"))):
-    print("%-34s calls=%-4s avg_us=%9.1f  %s%%" % (kname(r["Name"]) or r["Name"][:30], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
-print(json.dumps(sq["k_voxelize<false>"]))
+    shutil.copy(stats, os.path.join(out_dir, f"{w}_kernel_stats.csv"))
+    rows = [(kname(r["Name"]), r) for r in csv.DictReader(open(stats))]
+    # k_voxelize runs exactly once per pass of the pipeline (a step is one pass unless a buffer had to grow in the warm-up)
+    passes = sum(int(r["Calls"]) for k, r in rows if k and k.startswith("k_voxelize")) or 1
+    kernels = {}
+    for k, r in rows:
+        if not k:
+            continue
+        kernels[k] = {"calls": int(r["Calls"]), "launches_per_step": round(int(r["Calls"]) / passes, 2),
+                      "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "share_pct": float(r["Percentage"])}
+    fetch, write = counters(find(f"{src}/{w}_FETCH_SIZE/**/p_counter_collection.csv")), counters(find(f"{src}/{w}_WRITE_SIZE/**/p_counter_collection.csv"))
+    for k in kernels:
+        f = fetch.get(k, {}).get("FETCH_SIZE")
+        wr = write.get(k, {}).get("WRITE_SIZE")
+        if f and wr:
+            f, wr = sum(f) / len(f) * 1024, sum(wr) / len(wr) * 1024   # the counters are in KiB
+            kernels[k].update({"fetch_size_raw_bytes": round(f), "write_size_bytes": round(wr), "hbm_bytes": round(2 * f + wr)})
+    sq = {}
+    for part in ("sq1", "sq2"):
+        for k, d in counters(find(f"{src}/{w}_{part}/**/p_counter_collection.csv")).items():
+            sq.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in d.items()})
+    for k, d in sq.items():
+        if k in kernels and d.get("SQ_INSTS_VALU", 0) > 1e6:
+            d["derived"] = {"active_lanes_per_valu_instruction": round(d["SQ_THREAD_CYCLES_VALU"] / d["SQ_INSTS_VALU"], 1),
+                            "valu_issue_fraction_of_peak_at_2_cycles": None}
+            kernels[k]["sq"] = d
+    line = None
+    lp = os.path.join(src, f"{w}_line.json")
+    if os.path.exists(lp) and os.path.getsize(lp):
+        line = json.loads(open(lp).read())
+    step_traffic = sum(v["hbm_bytes"] * v["launches_per_step"] for v in kernels.values() if "hbm_bytes" in v)
+    doc = {"_comment": "rocprofv3 on MI355X, one workload of tools/profile_all.sh. kernel times: --kernel-trace --stats; HBM bytes per "
+                       "launch: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (--kernel-trace only), counters in KiB, "
+                       "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half "
+                       "the bytes of wide coalesced reads; calibrated in round 1 on k_bounds = 36 B x triangles read and "
+                       "k_reset_bricks = 1 KiB per dirty brick written); sq: two --pmc passes of 8 SQ counters, averages per launch "
+                       "(SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles).",
+           "workload": w, "command": "python bench.py --no-cpu-baseline --no-capi" if w == "config2" else f"python tools/run_workload.py {w}",
+           "result_line": line, "hbm_bytes_per_step_all_kernels": round(step_traffic), "kernels": kernels}
+    json.dump(doc, open(os.path.join(out_dir, f"{w}_profile.json"), "w"), indent=1)
+    summary[w] = doc
+    print(f"== {w}: {round(step_traffic / 1e6, 1)} MB of HBM traffic per step")
+    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_per_step"]):
+        if v["avg_us"] * v["launches_per_step"] >= 5:
+            print("   %-30s x%-5s avg %9.1f us  %6.1f MB  %s" % (k, v["launches_per_step"], v["avg_us"], v.get("hbm_bytes", 0) / 1e6,
+                                                             ("VALU %.1f M, lanes %.1f" % (v["sq"]["SQ_INSTS_VALU"] / 1e6, v["sq"]["derived"]["active_lanes_per_valu_instruction"])) if "sq" in v else ""))
+if "config2" in summary:
+    cur = {"source": f"profiles/{rnd}/config2_profile.json (rocprofv3 passes of `python bench.py --no-cpu-baseline --no-capi`)",
+           "kernels": summary["config2"]["kernels"]}
+    json.dump(cur, open("profiles/current.json", "w"), indent=1)
+if os.path.exists(os.path.join(src, "bench_line.json")):
+    shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(out_dir, "bench_line.json"))

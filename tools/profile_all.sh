@@ -1,20 +1,28 @@
 #!/bin/bash
 # Runs on the GPU box: every rocprofv3 pass the committed summaries under profiles/<round>/ are made from
-# (tools/collect_profiles.py turns gpurun_out/ into profiles/).  Counter passes use --kernel-trace only.
+# (tools/collect_profiles.py turns gpurun_out/prof/ into profiles/).  Counter passes use --kernel-trace only, one counter
+# family per pass.  Workloads: the bench command itself (BASELINE configs[2], direct MAX route) and the general route
+# (pool -> counting sort -> ordered replay): the bench mesh with BLEND, configs[1], configs[3] (tools/run_workload.py).
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-OUT=gpurun_out
-mkdir -p $OUT
-B="python bench.py --no-cpu-baseline"
-timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_final -o f -- $B --steps 20 --warmup 3 > $OUT/prof_final.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcf_$c -o p -- $B --steps 3 --warmup 1 > $OUT/pmcf_$c.log 2>&1
+OUT=gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+SQ1="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"
+SQ2="SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"
+for W in config2 config2_blend config1 config3; do
+  if [ $W = config2 ]; then CMD="python bench.py --no-cpu-baseline --no-capi"; S1="--steps 20 --warmup 3"; S2="--steps 3 --warmup 1"
+  else CMD="python tools/run_workload.py $W"; S1="--steps 10 --warmup 2"; S2="--steps 3 --warmup 1"; fi
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_stats -o s -- $CMD $S1 > $OUT/${W}_stats.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${W}_$c -o p -- $CMD $S2 > $OUT/${W}_$c.log 2>&1
+  done
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $OUT/${W}_sq1 -o p -- $CMD $S2 > $OUT/${W}_sq1.log 2>&1
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OUT/${W}_sq2 -o p -- $CMD $S2 > $OUT/${W}_sq2.log 2>&1
+  grep "^{" $OUT/${W}_stats.log | tail -1 > $OUT/${W}_line.json
 done
-timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmcf_sq -o p -- $B --steps 3 --warmup 1 > $OUT/pmcf_sq.log 2>&1
-# the bench line itself (with the CPU baseline), unprofiled
-timeout -k 5 600 python bench.py > $OUT/bench_final.json 2> $OUT/bench_final.err
-# predicted multi-GPU balance (one GPU runs the 8 slabs of the 8-GPU job in turn)
-timeout -k 5 300 python tools/predict_scaling.py 8 > $OUT/predict_scaling_8.jsonl 2>&1
-find $OUT -name "*_kernel_stats.csv" -o -name "*_counter_collection.csv" | head
-tail -c 600 $OUT/bench_final.json
+# the bench line itself (with the CPU baseline and the C API wall time), unprofiled
+timeout -k 5 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+# keep the merge small: only the summaries travel back
+find $OUT -name "*_agent_info.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete
+du -sh $OUT; tail -c 400 $OUT/bench_line.json

@@ -21,11 +21,11 @@ enum : uint32_t {
     kClsFlagLo = 32u,    // mode 1: lo flag of vertex r+1;  mode 2: the isolated vertex is lo
 };
 
-__device__ __forceinline__ uint32_t classify_piece(float c0, float c1, float c2, float plane)
+// The case analysis on the six flags (lo and planar per vertex), voxelization.cpp:190-232; index = l0 | l1 << 1 | l2 << 2 |
+// p0 << 3 | p1 << 4 | p2 << 5.  The kernel keeps the 64 results in an LDS table: one byte load replaces the branches.
+__host__ __device__ constexpr uint32_t classify_flags(uint32_t idx)
 {
-    // SplittingValues, voxelization.cpp:121-131
-    const bool p0 = abs_f(c0 - plane) < kEpsilon, p1 = abs_f(c1 - plane) < kEpsilon, p2 = abs_f(c2 - plane) < kEpsilon;
-    const bool l0 = c0 < plane, l1 = c1 < plane, l2 = c2 < plane;
+    const bool l0 = idx & 1u, l1 = idx & 2u, l2 = idx & 4u, p0 = idx & 8u, p1 = idx & 16u, p2 = idx & 32u;
     const uint32_t lo_sum = (uint32_t) l0 + (uint32_t) l1 + (uint32_t) l2;
     const uint32_t pl_sum = (uint32_t) p0 + (uint32_t) p1 + (uint32_t) p2;
     if (lo_sum == 0) return 0u;
@@ -42,6 +42,14 @@ __device__ __forceinline__ uint32_t classify_piece(float c0, float c1, float c2,
     const bool iso_lo = lo_sum == 1;
     const uint32_t r = iso_lo ? (l0 ? 0u : (l1 ? 1u : 2u)) : (!l0 ? 0u : (!l1 ? 1u : 2u));
     return 2u | (r << kClsRotShift) | (iso_lo ? kClsFlagLo : 0u);
+}
+
+// SplittingValues, voxelization.cpp:121-131: the six flags of a piece against an axis plane
+__device__ __forceinline__ uint32_t classify_index(float c0, float c1, float c2, float plane)
+{
+    const bool p0 = abs_f(c0 - plane) < kEpsilon, p1 = abs_f(c1 - plane) < kEpsilon, p2 = abs_f(c2 - plane) < kEpsilon;
+    const bool l0 = c0 < plane, l1 = c1 < plane, l2 = c2 < plane;
+    return (uint32_t) l0 | ((uint32_t) l1 << 1) | ((uint32_t) l2 << 2) | ((uint32_t) p0 << 3) | ((uint32_t) p1 << 4) | ((uint32_t) p2 << 5);
 }
 
 // The geometric part of splitTriangle<DISCARD_LO|DISCARD_HI> for a piece whose classification says it is cut
@@ -121,11 +129,15 @@ __device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area
     w = ws;
 }
 
-// Pending sibling pieces of the depth-first clip walk, one slot per level 1..5, held in registers: every access
-// uses a compile-time slot index (selected by a switch), so the array never leaves the VGPR file.
+// Pending sibling pieces of the depth-first clip walk: a stack (last in, first out - the sibling pushed last belongs to
+// the deepest level and is next in depth-first order).  Under DISCARD a cut keeps <= 2 pieces, so at most one sibling per
+// level 1..5 is pending.  The first kStackRegs entries live in registers and are accessed with value selects on the stack
+// pointer (every access uses a compile-time slot, so they never leave the VGPR file); deeper entries - 1 % of the pushes
+// on the bench mesh - go to a small per-lane overflow array (scratch memory).
+constexpr uint32_t kStackRegs = 3, kStackOverflow = 2;
 template <bool UV>
 struct PieceStack {
-    Piece<UV> s0, s1, s2, s3, s4;
+    Piece<UV> s0, s1, s2;
 };
 
 // Value-level selects (v_cndmask), not control flow: a branchy form gets folded by the compiler into a select of
@@ -150,18 +162,11 @@ __device__ __forceinline__ void stack_store(PieceStack<UV> &st, uint32_t slot, c
     st.s0 = sel_piece<UV>(slot == 0, pc, st.s0);
     st.s1 = sel_piece<UV>(slot == 1, pc, st.s1);
     st.s2 = sel_piece<UV>(slot == 2, pc, st.s2);
-    st.s3 = sel_piece<UV>(slot == 3, pc, st.s3);
-    st.s4 = sel_piece<UV>(slot == 4, pc, st.s4);
 }
 template <bool UV>
-__device__ __forceinline__ void stack_load(const PieceStack<UV> &st, uint32_t slot, Piece<UV> &pc)
+__device__ __forceinline__ Piece<UV> stack_load(const PieceStack<UV> &st, uint32_t slot)
 {
-    Piece<UV> r = st.s4;
-    r = sel_piece<UV>(slot == 3, st.s3, r);
-    r = sel_piece<UV>(slot == 2, st.s2, r);
-    r = sel_piece<UV>(slot == 1, st.s1, r);
-    r = sel_piece<UV>(slot == 0, st.s0, r);
-    pc = r;
+    return sel_piece<UV>(slot == 0, st.s0, sel_piece<UV>(slot == 1, st.s1, st.s2));
 }
 
 // Conservative triangle / voxel overlap test (separating axes: the triangle's plane and the nine edge x axis
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
     __shared__ uint16_t s_surv[kMaxSurvivors];
     __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits, s_direct;
+    __shared__ uint8_t s_cls[64];  // classify_flags
 
     if (expand_overflowed(c, p)) return;
     const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
         s_hits = 0;
         s_direct = 0;
     }
+    if (threadIdx.x < 64u) s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
 
     for (;;) {
         __syncthreads();
@@ -434,9 +441,10 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             // ---- phase 2: persistent lanes ------------------------------------------------------------------
             Piece<UV> cur{}, sec{};
             PieceStack<UV> stack{};
-            uint32_t pending = 0, my_k = 0;
+            Piece<UV> overflow[kStackOverflow];
+            uint32_t sp = 0, my_k = 0;  // sp: pending siblings of this lane's job
             uint32_t cf = 0;     // planes the current piece does not pass whole (bit = level), see piece_masks
-            uint32_t pmask = 0;  // the same for the pending siblings: 6 bits per stack slot
+            uint32_t pmask = 0;  // the same for the pending siblings: 6 bits per stack entry
             bool active = false, has_job = false, small = false;
             float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
             float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
@@ -517,11 +525,11 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 O2V_EV(0, lane == 0);
                 // pop a pending sibling (with the plane mask it was pushed with), or fetch the next survivor
                 if (!active) {
-                    if (pending) {
-                        const uint32_t lv = 31u - (uint32_t) __clz((int) pending);  // deepest pending level first: depth-first order
-                        pending ^= 1u << lv;
-                        stack_load<UV>(stack, lv - 1u, cur);
-                        const uint32_t sh = 6u * (lv - 1u);
+                    if (sp) {
+                        sp -= 1u;
+                        cur = stack_load<UV>(stack, sp);
+                        if (sp >= kStackRegs) cur = overflow[sp - kStackRegs];
+                        const uint32_t sh = 6u * sp;
                         cf = (pmask >> sh) & 63u;
                         pmask &= ~(63u << sh);
                         active = true;
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                         const bool keep_lo = level >= 3u;
                         const uint32_t axis = keep_lo ? level - 3u : level;
                         const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
-                        const uint32_t cls = classify_piece(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane);
+                        const uint32_t cls = s_cls[classify_index(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane)];
                         if ((cls & kClsModeMask) == 0u) {
                             // whole triangle to one side (one of the planar special cases, or a job whose masks are not
                             // computed: see piece_masks)
@@ -641,9 +649,11 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                             if (c_done) accumulate_piece<UV>(cur, area, w, u, v);
                             if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v);
                             O2V_EV(12, s_push);
-                            stack_store<UV>(stack, s_push ? level : 7u, sec);  // slot of level + 1 (7: no slot, nothing stored)
-                            pending |= s_push ? 1u << (level + 1u) : 0u;
-                            pmask |= s_push ? s_fail << (6u * level) : 0u;
+                            O2V_EV(13, s_push && sp >= kStackRegs);
+                            stack_store<UV>(stack, s_push ? sp : 7u, sec);  // 7: no slot, nothing stored
+                            if (s_push && sp >= kStackRegs) overflow[sp - kStackRegs] = sec;
+                            pmask |= s_push ? s_fail << (6u * sp) : 0u;
+                            sp += s_push ? 1u : 0u;
                             cur = sel_piece<UV>(s_takes_over, sec, cur);
                             cf = s_takes_over ? s_fail : c_fail;
                             active = s_takes_over || !c_over;
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 // combine happens in the resolve kernels.  A finished hit is parked in the lane's result registers and
                 // the append section runs only when half the wavefront holds one (or a lane needs its slot again, or
                 // the wavefront leaves), not in every iteration.
-                const bool finished = has_job && !active && pending == 0;
+                const bool finished = has_job && !active && sp == 0;
                 const bool fin_hit = finished && w != 0.f;
                 if (finished) has_job = false;
                 if (__ballot(fin_hit && d_valid)) flush_results();
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                     d_zk = pz | (my_k << 16);
                     d_valid = true;
                 }
-                const bool leaving = !__ballot(active || pending != 0 || !queue_empty);
+                const bool leaving = !__ballot(active || sp != 0 || !queue_empty);
                 const unsigned long long dm = __ballot(d_valid);
                 if (dm && ((uint32_t) __popcll(dm) >= 32u || leaving)) flush_results();
                 if (leaving) break;

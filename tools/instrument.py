@@ -12,7 +12,8 @@ from obj2voxel_amd import hip, meshes
 
 NAMES = ["wave_iterations", "lane_events", "acc_passes_all(event)", "whole_keep(event)", "-", "whole_discard(event)",
          "-", "cut(event)", "cut: first piece final", "cut: first piece dropped", "cut: second piece final",
-         "cut: second piece dropped", "cut: second piece pushed", "-", "-", "-"]
+         "cut: second piece dropped", "cut: second piece pushed", "push onto >= 2 pending", "push onto >= 3 pending",
+         "wave iterations with a push onto >= 2 pending"]
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 467
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 textured = len(sys.argv) > 3
@@ -29,5 +30,5 @@ n = dv.voxelize(res, read=False)
 c = dv.debug_counters()
 st = dv.stats()
 out = {"voxels": int(n), "hits": st["hits"], "candidates": st["candidates"], "timings": dv.timings()}
-out["events"] = {NAMES[i]: int(c[i]) for i in range(15)}
+out["events"] = {NAMES[i]: int(c[i]) for i in range(16)}
 print(json.dumps(out, indent=1))

@@ -229,14 +229,18 @@ __device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, float cx, f
 constexpr float kOutMargin = 0.0625f;
 constexpr float kSmallCoord = 8192.0f;
 
-template <bool UV>
-__device__ __forceinline__ bool piece_is_small(const Piece<UV> &q)
+// (once per staged leaf: q = its nine vertex coordinates)
+__device__ __forceinline__ bool leaf_is_small(const uint32_t *q)
 {
-    const float m = fmaxf(fmaxf(fmaxf(abs_f(q.a.x), abs_f(q.a.y)), fmaxf(abs_f(q.a.z), abs_f(q.b.x))),
-                          fmaxf(fmaxf(abs_f(q.b.y), abs_f(q.b.z)), fmaxf(fmaxf(abs_f(q.c.x), abs_f(q.c.y)), abs_f(q.c.z))));
-    const float sum = (((q.a.x + q.a.y) + (q.a.z + q.b.x)) + ((q.b.y + q.b.z) + (q.c.x + q.c.y))) + q.c.z;
-    const bool finite = sum == sum;  // false if any coordinate is NaN (fmaxf above ignores NaN operands) or inf - inf occurred
-    return finite && m < kSmallCoord;
+    float m = 0.f, sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float f = __uint_as_float(q[i]);
+        m = fmaxf(m, abs_f(f));
+        sum += f;
+    }
+    // sum == sum is false if any coordinate is NaN (fmaxf ignores NaN operands) or inf - inf occurred
+    return sum == sum && m < kSmallCoord;
 }
 
 template <bool UV>
@@ -263,6 +267,7 @@ __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float 
     out = small ? (o & planes) : 0u;
 }
 
+constexpr uint32_t kFlushAt = 48;             // parked hits per wavefront that trigger the append section
 constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
 constexpr uint32_t kMaxSurvivors = 8192;      // survivor queue entries (= candidate voxels) per sub-batch
 
@@ -347,7 +352,8 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
             const uint32_t rem = dx * dy * dz - s_tstart[threadIdx.x];
             my_count = rem < kTileSize ? rem : kTileSize;
-            s_tcount[threadIdx.x] = my_count;
+            // bit 31: every coordinate of the leaf is finite and below kSmallCoord (see piece_masks)
+            s_tcount[threadIdx.x] = my_count | (leaf_is_small(lf) ? 0x80000000u : 0u);
             s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
         }
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                     chunk_base = __shfl(base, (int) leader, 64);
                     chunk_used = 0;
                 }
-                const uint32_t mine = chunk_base + chunk_used + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+                const uint32_t mine = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
                 chunk_used += cnt;
                 if (d_valid) {
                     const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
@@ -521,15 +527,31 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
 #else
 #define O2V_EV(i, cond) do { } while (0)
 #endif
+            bool leaving = false;
             for (;;) {
                 O2V_EV(0, lane == 0);
+                {
+                    // lanes whose job ended in a hit park it (w, u, v, position) in their result registers; if a lane's
+                    // registers are still taken, everything parked is appended first
+                    const bool fin_hit = has_job && !active && sp == 0;
+                    const unsigned long long dv = __ballot(d_valid);
+                    if (__ballot(fin_hit && d_valid) || (uint32_t) __popcll(dv) >= kFlushAt || (leaving && dv)) flush_results();
+                    if (leaving) break;
+                    if (fin_hit) {
+                        d_w = w; d_u = u; d_v = v;
+                        d_xy = px | (py << 16);
+                        d_zk = pz | (my_k << 16);
+                        d_valid = true;
+                        has_job = false;
+                    }
+                }
                 // pop a pending sibling (with the plane mask it was pushed with), or fetch the next survivor
                 if (!active) {
                     if (sp) {
                         sp -= 1u;
                         cur = stack_load<UV>(stack, sp);
                         if (sp >= kStackRegs) cur = overflow[sp - kStackRegs];
-                        const uint32_t sh = 6u * sp;
+                        const uint32_t sh = (sp << 2) + (sp << 1);  // 6 bits per entry
                         cf = (pmask >> sh) & 63u;
                         pmask &= ~(63u << sh);
                         active = true;
@@ -539,18 +561,18 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                         if (q < n_surv) {
                             const uint32_t e = s_surv[q];
                             my_k = t_begin + (e >> 8);
-                            const uint32_t *lf = &s_leaf[my_k * kLeafStride];
+                            const uint32_t *lf = &s_leaf[__umul24(my_k, kLeafStride)];
                             const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
                             const uint32_t j = s_tstart[my_k] + (e & 255u);
                             uint32_t row, lx, ly, lz;
                             if (j < (1u << 24)) {
                                 row = (uint32_t) ((float) j * s_inv_dx[my_k]);
-                                int32_t rx = (int32_t) (j - row * dx);
+                                int32_t rx = (int32_t) (j - __umul24(row, dx));  // all below 2^24 here
                                 if (rx < 0) { row -= 1; rx += (int32_t) dx; }
                                 else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
                                 lx = (uint32_t) rx;
                                 lz = (uint32_t) ((float) row * s_inv_dy[my_k]);
-                                int32_t ry = (int32_t) (row - lz * dy);
+                                int32_t ry = (int32_t) (row - __umul24(lz, dy));
                                 if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
                                 else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
                                 ly = (uint32_t) ry;
@@ -579,7 +601,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                             w = 0.f;
                             u = 0.f;
                             v = 0.f;
-                            small = piece_is_small<UV>(cur);
+                            small = (s_tcount[my_k] >> 31) != 0u;
                             uint32_t out_unused;
                             piece_masks<UV>(cur, fx, fy, fz, small, 63u, cf, out_unused);
                             active = true;
@@ -652,7 +674,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                             O2V_EV(13, s_push && sp >= kStackRegs);
                             stack_store<UV>(stack, s_push ? sp : 7u, sec);  // 7: no slot, nothing stored
                             if (s_push && sp >= kStackRegs) overflow[sp - kStackRegs] = sec;
-                            pmask |= s_push ? s_fail << (6u * sp) : 0u;
+                            pmask |= s_push ? s_fail << ((sp << 2) + (sp << 1)) : 0u;
                             sp += s_push ? 1u : 0u;
                             cur = sel_piece<UV>(s_takes_over, sec, cur);
                             cf = s_takes_over ? s_fail : c_fail;
@@ -662,23 +684,12 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 }
                 // A job is finished when nothing of it is in flight.  `not eqExactly(uv.weight, 0.f)` -> insertWeighted
                 // (voxelization.cpp:466-468): the hit is appended to the pool and counted in its cell; the ordered
-                // combine happens in the resolve kernels.  A finished hit is parked in the lane's result registers and
-                // the append section runs only when half the wavefront holds one (or a lane needs its slot again, or
-                // the wavefront leaves), not in every iteration.
+                // combine happens in the resolve kernels.  A finished hit is parked in the lane's result registers; the
+                // append section (flush_results, at the top of the loop) runs when kFlushAt lanes hold one, when a lane
+                // needs its slot again or when the wavefront leaves - not in every iteration.
                 const bool finished = has_job && !active && sp == 0;
-                const bool fin_hit = finished && w != 0.f;
-                if (finished) has_job = false;
-                if (__ballot(fin_hit && d_valid)) flush_results();
-                if (fin_hit) {
-                    d_w = w; d_u = u; d_v = v;
-                    d_xy = px | (py << 16);
-                    d_zk = pz | (my_k << 16);
-                    d_valid = true;
-                }
-                const bool leaving = !__ballot(active || sp != 0 || !queue_empty);
-                const unsigned long long dm = __ballot(d_valid);
-                if (dm && ((uint32_t) __popcll(dm) >= 32u || leaving)) flush_results();
-                if (leaving) break;
+                if (finished && w == 0.f) has_job = false;  // the voxel was not hit
+                leaving = !__ballot(active || sp != 0 || !queue_empty || has_job);
             }
             t_begin = t_end;
         }

@@ -6,7 +6,7 @@
 // ---- device-side records ----------------------------------------------------------------------------------
 
 constexpr uint32_t kTileSize = 256;       // candidate voxels per work tile
-constexpr uint32_t kTilesPerBatch = 128;  // tiles a workgroup stages at once (at most)
+constexpr uint32_t kTilesPerBatch = 256;  // tiles a workgroup stages at once (at most: one thread per tile)
 constexpr uint32_t kMinTilesPerBatch = 4;  // ... and at least (one tile per wavefront in phase 1)
 constexpr uint32_t kBlock = 256;          // threads per workgroup (4 wavefronts)
 constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key holds 15 levels)

@@ -269,7 +269,9 @@ __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float 
 
 constexpr uint32_t kFlushAt = 48;             // parked hits per wavefront that trigger the append section
 constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
-constexpr uint32_t kMaxSurvivors = 8192;      // survivor queue entries (= candidate voxels) per sub-batch
+constexpr uint32_t kQueueCap = 16384;         // job queue records (= candidate voxels at most) per sub-batch and workgroup
+constexpr uint32_t kBatchesPerBlock = 4;      // aimed-at number of batches per workgroup (see tiles_per_batch)
+constexpr uint32_t kHeavyPlanes = 5;          // a job whose leaf straddles at least this many voxel planes is queued first
 
 // K2.  Persistent workgroups pull batches of tiles.  Per batch:
 //   phase 1  every candidate voxel of the tiles: decode, plane-distance cull (voxelization.cpp:451-458), SAT
@@ -289,7 +291,7 @@ constexpr uint32_t kMaxSurvivors = 8192;      // survivor queue entries (= candi
 template <bool UV>
 __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                                      Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
-                                                     Params p)
+                                                     uint2 *jobq_all, Params p)
 {
     __shared__ uint32_t s_leaf[kTilesPerBatch * kLeafStride];
     __shared__ uint32_t s_tleaf[kTilesPerBatch];
@@ -298,20 +300,24 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     __shared__ uint32_t s_tprefix[kTilesPerBatch + 2];
     __shared__ uint32_t s_scan[kBlock / 64];
     __shared__ uint32_t s_tend;
-    __shared__ uint32_t s_chunk_tile[kMaxSurvivors / 64 + 1];
+    __shared__ uint32_t s_chunk_tile[kQueueCap / 64 + 1];
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
-    __shared__ uint16_t s_surv[kMaxSurvivors];
-    __shared__ uint32_t s_batch, s_nsurv, s_next, s_hits, s_direct;
+    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct;
+    // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
+    // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
+    // voxel (the long ones) are filed from the front, the others from the back, and the queue is served front to back:
+    // longest jobs first keeps the end of a sub-batch, when lanes run out of work, short.
+    uint2 *jobq = jobq_all + (size_t) blockIdx.x * kQueueCap;
     __shared__ uint8_t s_cls[64];  // classify_flags
 
     if (expand_overflowed(c, p)) return;
     const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
-    // Batch size: about six batches per workgroup, between one tile per wavefront and what the LDS staging holds.  Few
+    // Batch size: about kBatchesPerBlock batches per workgroup, between one tile per wavefront and what the LDS staging holds.  Few
     // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
     // of the machine busy); many small ones pay the per-batch staging and barriers too often.  Measured on seven
     // workload shapes.
-    uint32_t tiles_per_batch = (n_tiles + gridDim.x * 6u - 1u) / (gridDim.x * 6u);
+    uint32_t tiles_per_batch = (n_tiles + gridDim.x * kBatchesPerBlock - 1u) / (gridDim.x * kBatchesPerBlock);
     tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
                       : (tiles_per_batch > kTilesPerBatch ? kTilesPerBatch : tiles_per_batch);
     const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
@@ -319,6 +325,17 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
 #ifdef O2V_INSTRUMENT
     uint32_t dbgc[16] = {};
+    unsigned long long tmr[4] = {0, 0, 0, 0};  // cycles: staging + phase 1 | phase 2 loop | waiting at the barrier after phase 2 | whole kernel
+    unsigned long long t_mark = __builtin_readcyclecounter();
+    const unsigned long long t_kernel0 = t_mark;
+    auto lap = [&](int which) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        tmr[which] += now - t_mark;
+        t_mark = now;
+    };
+#define O2V_LAP(i) lap(i)
+#else
+#define O2V_LAP(i) do { } while (0)
 #endif
     if (threadIdx.x == 0) {
         s_hits = 0;
@@ -361,22 +378,24 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             // exclusive prefix of the tile sizes: s_tprefix[k] = candidates before tile k, s_tprefix[nt] = total
             uint32_t total;
             const uint32_t ex = block_exscan(my_count, s_scan, total);
-            if (threadIdx.x <= nt) s_tprefix[threadIdx.x] = threadIdx.x < nt ? ex : total;
+            if (threadIdx.x < nt) s_tprefix[threadIdx.x] = ex;
+            if (threadIdx.x == 0) s_tprefix[nt] = total;  // (nt may equal the number of threads)
         }
 
-        // sub-batches of whole tiles with at most kMaxSurvivors candidates
+        // sub-batches of whole tiles with at most kQueueCap candidates
         uint32_t t_begin = 0;
         while (t_begin < nt) {
             __syncthreads();
             const uint32_t base_cand = s_tprefix[t_begin];
             // the last tile whose end still fits decides t_end (found by the thread that owns it)
             if (threadIdx.x >= t_begin && threadIdx.x < nt) {
-                const bool fits = s_tprefix[threadIdx.x + 1] - base_cand <= kMaxSurvivors;
-                const bool next_fits = threadIdx.x + 1 < nt && s_tprefix[threadIdx.x + 2] - base_cand <= kMaxSurvivors;
+                const bool fits = s_tprefix[threadIdx.x + 1] - base_cand <= kQueueCap;
+                const bool next_fits = threadIdx.x + 1 < nt && s_tprefix[threadIdx.x + 2] - base_cand <= kQueueCap;
                 if (fits && !next_fits) s_tend = threadIdx.x + 1;
             }
             if (threadIdx.x == 0) {
-                s_nsurv = 0;
+                s_nheavy = 0;
+                s_nlight = 0;
                 s_next = 0;
             }
             __syncthreads();
@@ -395,7 +414,8 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             __syncthreads();
             for (uint32_t g0 = wave * 64u; g0 < n_cand; g0 += kBlock) {
                 const uint32_t g = g0 + lane;
-                bool keep = false;
+                bool keep = false, heavy = false;
+                uint2 rec = make_uint2(0u, 0u);
                 uint32_t k = s_chunk_tile[g0 / 64u], i = 0;
                 if (g < n_cand) {
                     while (s_tprefix[k + 1] - base_cand <= g) ++k;
@@ -432,30 +452,61 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                     // plane distance cull, voxelization.cpp:451-458
                     const float sd = dot(nrm, V3{cx, cy, cz} - v0);
                     keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, cx, cy, cz);
+                    if (keep) {
+                        // the job record: position, tile slot, the planes of this voxel the leaf does not pass whole
+                        const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + ly, qz = (lf[21] & 0xffffu) + lz;
+                        const bool small = (s_tcount[k] >> 31) != 0u;
+                        Piece<false> leaf;
+                        leaf.a = v0;
+                        leaf.b = v1;
+                        leaf.c = v2;
+                        uint32_t cf0, out_unused;
+                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 63u, cf0, out_unused);
+                        rec = make_uint2(qx | (qy << 16), qz | (k << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u));
+                        heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
+                    }
                 }
-                const unsigned long long m = __ballot(keep);
-                if (m) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&s_nsurv, (uint32_t) __popcll(m));
-                    base = __shfl(base, 0, 64);
-                    if (keep) s_surv[base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t) (((k - t_begin) << 8) | i);
+                const unsigned long long mh = __ballot(keep && heavy), ml = __ballot(keep && !heavy);
+                if (mh | ml) {
+                    uint32_t base_h = 0, base_l = 0;
+                    if (lane == 0) {
+                        if (mh) base_h = atomicAdd(&s_nheavy, (uint32_t) __popcll(mh));
+                        if (ml) base_l = atomicAdd(&s_nlight, (uint32_t) __popcll(ml));
+                    }
+                    base_h = __shfl(base_h, 0, 64);
+                    base_l = __shfl(base_l, 0, 64);
+                    if (keep) {
+                        const uint32_t at = heavy ? base_h + __builtin_amdgcn_mbcnt_hi((uint32_t) (mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mh, 0u))
+                                                  : kQueueCap - 1u - (base_l + __builtin_amdgcn_mbcnt_hi((uint32_t) (ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ml, 0u)));
+                        jobq[at] = rec;
+                    }
                 }
             }
-            __syncthreads();
-            const uint32_t n_surv = s_nsurv;
+            __syncthreads();  // (workgroup scope: the records written above are visible to every wavefront of the workgroup)
+            const uint32_t n_heavy = s_nheavy, n_surv = n_heavy + s_nlight;
 
+            O2V_LAP(0);
             // ---- phase 2: persistent lanes ------------------------------------------------------------------
             Piece<UV> cur{}, sec{};
             PieceStack<UV> stack{};
             Piece<UV> overflow[kStackOverflow];
-            uint32_t sp = 0, my_k = 0;  // sp: pending siblings of this lane's job
+            uint32_t sp = 0, my_k = 0;  // sp: pending siblings of this lane's job; my_k: its tile slot
             uint32_t cf = 0;     // planes the current piece does not pass whole (bit = level), see piece_masks
             uint32_t pmask = 0;  // the same for the pending siblings: 6 bits per stack entry
             bool active = false, has_job = false, small = false;
             float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
             float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
-            uint32_t px = 0, py = 0, pz = 0;
-            bool queue_empty = n_surv == 0;
+            uint32_t pos_xy = 0, pos_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
+            // Every lane holds its next job one ahead: the record is requested from the queue (an LDS ticket, then a load
+            // that L2 answers) when the lane starts a job and is only looked at when that job is done.
+            uint2 next_rec = make_uint2(0u, 0u);
+            bool next_valid = false;
+            auto take_job = [&]() {
+                const uint32_t q = atomicAdd(&s_next, 1u);
+                next_valid = q < n_surv;
+                if (next_valid) next_rec = jobq[q < n_heavy ? q : kQueueCap - 1u - (q - n_heavy)];
+            };
+            take_job();
             // parked result of this lane's last finished hit
             float d_w = 0.f, d_u = 0.f, d_v = 0.f;
             uint32_t d_xy = 0, d_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
@@ -539,8 +590,8 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                     if (leaving) break;
                     if (fin_hit) {
                         d_w = w; d_u = u; d_v = v;
-                        d_xy = px | (py << 16);
-                        d_zk = pz | (my_k << 16);
+                        d_xy = pos_xy;
+                        d_zk = pos_zk;
                         d_valid = true;
                         has_job = false;
                     }
@@ -556,63 +607,43 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                         pmask &= ~(63u << sh);
                         active = true;
                     }
-                    else if (!queue_empty) {
-                        const uint32_t q = atomicAdd(&s_next, 1u);
-                        if (q < n_surv) {
-                            const uint32_t e = s_surv[q];
-                            my_k = t_begin + (e >> 8);
-                            const uint32_t *lf = &s_leaf[__umul24(my_k, kLeafStride)];
-                            const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
-                            const uint32_t j = s_tstart[my_k] + (e & 255u);
-                            uint32_t row, lx, ly, lz;
-                            if (j < (1u << 24)) {
-                                row = (uint32_t) ((float) j * s_inv_dx[my_k]);
-                                int32_t rx = (int32_t) (j - __umul24(row, dx));  // all below 2^24 here
-                                if (rx < 0) { row -= 1; rx += (int32_t) dx; }
-                                else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
-                                lx = (uint32_t) rx;
-                                lz = (uint32_t) ((float) row * s_inv_dy[my_k]);
-                                int32_t ry = (int32_t) (row - __umul24(lz, dy));
-                                if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
-                                else if ((uint32_t) ry >= dy) { lz += 1; ry -= (int32_t) dy; }
-                                ly = (uint32_t) ry;
-                            }
-                            else {
-                                row = j / dx;
-                                lx = j - row * dx;
-                                lz = row / dy;
-                                ly = row - lz * dy;
-                            }
-                            px = (lf[20] & 0xffffu) + lx;
-                            py = (lf[20] >> 16) + ly;
-                            pz = (lf[21] & 0xffffu) + lz;
-                            fx = (float) px;
-                            fy = (float) py;
-                            fz = (float) pz;
-                            cur.a = {__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
-                            cur.b = {__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
-                            cur.c = {__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
-                            if (UV) {
-                                cur.ta = {__uint_as_float(lf[12]), __uint_as_float(lf[13])};
-                                cur.tb = {__uint_as_float(lf[14]), __uint_as_float(lf[15])};
-                                cur.tc = {__uint_as_float(lf[16]), __uint_as_float(lf[17])};
-                            }
-                            area = __uint_as_float(lf[23]);
-                            w = 0.f;
-                            u = 0.f;
-                            v = 0.f;
-                            small = (s_tcount[my_k] >> 31) != 0u;
-                            uint32_t out_unused;
-                            piece_masks<UV>(cur, fx, fy, fz, small, 63u, cf, out_unused);
-                            active = true;
-                            has_job = true;
+                    else if (next_valid) {
+                        // the next job was fetched while this lane worked on the last one (take_job below)
+                        const uint2 rec = next_rec;
+                        my_k = (rec.y >> 16) & 255u;
+                        const uint32_t *lf = &s_leaf[__umul24(my_k, kLeafStride)];
+                        pos_xy = rec.x;
+                        pos_zk = rec.y & 0x00ffffffu;  // z | tile slot << 16
+                        fx = (float) (rec.x & 0xffffu);
+                        fy = (float) (rec.x >> 16);
+                        fz = (float) (rec.y & 0xffffu);
+                        cf = (rec.y >> 24) & 63u;
+                        small = (rec.y >> 30) & 1u;
+                        cur.a = {__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                        cur.b = {__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                        cur.c = {__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                        if (UV) {
+                            cur.ta = {__uint_as_float(lf[12]), __uint_as_float(lf[13])};
+                            cur.tb = {__uint_as_float(lf[14]), __uint_as_float(lf[15])};
+                            cur.tc = {__uint_as_float(lf[16]), __uint_as_float(lf[17])};
                         }
-                        else {
-                            queue_empty = true;
-                        }
+                        area = __uint_as_float(lf[23]);
+                        w = 0.f;
+                        u = 0.f;
+                        v = 0.f;
+                        active = true;
+                        has_job = true;
+                        take_job();
                     }
                 }
                 O2V_EV(1, active);
+#ifdef O2V_INSTRUMENT
+                {
+                    const uint32_t na = (uint32_t) __popcll(__ballot(active));
+                    O2V_EV(4, lane == 0 && na <= 16u);
+                    O2V_EV(6, lane == 0 && na <= 32u);
+                }
+#endif
                 if (active) {
                     // `cf` names the planes (bit = level: lo x, y, z, hi x, y, z) this piece does not pass whole; all others
                     // are the loSum == 0 / loSum == 3 case of splitTriangle (voxelization.cpp:194-205), which hands the
@@ -671,7 +702,6 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                             if (c_done) accumulate_piece<UV>(cur, area, w, u, v);
                             if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v);
                             O2V_EV(12, s_push);
-                            O2V_EV(13, s_push && sp >= kStackRegs);
                             stack_store<UV>(stack, s_push ? sp : 7u, sec);  // 7: no slot, nothing stored
                             if (s_push && sp >= kStackRegs) overflow[sp - kStackRegs] = sec;
                             pmask |= s_push ? s_fail << ((sp << 2) + (sp << 1)) : 0u;
@@ -689,8 +719,13 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 // needs its slot again or when the wavefront leaves - not in every iteration.
                 const bool finished = has_job && !active && sp == 0;
                 if (finished && w == 0.f) has_job = false;  // the voxel was not hit
-                leaving = !__ballot(active || sp != 0 || !queue_empty || has_job);
+                leaving = !__ballot(active || sp != 0 || next_valid || has_job);
             }
+            O2V_LAP(1);
+#ifdef O2V_INSTRUMENT
+            __syncthreads();
+            O2V_LAP(2);
+#endif
             t_begin = t_end;
         }
     }
@@ -698,11 +733,14 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     for (uint32_t k = chunk_used + lane; k < kHitChunk; k += 64)
         if (chunk_used != kHitChunk && chunk_base + k < p.cap_hits) pool[chunk_base + k].brick = kHoleBrick;
 #ifdef O2V_INSTRUMENT
-    for (uint32_t k = 0; k < 16; ++k) {
+    tmr[3] = __builtin_readcyclecounter() - t_kernel0;
+    for (uint32_t k = 0; k < 12; ++k) {
         uint32_t t = dbgc[k];
         for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
         if (lane == 0 && t) atomicAdd(&c->dbg[k], (unsigned long long) t);
     }
+    if (lane == 0)
+        for (uint32_t k = 0; k < 4; ++k) atomicAdd(&c->dbg[12 + k], tmr[k]);  // summed over the wavefronts
 #endif
     __syncthreads();
     if (threadIdx.x == 0 && s_hits) atomicAdd(&c->n_hits, (unsigned long long) s_hits);

@@ -95,6 +95,7 @@ struct o2v_hip_ctx {
     Tile *d_tiles = nullptr;
     BigLeaf *d_big = nullptr;
     Node *d_nodes[2] = {nullptr, nullptr};
+    uint2 *d_jobq = nullptr;  // k_voxelize's job queues: kQueueCap records per workgroup
     HitRec *d_pool = nullptr;
     SortedRec *d_sorted = nullptr;  // cap_hits records (read through SortedView: 24 or 16 bytes per record)
     uint32_t sorted_stride = 6;
@@ -252,11 +253,11 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? 3u : 4u);
         if (use_uv) {
             hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         else {
             hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         O2V_STAGE("k_voxelize");
     }
@@ -504,7 +505,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
-                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid,
+                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq,
                     ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
     for (void *q : ptrs)
@@ -724,6 +725,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         ctx->stats.grid_bytes += cells * sizeof(unsigned long long) + n_bricks;
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
+    if (!ctx->d_jobq)
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * 4u * kQueueCap * sizeof(uint2)));
 
     // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
     uint64_t want_leaves = std::max<uint64_t>(ctx->cap_leaves, ctx->n_tris + ctx->n_tris / 4 + (1u << 16));

@@ -179,39 +179,42 @@ __device__ __forceinline__ Piece<UV> stack_load(const PieceStack<UV> &st, uint32
 // NaN rejects nothing.
 constexpr float kSatMargin = 0.02f;
 
-__device__ __forceinline__ bool sat_axis_separates(float p0, float p1, float rad)
+// (not reference arithmetic: fused multiply-adds are fine here, the margin covers their rounding as well)
+__device__ __forceinline__ float sat_axis_excess(float ea, float eb, float ua, float ub, float wa, float wb)
 {
-    const float lo = p0 < p1 ? p0 : p1, hi = p0 < p1 ? p1 : p0;
-    return lo > rad || hi < -rad;
+    // axis = (coordinate axis) x edge; p0, p1 = projections of a vertex on the edge and of the vertex opposite it; the
+    // triangle's interval [min, max] of the two misses the box interval [-rad, rad] iff |p0 + p1| - |p0 - p1| > 2 rad
+    const float p0 = __builtin_fmaf(ea, ub, -(eb * ua)), p1 = __builtin_fmaf(ea, wb, -(eb * wa));
+    const float rad2 = (2.0f * (0.5f + kSatMargin)) * (abs_f(ea) + abs_f(eb));
+    return (abs_f(p0 + p1) - abs_f(p0 - p1)) - rad2;  // > 0: this axis separates
 }
 
+// Only for leaves whose coordinates are all finite (`small`): with a NaN anywhere the maxima below would ignore it.
 __device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, float cx, float cy, float cz)
 {
     const float h = 0.5f + kSatMargin;
     const V3 c{cx, cy, cz};
     const V3 a = v0 - c, b = v1 - c, d = v2 - c;
     const V3 e0 = b - a, e1 = d - b, e2 = a - d;
-    {
-        // plane axis: |n . a| <= h * |n|_1, n = e0 x e1.  Each component of n carries an absolute rounding error of a
-        // few ulp of |e0|_1 |e1|_1 (cancellation), which the bound below over-estimates by more than 10x.
-        const V3 n = cross(e0, e1);
-        const float dist = n.x * a.x + n.y * a.y + n.z * a.z;
-        const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z));
-        const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
-        const float la = abs_f(a.x) + abs_f(a.y) + abs_f(a.z);
-        const float err = 1e-5f * l0 * l1 * (la + 1.0f);
-        if (abs_f(dist) > rad + err) return false;
-    }
-    // axis = X x e: projections use only the vertices not on edge e (the edge's own vertices project equally)
-#define O2V_SAT_EDGE(E, U, W)                                                                               \
-    if (sat_axis_separates(E.z * U.y - E.y * U.z, E.z * W.y - E.y * W.z, h * (abs_f(E.z) + abs_f(E.y)))) return false; \
-    if (sat_axis_separates(E.x * U.z - E.z * U.x, E.x * W.z - E.z * W.x, h * (abs_f(E.x) + abs_f(E.z)))) return false; \
-    if (sat_axis_separates(E.y * U.x - E.x * U.y, E.y * W.x - E.x * W.y, h * (abs_f(E.y) + abs_f(E.x)))) return false;
+    // plane axis: |n . a| <= h * |n|_1, n = e0 x e1.  Each component of n carries an absolute rounding error of a
+    // few ulp of |e0|_1 |e1|_1 (cancellation), which the bound below over-estimates by more than 10x.
+    const V3 n = cross(e0, e1);
+    const float dist = n.x * a.x + n.y * a.y + n.z * a.z;
+    const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z));
+    const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
+    const float la = abs_f(a.x) + abs_f(a.y) + abs_f(a.z);
+    const float err = 1e-5f * l0 * l1 * (la + 1.0f);
+    float worst = abs_f(dist) - (rad + err);
+    // the nine edge axes, branch-free: the largest excess decides
+#define O2V_SAT_EDGE(E, U, W)                                                            \
+    worst = fmaxf(worst, fmaxf(fmaxf(sat_axis_excess(E.z, E.y, U.z, U.y, W.z, W.y),      \
+                                     sat_axis_excess(E.x, E.z, U.x, U.z, W.x, W.z)),     \
+                               sat_axis_excess(E.y, E.x, U.y, U.x, W.y, W.x)));
     O2V_SAT_EDGE(e0, a, d)
     O2V_SAT_EDGE(e1, b, a)
     O2V_SAT_EDGE(e2, d, b)
 #undef O2V_SAT_EDGE
-    return true;
+    return !(worst > 0.f);
 }
 
 
@@ -270,8 +273,14 @@ __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float 
 constexpr uint32_t kFlushAt = 48;             // parked hits per wavefront that trigger the append section
 constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
 constexpr uint32_t kQueueCap = 16384;         // job queue records (= candidate voxels at most) per sub-batch and workgroup
-constexpr uint32_t kBatchesPerBlock = 4;      // aimed-at number of batches per workgroup (see tiles_per_batch)
-constexpr uint32_t kHeavyPlanes = 5;          // a job whose leaf straddles at least this many voxel planes is queued first
+#ifndef O2V_BATCHES_PER_BLOCK
+#define O2V_BATCHES_PER_BLOCK 4
+#endif
+#ifndef O2V_HEAVY_PLANES
+#define O2V_HEAVY_PLANES 5
+#endif
+constexpr uint32_t kBatchesPerBlock = O2V_BATCHES_PER_BLOCK;      // aimed-at number of batches per workgroup (see tiles_per_batch)
+constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf straddles at least this many voxel planes is queued first
 
 // K2.  Persistent workgroups pull batches of tiles.  Per batch:
 //   phase 1  every candidate voxel of the tiles: decode, plane-distance cull (voxelization.cpp:451-458), SAT
@@ -288,8 +297,11 @@ constexpr uint32_t kHeavyPlanes = 5;          // a job whose leaf straddles at l
 //            pieces pop the next survivor, so the wavefront stays full.
 // Register budget: 4 waves per SIMD without uv arithmetic, 3 with it (the allocator spills a handful of cold values;
 // measured faster than running one wave fewer on the bench mesh and on the large textured workloads).
+#ifndef O2V_K2_WAVES
+#define O2V_K2_WAVES 4
+#endif
 template <bool UV>
-__global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+__global__ __launch_bounds__(kBlock, (UV ? 3 : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                                      Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
                                                      uint2 *jobq_all, Params p)
 {
@@ -297,10 +309,10 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
     __shared__ uint32_t s_tleaf[kTilesPerBatch];
     __shared__ uint32_t s_tstart[kTilesPerBatch];
     __shared__ uint32_t s_tcount[kTilesPerBatch];
-    __shared__ uint32_t s_tprefix[kTilesPerBatch + 2];
+    __shared__ uint32_t s_tprefix[kTilesPerBatch + 6];  // + total + padding for the four-entry window of phase 1
     __shared__ uint32_t s_scan[kBlock / 64];
     __shared__ uint32_t s_tend;
-    __shared__ uint32_t s_chunk_tile[kQueueCap / 64 + 1];
+    __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-candidate chunk's first candidate
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
     __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct;
     // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
@@ -380,6 +392,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             const uint32_t ex = block_exscan(my_count, s_scan, total);
             if (threadIdx.x < nt) s_tprefix[threadIdx.x] = ex;
             if (threadIdx.x == 0) s_tprefix[nt] = total;  // (nt may equal the number of threads)
+            if (threadIdx.x < 5u) s_tprefix[nt + 1u + threadIdx.x] = 0xffffffffu;  // never <= a candidate index
         }
 
         // sub-batches of whole tiles with at most kQueueCap candidates
@@ -409,16 +422,23 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             if (threadIdx.x >= t_begin && threadIdx.x < t_end) {
                 const uint32_t lo = s_tprefix[threadIdx.x] - base_cand, hi = s_tprefix[threadIdx.x + 1] - base_cand;
                 if (hi > lo)
-                    for (uint32_t ch = (lo + 63u) / 64u; ch * 64u < hi; ++ch) s_chunk_tile[ch] = threadIdx.x;
+                    for (uint32_t ch = (lo + 63u) / 64u; ch * 64u < hi; ++ch) s_chunk_tile[ch] = (uint8_t) threadIdx.x;
             }
             __syncthreads();
+            O2V_LAP(0);
             for (uint32_t g0 = wave * 64u; g0 < n_cand; g0 += kBlock) {
                 const uint32_t g = g0 + lane;
                 bool keep = false, heavy = false;
                 uint2 rec = make_uint2(0u, 0u);
                 uint32_t k = s_chunk_tile[g0 / 64u], i = 0;
                 if (g < n_cand) {
-                    while (s_tprefix[k + 1] - base_cand <= g) ++k;
+                    // the chunk starts in tile k; this lane's tile is at most a few further on: count the tile ends at or
+                    // before g among the next four (one LDS round trip), walk on only if all four are (tiny tiles)
+                    const uint32_t e1 = s_tprefix[k + 1], e2 = s_tprefix[k + 2], e3 = s_tprefix[k + 3], e4 = s_tprefix[k + 4];
+                    const uint32_t gg = g + base_cand;
+                    k += (e1 <= gg ? 1u : 0u) + (e2 <= gg ? 1u : 0u) + (e3 <= gg ? 1u : 0u) + (e4 <= gg ? 1u : 0u);
+                    if (e4 <= gg)
+                        while (s_tprefix[k + 1] <= gg) ++k;
                     i = g - (s_tprefix[k] - base_cand);
                     const uint32_t *lf = &s_leaf[k * kLeafStride];
                     const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
@@ -451,11 +471,11 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                                 cz = (float) ((lf[21] & 0xffffu) + lz) + 0.5f;
                     // plane distance cull, voxelization.cpp:451-458
                     const float sd = dot(nrm, V3{cx, cy, cz} - v0);
-                    keep = !(abs_f(sd) > kPlaneDistanceLimit) && sat_may_overlap(v0, v1, v2, cx, cy, cz);
+                    const bool small = (s_tcount[k] >> 31) != 0u;
+                    keep = !(abs_f(sd) > kPlaneDistanceLimit) && (!small || sat_may_overlap(v0, v1, v2, cx, cy, cz));
                     if (keep) {
                         // the job record: position, tile slot, the planes of this voxel the leaf does not pass whole
                         const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + ly, qz = (lf[21] & 0xffffu) + lz;
-                        const bool small = (s_tcount[k] >> 31) != 0u;
                         Piece<false> leaf;
                         leaf.a = v0;
                         leaf.b = v1;
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
             __syncthreads();  // (workgroup scope: the records written above are visible to every wavefront of the workgroup)
             const uint32_t n_heavy = s_nheavy, n_surv = n_heavy + s_nlight;
 
-            O2V_LAP(0);
+            O2V_LAP(2);
             // ---- phase 2: persistent lanes ------------------------------------------------------------------
             Piece<UV> cur{}, sec{};
             PieceStack<UV> stack{};
@@ -602,7 +622,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                         sp -= 1u;
                         cur = stack_load<UV>(stack, sp);
                         if (sp >= kStackRegs) cur = overflow[sp - kStackRegs];
-                        const uint32_t sh = (sp << 2) + (sp << 1);  // 6 bits per entry
+                        const uint32_t sh = __umul24(sp, 6u);  // 6 bits per entry
                         cf = (pmask >> sh) & 63u;
                         pmask &= ~(63u << sh);
                         active = true;
@@ -704,7 +724,7 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                             O2V_EV(12, s_push);
                             stack_store<UV>(stack, s_push ? sp : 7u, sec);  // 7: no slot, nothing stored
                             if (s_push && sp >= kStackRegs) overflow[sp - kStackRegs] = sec;
-                            pmask |= s_push ? s_fail << ((sp << 2) + (sp << 1)) : 0u;
+                            pmask |= s_push ? s_fail << __umul24(sp, 6u) : 0u;
                             sp += s_push ? 1u : 0u;
                             cur = sel_piece<UV>(s_takes_over, sec, cur);
                             cf = s_takes_over ? s_fail : c_fail;
@@ -722,10 +742,6 @@ __global__ __launch_bounds__(kBlock, (UV ? 3 : 4)) void k_voxelize(const Leaf *_
                 leaving = !__ballot(active || sp != 0 || next_valid || has_job);
             }
             O2V_LAP(1);
-#ifdef O2V_INSTRUMENT
-            __syncthreads();
-            O2V_LAP(2);
-#endif
             t_begin = t_end;
         }
     }

@@ -1,9 +1,6 @@
-mkdir -p gpurun_out
-timeout 60 python tools/run_workload.py cube1024 2>&1 | cut -c1-200
-timeout 60 python tools/run_workload.py room2048 2>&1 | cut -c1-200
-timeout 60 python tools/run_workload.py lowpoly1024 2>&1 | cut -c1-200
-timeout 120 python tools/bench_configs.py config 2>&1 | python -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l); print(d['workload'], d['ms'], d['mvox_s'], d['stages_ms']['voxelize_ms'])"
-timeout 400 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -k "not 4096" > gpurun_out/t.log 2>&1; echo rc=$?; grep -E "passed|failed" gpurun_out/t.log
+for lib in libobj2voxel_amd.so libvar_w5.so; do echo "== $lib"; 
+O2V_LIB=obj2voxel_amd/$lib timeout 100 python bench.py --no-cpu-baseline --no-capi --steps 20 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['pipeline']['stages_ms'])"
+O2V_LIB=obj2voxel_amd/$lib timeout 60 python tools/run_workload.py config2_blend 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['workload'], d['ms'], d['stages_ms'])"
+done
+timeout 300 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py -x -q > gpurun_out/t.log 2>&1; echo rc=$?; grep -E "passed|failed" gpurun_out/t.log
+O2V_LIB=obj2voxel_amd/libvar_w5.so timeout 300 python -m pytest tests/test_gpu_fuzz.py -x -q > gpurun_out/t5.log 2>&1; echo rc=$?; grep -E "passed|failed" gpurun_out/t5.log

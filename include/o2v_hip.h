@@ -97,6 +97,25 @@ int o2v_hip_set_triangles(o2v_hip_ctx *ctx, const float *verts, const float *uvs
                           const float *colors, const int32_t *texids, uint64_t count);
 int o2v_hip_set_textures(o2v_hip_ctx *ctx, const o2v_hip_texture *textures, uint32_t count);
 
+/* Streamed variant of o2v_hip_set_triangles for a triangle source that is drained one triangle at a time (the reference's
+ * cache loop, src/obj2voxel.cpp:578-600): the caller fills a block of page-locked staging memory owned by the context,
+ * commits it - the block is copied to the device asynchronously while the caller fills the other block - and finishes.
+ * `arrays` says which optional arrays the mesh has so far (bit 0 uvs, 1 types, 2 colors, 3 texids; verts always); an
+ * array may appear at any commit, the triangles before it get its default (zero uvs / MATERIALLESS / zero colour /
+ * texture 0) on the device, and from then on the caller fills it for every triangle. */
+typedef struct {
+    float *verts;      /* [capacity][9] */
+    float *uvs;        /* [capacity][6] */
+    uint32_t *types;   /* [capacity]    */
+    float *colors;     /* [capacity][3] */
+    int32_t *texids;   /* [capacity]    */
+    uint64_t capacity; /* triangles per block */
+} o2v_hip_staging;
+enum { O2V_HIP_ARRAY_UVS = 1, O2V_HIP_ARRAY_TYPES = 2, O2V_HIP_ARRAY_COLORS = 4, O2V_HIP_ARRAY_TEXIDS = 8 };
+int o2v_hip_begin_triangles(o2v_hip_ctx *ctx, o2v_hip_staging *out_block);
+int o2v_hip_commit_triangles(o2v_hip_ctx *ctx, uint64_t count, uint32_t arrays, o2v_hip_staging *out_next_block);
+int o2v_hip_end_triangles(o2v_hip_ctx *ctx, uint32_t any_textured);
+
 /* Runs the whole device pipeline and waits for it.  out_voxel_count receives the number of occupied voxels. */
 int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *out_voxel_count);
 

@@ -233,6 +233,73 @@ struct MeshArrays {
     }
 };
 
+// The same for a single-GPU session, without the intermediate host copy: the source is drained straight into the
+// page-locked staging blocks of the device context (o2v_hip_begin / commit / end_triangles), each block being copied to
+// the device while the next one is filled.
+struct StreamedUpload {
+    o2v_hip_ctx *ctx = nullptr;
+    o2v_hip_staging st{};
+    uint64_t in_block = 0, total = 0;
+    uint32_t arrays = 0;  // O2V_HIP_ARRAY_* the mesh has so far
+    bool any_textured = false, failed = false;
+    std::map<const obj2voxel_texture *, int32_t> tex_index;
+    std::vector<const obj2voxel_texture *> tex_list;
+
+    bool begin(o2v_hip_ctx *c)
+    {
+        ctx = c;
+        return o2v_hip_begin_triangles(ctx, &st) == O2V_HIP_OK;
+    }
+    // an optional array appears: the triangles of this block so far get its default (earlier blocks: on the device)
+    void activate(uint32_t which)
+    {
+        if (which & O2V_HIP_ARRAY_TYPES) std::fill(st.types, st.types + in_block, (uint32_t) O2V_HIP_TRI_MATERIALLESS);
+        if (which & O2V_HIP_ARRAY_COLORS) std::fill(st.colors, st.colors + in_block * 3, 0.f);
+        if (which & O2V_HIP_ARRAY_UVS) std::fill(st.uvs, st.uvs + in_block * 6, 0.f);
+        if (which & O2V_HIP_ARRAY_TEXIDS) std::fill(st.texids, st.texids + in_block, 0);
+        arrays |= which;
+    }
+    void commit()
+    {
+        if (o2v_hip_commit_triangles(ctx, in_block, arrays, &st) != O2V_HIP_OK) failed = true;
+        total += in_block;
+        in_block = 0;
+    }
+    void push(const HostTriangle &t)
+    {
+        if (failed) return;
+        std::memcpy(st.verts + in_block * 9, t.v, sizeof(t.v));
+        if (t.type != O2V_HIP_TRI_MATERIALLESS && !(arrays & O2V_HIP_ARRAY_TYPES)) activate(O2V_HIP_ARRAY_TYPES);
+        if (t.type == O2V_HIP_TRI_UNTEXTURED && !(arrays & O2V_HIP_ARRAY_COLORS)) activate(O2V_HIP_ARRAY_COLORS);
+        if (t.type == O2V_HIP_TRI_TEXTURED) {
+            O2V_ASSERT(t.texture != nullptr && t.texture->loaded(), "textured triangle without a loaded texture");
+            if (!(arrays & O2V_HIP_ARRAY_UVS)) activate(O2V_HIP_ARRAY_UVS | O2V_HIP_ARRAY_TEXIDS);
+            any_textured = true;
+        }
+        if (arrays & O2V_HIP_ARRAY_TYPES) st.types[in_block] = t.type;
+        if (arrays & O2V_HIP_ARRAY_COLORS) std::memcpy(st.colors + in_block * 3, t.color, sizeof(t.color));
+        if (arrays & O2V_HIP_ARRAY_UVS) {
+            int32_t id = 0;
+            if (t.type == O2V_HIP_TRI_TEXTURED) {
+                auto it = tex_index.find(t.texture);
+                if (it == tex_index.end()) {
+                    it = tex_index.emplace(t.texture, (int32_t) tex_list.size()).first;
+                    tex_list.push_back(t.texture);
+                }
+                id = it->second;
+            }
+            std::memcpy(st.uvs + in_block * 6, t.t, sizeof(t.t));
+            st.texids[in_block] = id;
+        }
+        if (++in_block == st.capacity) commit();
+    }
+    bool finish()
+    {
+        if (in_block && !failed) commit();
+        return !failed && o2v_hip_end_triangles(ctx, any_textured ? 1u : 0u) == O2V_HIP_OK;
+    }
+};
+
 // ---- device sessions -----------------------------------------------------------------------------------------------
 // What one obj2voxel_voxelize call drives: one GPU (a context), or - if the environment names several devices
 // (O2V_DEVICES=0,1,2,3 or O2V_DEVICES=all) - an in-process group of GPUs with the grid sharded by z-slab
@@ -335,26 +402,9 @@ void release_session(Session *s, bool from_cache)
 
 // The GPU leg of voxelize_specialized (reference obj2voxel.cpp:467-520): bounds, transform, per-triangle
 // voxelization, colour combine and packing all happen on the device(s); the host only moves data.
-obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, MeshArrays &mesh)
+obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session, const std::vector<int> &devices, MeshArrays *mesh_ptr,
+                                     const std::vector<const obj2voxel_texture *> &tex_list, uint64_t T, PhaseClock &clock)
 {
-    const uint64_t T = mesh.n;
-    const std::vector<const obj2voxel_texture *> &tex_list = mesh.tex_list;
-    PhaseClock clock;
-
-    const std::vector<int> devices = requested_devices();
-    bool from_cache = false;
-    Session *session = acquire_session(devices, from_cache);
-    if (!session) {
-        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device: the GPU voxelization path cannot run "
-                                               "and this library has no CPU fallback");
-        return OBJ2VOXEL_ERR_DEVICE;
-    }
-    struct Guard {
-        Session *s;
-        bool from_cache;
-        ~Guard() { release_session(s, from_cache); }
-    } guard{session, from_cache};
-
     auto device_error = [&](const char *what) {
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, std::string(what) + ": " + session->last_error());
         return OBJ2VOXEL_ERR_DEVICE;
@@ -364,11 +414,12 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, MeshArrays &mesh)
     for (const obj2voxel_texture *t : tex_list)
         tex_desc.push_back(o2v_hip_texture{t->pixels.data(), (uint32_t) t->width, (uint32_t) t->height,
                                            (uint32_t) t->channels, t->wrap});
-    const float *uvs = mesh.uvs.empty() ? nullptr : mesh.uvs.data();
-    const uint32_t *types = mesh.types.empty() ? nullptr : mesh.types.data();
-    const float *colors = mesh.colors.empty() ? nullptr : mesh.colors.data();
-    const int32_t *texids = mesh.texids.empty() ? nullptr : mesh.texids.data();
     if (session->group) {
+        MeshArrays &mesh = *mesh_ptr;
+        const float *uvs = mesh.uvs.empty() ? nullptr : mesh.uvs.data();
+        const uint32_t *types = mesh.types.empty() ? nullptr : mesh.types.data();
+        const float *colors = mesh.colors.empty() ? nullptr : mesh.colors.data();
+        const int32_t *texids = mesh.texids.empty() ? nullptr : mesh.texids.data();
         int upload = O2V_HIP_UPLOAD_H2D;
         if (const char *env = std::getenv("O2V_UPLOAD"))
             upload = std::strcmp(env, "broadcast") == 0 ? O2V_HIP_UPLOAD_BROADCAST : std::strcmp(env, "peer") == 0 ? O2V_HIP_UPLOAD_PEER : O2V_HIP_UPLOAD_H2D;
@@ -376,14 +427,13 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, MeshArrays &mesh)
             return device_error("uploading textures failed");
         if (o2v_hip_group_set_triangles(session->group, mesh.verts.data(), uvs, types, colors, texids, T, upload) != O2V_HIP_OK)
             return device_error("uploading triangles failed");
+        mesh = MeshArrays{};  // the devices hold the triangles now
     }
     else {
+        // the triangles were streamed to the device while the source was drained
         if (!tex_desc.empty() && o2v_hip_set_textures(session->ctx, tex_desc.data(), (uint32_t) tex_desc.size()) != O2V_HIP_OK)
             return device_error("uploading textures failed");
-        if (o2v_hip_set_triangles(session->ctx, mesh.verts.data(), uvs, types, colors, texids, T) != O2V_HIP_OK)
-            return device_error("uploading triangles failed");
     }
-    mesh = MeshArrays{};  // the device holds the triangles now
     const double ms_upload = clock.lap_ms();
 
     o2v_hip_params params{};
@@ -482,19 +532,60 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
 
     log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "Caching triangles ...");
     PhaseClock clock;
+    const HostTriangle *tri = input->next();
+    if (!tri) {
+        // reference obj2voxel.cpp:590-594 (no device is needed for an empty model)
+        log_message(OBJ2VOXEL_LOG_LEVEL_WARNING, "Model has no triangles, aborting and writing empty voxel model");
+        inst.sink->finalize();
+        const obj2voxel_error_t empty_result = inst.sink->can_write() ? OBJ2VOXEL_ERR_OK : OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
+        if (inst.output_kind != IoKind::MEMORY) inst.sink.reset();
+        inst.done = true;
+        return empty_result;
+    }
+    // The device session comes before the rest of the source: with one GPU the triangles are drained straight into its
+    // staging memory.
+    const std::vector<int> devices = requested_devices();
+    bool from_cache = false;
+    Session *session = acquire_session(devices, from_cache);
+    if (!session) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device: the GPU voxelization path cannot run "
+                                               "and this library has no CPU fallback");
+        if (inst.output_kind != IoKind::MEMORY) inst.sink.reset();
+        inst.done = true;
+        return OBJ2VOXEL_ERR_DEVICE;
+    }
+    struct Guard {
+        Session *s;
+        bool from_cache;
+        ~Guard() { release_session(s, from_cache); }
+    } guard{session, from_cache};
+
     MeshArrays mesh;
-    while (const HostTriangle *tri = input->next()) mesh.push(*tri);
+    StreamedUpload stream;
+    uint64_t n_tris = 0;
+    bool upload_ok = true;
+    if (session->group) {
+        for (; tri; tri = input->next()) mesh.push(*tri);
+        n_tris = mesh.n;
+    }
+    else {
+        upload_ok = stream.begin(session->ctx);
+        if (upload_ok) {
+            for (; tri; tri = input->next()) stream.push(*tri);
+            upload_ok = stream.finish();
+        }
+        n_tris = stream.total;
+    }
     log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: draining the triangle source " + std::to_string(clock.lap_ms()) + " ms");
 
     obj2voxel_error_t result;
-    if (mesh.n == 0) {
-        log_message(OBJ2VOXEL_LOG_LEVEL_WARNING, "Model has no triangles, aborting and writing empty voxel model");
-        inst.sink->finalize();
-        result = inst.sink->can_write() ? OBJ2VOXEL_ERR_OK : OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
+    if (!upload_ok) {
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, std::string("uploading triangles failed: ") + session->last_error());
+        result = OBJ2VOXEL_ERR_DEVICE;
     }
     else {
-        log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Cached model with " + std::to_string(mesh.n) + " triangles");
-        result = voxelize_on_device(inst, mesh);
+        log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Cached model with " + std::to_string(n_tris) + " triangles");
+        result = voxelize_on_device(inst, session, devices, &mesh, session->group ? mesh.tex_list : stream.tex_list, n_tris, clock);
     }
     if (inst.output_kind != IoKind::MEMORY) inst.sink.reset();
     inst.done = true;

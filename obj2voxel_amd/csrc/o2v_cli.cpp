@@ -8,6 +8,7 @@
 #include "../../include/obj2voxel.h"
 
 #include <cctype>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -32,27 +33,22 @@ void usage()
               "  -h, --help          this text");
 }
 
-// reference src/main.cpp:224-262
+// The -p argument: three letters, one per output axis, naming the model axis it takes its values from; a capital letter
+// flips it ("xZy": x = x, y = -z, z = y).  Same rule as the reference's -p (src/main.cpp:224-262): every model axis must
+// be used exactly once.  Row i of the result is the signed unit vector of the axis letter i selects.
 bool parse_permutation(const std::string &str, int out[9])
 {
+    static const std::string letters = "xyzXYZ";
     if (str.size() != 3) return false;
-    bool found[3] = {false, false, false};
-    for (size_t i = 0; i < 3; ++i) {
-        int *row = out + i * 3;
-        char c = str[i];
-        int two_if_negative = 0;
-        if (std::isupper((unsigned char) c)) {
-            c = (char) std::tolower((unsigned char) c);
-            two_if_negative = 2;
-        }
-        const unsigned axis = (unsigned) (c - 'x');
-        if (axis > 2) return false;
-        found[axis] = true;
-        row[axis] = 1 - two_if_negative;
-        row[(axis + 1) % 3] = 0;
-        row[(axis + 2) % 3] = 0;
+    unsigned used = 0;
+    std::fill(out, out + 9, 0);
+    for (size_t row = 0; row < 3; ++row) {
+        const size_t at = letters.find(str[row]);
+        if (at == std::string::npos) return false;
+        out[row * 3 + at % 3] = at < 3 ? 1 : -1;
+        used |= 1u << (at % 3);
     }
-    return found[0] && found[1] && found[2];
+    return used == 7u;
 }
 
 }  // namespace

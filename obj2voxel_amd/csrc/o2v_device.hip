@@ -74,6 +74,13 @@ struct o2v_hip_ctx {
     int32_t *d_texids = nullptr;
     uint64_t n_tris = 0;
     uint64_t cap_tri_bytes[5] = {0, 0, 0, 0, 0};  // allocated bytes of d_verts, d_uvs, d_types, d_colors, d_texids
+    // streamed upload (o2v_hip_begin / commit / end_triangles): two page-locked staging blocks, filled in turn
+    o2v_hip_staging stage[2] = {};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    int stage_cur = 0;
+    uint64_t stream_count = 0;
+    uint32_t stream_arrays = 0;
+    std::vector<void *> retired;  // device arrays replaced by larger ones while a streamed upload was in flight
     bool any_textured = false;
     DevTexture *d_textures = nullptr;
     std::vector<uint8_t *> d_texpix;
@@ -517,6 +524,12 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->d_zrange) (void) hipFree(ctx->d_zrange);
     if (ctx->d_zrange_xform) (void) hipFree(ctx->d_zrange_xform);
     if (ctx->h_zhist) (void) hipHostFree(ctx->h_zhist);
+    for (o2v_hip_staging &b : ctx->stage)
+        for (void *q : {(void *) b.verts, (void *) b.uvs, (void *) b.types, (void *) b.colors, (void *) b.texids})
+            if (q) (void) hipHostFree(q);
+    for (auto &e : ctx->ev_stage)
+        if (e) (void) hipEventDestroy(e);
+    for (void *q : ctx->retired) (void) hipFree(q);
     if (ctx->d_counts) (void) hipFree(ctx->d_counts);
     if (ctx->h_counts) (void) hipHostFree(ctx->h_counts);
     for (auto &e : ctx->ev_coll)
@@ -558,6 +571,126 @@ int o2v_hip_set_triangles(o2v_hip_ctx *ctx, const float *verts, const float *uvs
                 break;
             }
     return o2v::ctx_finish_triangles(ctx, any_textured, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+constexpr uint64_t kStageTriangles = 1u << 17;  // per staging block: 4.5 MiB of vertices, 10 MiB with every optional array
+
+// Makes room for `need` elements in a device array that already holds `have` valid ones (copied over if it has to move).
+template <typename T>
+int grow_keep(o2v_hip_ctx *ctx, T *&dptr, uint64_t &cap_bytes, uint64_t have, uint64_t need)
+{
+    if (dptr && need * sizeof(T) <= cap_bytes) return O2V_HIP_OK;
+    const uint64_t want = std::max<uint64_t>(need, 2 * (cap_bytes / sizeof(T))) * sizeof(T);
+    T *bigger = nullptr;
+    O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&bigger), want));
+    if (dptr) {
+        if (have) O2V_CHECK(hipMemcpyAsync(bigger, dptr, have * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->retired.push_back(dptr);  // freed once the stream has passed the copy (o2v_hip_end_triangles)
+    }
+    dptr = bigger;
+    cap_bytes = want;
+    return O2V_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int o2v_hip_begin_triangles(o2v_hip_ctx *ctx, o2v_hip_staging *out_block)
+{
+    if (!ctx || !out_block) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    O2V_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!ctx->stage[0].verts) {
+        for (int b = 0; b < 2; ++b) {
+            o2v_hip_staging &st = ctx->stage[b];
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.verts), kStageTriangles * 9 * sizeof(float), hipHostMallocDefault));
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.uvs), kStageTriangles * 6 * sizeof(float), hipHostMallocDefault));
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.types), kStageTriangles * sizeof(uint32_t), hipHostMallocDefault));
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.colors), kStageTriangles * 3 * sizeof(float), hipHostMallocDefault));
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.texids), kStageTriangles * sizeof(int32_t), hipHostMallocDefault));
+            st.capacity = kStageTriangles;
+            O2V_CHECK(hipEventCreateWithFlags(&ctx->ev_stage[b], hipEventDisableTiming));
+        }
+    }
+    ctx->stage_cur = 0;
+    ctx->stream_count = 0;
+    ctx->stream_arrays = 0;
+    ctx->n_tris = 0;
+    *out_block = ctx->stage[0];
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_commit_triangles(o2v_hip_ctx *ctx, uint64_t count, uint32_t arrays, o2v_hip_staging *out_next_block)
+{
+    if (!ctx || !out_next_block || !ctx->stage[0].verts || count > kStageTriangles) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const uint64_t have = ctx->stream_count, need = have + count;
+    if (need >= (1ull << 29)) {
+        ctx->err = "triangle count must be below 2^29";
+        return O2V_HIP_ERR_LIMIT;
+    }
+    O2V_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const o2v_hip_staging &st = ctx->stage[ctx->stage_cur];
+    const uint32_t fresh = arrays & ~ctx->stream_arrays;  // arrays that appear with this block
+    ctx->stream_arrays |= arrays;
+    int rc;
+    if ((rc = grow_keep(ctx, ctx->d_verts, ctx->cap_tri_bytes[0], have * 9, need * 9))) return rc;
+    if (ctx->stream_arrays & O2V_HIP_ARRAY_UVS) {
+        if ((rc = grow_keep(ctx, ctx->d_uvs, ctx->cap_tri_bytes[1], (fresh & O2V_HIP_ARRAY_UVS) ? 0 : have * 6, need * 6))) return rc;
+        if ((fresh & O2V_HIP_ARRAY_UVS) && have) O2V_CHECK(hipMemsetAsync(ctx->d_uvs, 0, have * 6 * sizeof(float), s));
+    }
+    if (ctx->stream_arrays & O2V_HIP_ARRAY_TYPES) {
+        if ((rc = grow_keep(ctx, ctx->d_types, ctx->cap_tri_bytes[2], (fresh & O2V_HIP_ARRAY_TYPES) ? 0 : have, need))) return rc;
+        if ((fresh & O2V_HIP_ARRAY_TYPES) && have) O2V_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_types), (int) O2V_HIP_TRI_MATERIALLESS, have, s));
+    }
+    if (ctx->stream_arrays & O2V_HIP_ARRAY_COLORS) {
+        if ((rc = grow_keep(ctx, ctx->d_colors, ctx->cap_tri_bytes[3], (fresh & O2V_HIP_ARRAY_COLORS) ? 0 : have * 3, need * 3))) return rc;
+        if ((fresh & O2V_HIP_ARRAY_COLORS) && have) O2V_CHECK(hipMemsetAsync(ctx->d_colors, 0, have * 3 * sizeof(float), s));
+    }
+    if (ctx->stream_arrays & O2V_HIP_ARRAY_TEXIDS) {
+        if ((rc = grow_keep(ctx, ctx->d_texids, ctx->cap_tri_bytes[4], (fresh & O2V_HIP_ARRAY_TEXIDS) ? 0 : have, need))) return rc;
+        if ((fresh & O2V_HIP_ARRAY_TEXIDS) && have) O2V_CHECK(hipMemsetAsync(ctx->d_texids, 0, have * sizeof(int32_t), s));
+    }
+    if (count) {
+        O2V_CHECK(hipMemcpyAsync(ctx->d_verts + have * 9, st.verts, count * 9 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (ctx->stream_arrays & O2V_HIP_ARRAY_UVS)
+            O2V_CHECK(hipMemcpyAsync(ctx->d_uvs + have * 6, st.uvs, count * 6 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (ctx->stream_arrays & O2V_HIP_ARRAY_TYPES)
+            O2V_CHECK(hipMemcpyAsync(ctx->d_types + have, st.types, count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        if (ctx->stream_arrays & O2V_HIP_ARRAY_COLORS)
+            O2V_CHECK(hipMemcpyAsync(ctx->d_colors + have * 3, st.colors, count * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+        if (ctx->stream_arrays & O2V_HIP_ARRAY_TEXIDS)
+            O2V_CHECK(hipMemcpyAsync(ctx->d_texids + have, st.texids, count * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    O2V_CHECK(hipEventRecord(ctx->ev_stage[ctx->stage_cur], s));
+    ctx->stream_count = need;
+    ctx->stage_cur ^= 1;
+    O2V_CHECK(hipEventSynchronize(ctx->ev_stage[ctx->stage_cur]));  // the other block's copy (two commits ago) has landed
+    *out_next_block = ctx->stage[ctx->stage_cur];
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_end_triangles(o2v_hip_ctx *ctx, uint32_t any_textured)
+{
+    if (!ctx) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    // optional arrays the mesh never used read as null in the kernels
+    if (!(ctx->stream_arrays & O2V_HIP_ARRAY_UVS) && ctx->d_uvs) { ctx->retired.push_back(ctx->d_uvs); ctx->d_uvs = nullptr; ctx->cap_tri_bytes[1] = 0; }
+    if (!(ctx->stream_arrays & O2V_HIP_ARRAY_TYPES) && ctx->d_types) { ctx->retired.push_back(ctx->d_types); ctx->d_types = nullptr; ctx->cap_tri_bytes[2] = 0; }
+    if (!(ctx->stream_arrays & O2V_HIP_ARRAY_COLORS) && ctx->d_colors) { ctx->retired.push_back(ctx->d_colors); ctx->d_colors = nullptr; ctx->cap_tri_bytes[3] = 0; }
+    if (!(ctx->stream_arrays & O2V_HIP_ARRAY_TEXIDS) && ctx->d_texids) { ctx->retired.push_back(ctx->d_texids); ctx->d_texids = nullptr; ctx->cap_tri_bytes[4] = 0; }
+    ctx->n_tris = ctx->stream_count;
+    ctx->tri_generation += 1;
+    ctx->max_tri_extent = -1.f;
+    const int rc = o2v::ctx_finish_triangles(ctx, any_textured != 0, nullptr);  // waits for the stream
+    for (void *q : ctx->retired) (void) hipFree(q);
+    ctx->retired.clear();
+    return rc;
 }
 
 int o2v_hip_set_textures(o2v_hip_ctx *ctx, const o2v_hip_texture *textures, uint32_t count)

@@ -82,8 +82,24 @@ int paeth(int a, int b, int c)
 
 }  // namespace
 
+static bool decode_png_argb_unguarded(const uint8_t *data, size_t size, std::vector<uint8_t> &argb, size_t &width, size_t &height,
+                                      std::string &err);
+
+// (an allocation failure must not escape through the extern "C" texture loaders)
 bool decode_png_argb(const uint8_t *data, size_t size, std::vector<uint8_t> &argb, size_t &width, size_t &height,
                      std::string &err)
+{
+    try {
+        return decode_png_argb_unguarded(data, size, argb, width, height, err);
+    }
+    catch (const std::bad_alloc &) {
+        err = "out of memory";
+        return false;
+    }
+}
+
+static bool decode_png_argb_unguarded(const uint8_t *data, size_t size, std::vector<uint8_t> &argb, size_t &width, size_t &height,
+                                      std::string &err)
 {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (size < 8 || std::memcmp(data, sig, 8) != 0) {
@@ -121,12 +137,20 @@ bool decode_png_argb(const uint8_t *data, size_t size, std::vector<uint8_t> &arg
         err = "missing IHDR";
         return false;
     }
+    if ((uint64_t) w * h > (1ull << 28)) {  // 268 M texels: a hostile header must not force a huge allocation
+        err = "image too large";
+        return false;
+    }
     if (interlace) {
         err = "interlaced PNG is not supported";
         return false;
     }
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!channels || (depth != 8 && depth != 16 && !(depth < 8 && (ctype == 0 || ctype == 3)))) {
+    // bit depths the PNG specification allows per colour type: grey 1/2/4/8/16, palette 1/2/4/8, the others 8/16
+    const bool depth_ok = ctype == 0   ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                          : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                       : (depth == 8 || depth == 16);
+    if (!channels || !depth_ok) {
         err = "unsupported colour type / bit depth";
         return false;
     }

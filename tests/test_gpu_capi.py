@@ -225,3 +225,50 @@ def test_concurrent_instances_and_worker_pool(oracle):
             want = oracle.voxelize(meshes_in[k], resolutions[k])
             assert np.array_equal(meshes.sorted_voxels(results[k]), meshes.sorted_voxels(want))
     a.obj2voxel_set_log_level(capi.LOG_INFO)
+
+
+def test_streamed_upload_optional_arrays_appear_late(oracle):
+    """obj2voxel_voxelize() streams the triangle source into the device's staging blocks (131 072 triangles each): a mesh
+    of more than one block whose first textured triangle arrives in the second block - uvs, texture ids and types then
+    exist on the device only from that commit on and the triangles before it get the defaults."""
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    plain = meshes.uv_sphere(190)                                   # 143 640 triangles: more than one block
+    tv, tuv = meshes.uv_sphere(40, radius=0.5, center=(0.2, 0.1, -0.3), with_uv=True)
+    tex_pixels = meshes.checker_texture(64, 8)
+    tex = a.obj2voxel_texture_alloc()
+    assert a.obj2voxel_texture_load_pixels(tex, tex_pixels.ctypes.data_as(C.POINTER(C.c_ubyte)), 64, 64, 3)
+
+    class Mixed(capi.TriangleInput):
+        def __init__(self):
+            super().__init__(np.concatenate([plain, tv]))
+            self.n_plain = len(plain)
+
+        def _next(self, _data, tri):
+            if self.index >= len(self.verts):
+                return False
+            i = self.index
+            self.index += 1
+            v = self.verts[i].ctypes.data_as(C.POINTER(C.c_float))
+            if i < self.n_plain:
+                a.obj2voxel_set_triangle_basic(tri, v)
+            else:
+                a.obj2voxel_set_triangle_textured(tri, v, tuv[i - self.n_plain].ctypes.data_as(C.POINTER(C.c_float)), tex)
+            return True
+
+    inp, out = Mixed(), capi.CollectingOutput()
+    inst = a.obj2voxel_alloc()
+    a.obj2voxel_set_input_callback(inst, inp.callback, None)
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    a.obj2voxel_set_resolution(inst, 200)
+    a.obj2voxel_set_color_strategy(inst, 1)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    a.obj2voxel_free(inst)
+    a.obj2voxel_texture_free(tex)
+    verts = np.concatenate([plain, tv])
+    T, n0 = len(verts), len(plain)
+    uvs = np.concatenate([np.zeros((n0, 6), np.float32), tuv])
+    types = np.concatenate([np.full(n0, 1, np.uint32), np.full(len(tv), 3, np.uint32)])
+    want = oracle.voxelize(verts, 200, uvs=uvs, types=types, texids=np.zeros(T, np.int32), textures=[(tex_pixels, 1)], strategy=1)
+    assert np.array_equal(meshes.sorted_voxels(out.voxels()), meshes.sorted_voxels(want))

@@ -202,9 +202,22 @@ __global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restr
         CellFold f;
         for (uint32_t t = 0; t < W; ++t) {
             if (!__any(t < n)) break;
-            const int from = (int) (base_lane + t);
-            const uint32_t hh = __shfl(hi, from, 64);
-            const float ww = __shfl(w, from, 64), uu = __shfl(u, from, 64), vv = __shfl(v, from, 64);
+            uint32_t hh;
+            float ww, uu, vv;
+            if (W == 64) {
+                // one cell per wavefront: the source lane is uniform, the values come straight out of its registers
+                hh = (uint32_t) __builtin_amdgcn_readlane((int) hi, (int) t);
+                ww = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(w), (int) t));
+                uu = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(u), (int) t));
+                vv = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), (int) t));
+            }
+            else {
+                const int from = (int) (base_lane + t);
+                hh = __shfl(hi, from, 64);
+                ww = __shfl(w, from, 64);
+                uu = __shfl(u, from, 64);
+                vv = __shfl(v, from, 64);
+            }
             if (t < n) f.add(m, p.blend, hh, ww, uu, vv);
         }
         const uint32_t argb = f.finish(m, p.blend);
@@ -304,25 +317,43 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
                 }
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
+            if (threadIdx.x < 64u) {
+                // The chain over the groups is sequential, but nothing in it has to wait for memory: the first wavefront
+                // loads 64 entries at a time, one per lane, and walks the group starts among them in order, every value
+                // of the step coming out of a lane's register (v_readlane: the lane index is wavefront-uniform).  All
+                // lanes run the same recurrence; lane 0 writes the result.
+                const uint32_t lane = threadIdx.x;
                 bool have_sub = false, have_cell = false;
                 WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
                 uint32_t cur_sub = 0;
-                for (uint32_t t = 0; t < n; ++t) {
-                    const uint32_t hi = s_hi[t];
-                    if (t != 0 && hi == s_hi[t - 1]) continue;
-                    if (have_sub && (hi >> 29) != cur_sub) {
-                        cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
-                        have_cell = true;
-                        have_sub = false;
+                for (uint32_t base = 0; base < n; base += 64u) {
+                    const uint32_t t = base + lane;
+                    const bool in = t < n;
+                    const uint32_t hi_t = in ? s_hi[t] : 0u;
+                    const bool start = in && (t == 0 || hi_t != s_hi[t - 1]);
+                    const float w_t = in ? s_w[t] : 0.f, r_t = in ? s_u[t] : 0.f, g_t = in ? s_v[t] : 0.f;
+                    const uint32_t b_t = in ? s_idx[t] : 0u;
+                    unsigned long long starts = __ballot(start);
+                    while (starts) {
+                        const int j = __builtin_ctzll(starts);
+                        starts &= starts - 1ull;
+                        const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) hi_t, j);
+                        const WCol fresh{__uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(w_t), j)),
+                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(r_t), j)),
+                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(g_t), j)),
+                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) b_t, j))};
+                        if (have_sub && (hi >> 29) != cur_sub) {
+                            cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                            have_cell = true;
+                            have_sub = false;
+                        }
+                        sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
+                        have_sub = true;
+                        cur_sub = hi >> 29;
                     }
-                    const WCol fresh{s_w[t], s_u[t], s_v[t], __uint_as_float(s_idx[t])};
-                    sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
-                    have_sub = true;
-                    cur_sub = hi >> 29;
                 }
                 if (have_sub) cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
-                out[i] = cell_record(o, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b), p);
+                if (lane == 0) out[i] = cell_record(o, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b), p);
             }
         }
         else {

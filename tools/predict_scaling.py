@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
-"""Predicts the weak-scaling balance of bench.py --gpus N on ONE GPU: runs the N-GPU job's z-slabs one after the other
-(same mesh, same resolution, same slab plan as bench.py) and reports each slab's wall time per step (plan + voxelize,
-as bench.py times it) and voxel count.  predicted efficiency = (job voxels / slowest slab) / (N * N=1 rate).
-usage: predict_scaling.py [N] [--equal]   (--equal: equal-height slabs instead of o2v_hip_plan_slabs)"""
+"""Predicts the balance of bench.py --gpus N on ONE GPU: runs the N-GPU job's planned z-slabs one after the other (same
+mesh, same resolution, same cuts as o2v_hip_voxelize_sharded derives) and reports each slab's device time and voxel count.
+The plan itself is timed as the full, unsharded passes (o2v_hip_plan_slabs): an upper bound, since the N ranks share those
+passes (each streams 1/N of the triangles) and add two small all-reduces and two all-gathers instead.
+predicted efficiency = (job voxels / (slowest slab + plan / N)) / (N * N=1 rate).
+usage: predict_scaling.py [N] [weak|config4]"""
 import json
 import sys
 import time
 
 sys.path.insert(0, '.')
 from bench import workload_for
-from obj2voxel_amd import hip, meshes, slab
+from obj2voxel_amd import hip, meshes
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
-equal = "--equal" in sys.argv
+kind = sys.argv[2] if len(sys.argv) > 2 else "weak"
 steps = 5
 dv = hip.DeviceVoxelizer(0)
-res1, nv1 = workload_for(1)
+_, res1, nv1 = workload_for(1)
 dv.set_triangles(meshes.uv_sphere(nv1))
 for _ in range(3):
     dv.voxelize(res1, read=False)
@@ -23,30 +25,32 @@ t0 = time.perf_counter()
 for _ in range(steps):
     v1 = dv.voxelize(res1, read=False)
 t1 = (time.perf_counter() - t0) / steps * 1e3
-res, nv = workload_for(n)
+name, res, nv = workload_for(n, kind)
 verts = meshes.uv_sphere(nv)
 dv.set_triangles(verts)
-rows = []
-def step(r):
-    if equal:
-        z0, z1 = slab.slab_range(r, n, res)
-        return dv.voxelize(res, zslab=(z0, z1), read=False), (z0, z1)
+for _ in range(2):
     cuts, bnd = dv.plan_slabs(res, n)
-    return dv.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False), (cuts[r], cuts[r + 1])
-
-
+t0 = time.perf_counter()
+for _ in range(steps):
+    cuts, bnd = dv.plan_slabs(res, n)
+plan_ms = (time.perf_counter() - t0) / steps * 1e3
+rows = []
 for r in range(n):
     for _ in range(2):
-        step(r)
+        dv.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False)
     t0 = time.perf_counter()
     for i in range(steps):
-        cnt, (z0, z1) = step(r)
+        cnt = dv.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False)
     wall = (time.perf_counter() - t0) / steps * 1e3
     st, t = dv.stats(), dv.timings()
-    rows.append({"rank": r, "z": [z0, z1], "voxels": cnt, "leaves": st["leaves"], "hits": st["hits"],
+    rows.append({"rank": r, "z": [cuts[r], cuts[r + 1]], "voxels": cnt, "leaves": st["leaves"], "hits": st["hits"],
                  "ms": round(wall, 3), "stages": {k: round(v, 3) for k, v in t.items() if k.endswith("_ms")}})
     print(json.dumps(rows[-1]), flush=True)
-worst = max(r["ms"] for r in rows)
-print(json.dumps({"n": n, "resolution": res, "triangles": len(verts), "total_voxels": sum(r["voxels"] for r in rows),
-                  "n1_ms": round(t1, 3), "max_slab_ms": worst, "mean_slab_ms": round(sum(r["ms"] for r in rows) / n, 3),
-                  "predicted_weak_scaling_efficiency": round((sum(r["voxels"] for r in rows) / worst) / (n * v1 / t1), 3)}))
+worst = max(r["ms"] for r in rows) + plan_ms / n
+total = sum(r["voxels"] for r in rows)
+print(json.dumps({"n": n, "workload": name, "resolution": res, "triangles": len(verts), "total_voxels": total,
+                  "n1_ms": round(t1, 3), "n1_mvoxels_per_s": round(v1 / t1 / 1e3, 1), "full_plan_ms": round(plan_ms, 3),
+                  "max_slab_ms": max(r["ms"] for r in rows), "mean_slab_ms": round(sum(r["ms"] for r in rows) / n, 3),
+                  "predicted_step_ms": round(worst, 3), "predicted_mvoxels_per_s": round(total / worst / 1e3, 1),
+                  "predicted_speedup_over_n1": round((total / worst) / (v1 / t1), 2),
+                  "predicted_weak_scaling_efficiency": round((total / worst) / (n * v1 / t1), 3)}))

@@ -38,10 +38,12 @@ rows = []
 for r in range(n):
     for _ in range(2):
         dv.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False)
-    t0 = time.perf_counter()
-    for i in range(steps):
+    walls = []
+    for i in range(2 * steps - 1):
+        t0 = time.perf_counter()
         cnt = dv.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False)
-    wall = (time.perf_counter() - t0) / steps * 1e3
+        walls.append((time.perf_counter() - t0) * 1e3)
+    wall = sorted(walls)[len(walls) // 2]   # median: a single host hiccup must not decide the slowest slab
     st, t = dv.stats(), dv.timings()
     rows.append({"rank": r, "z": [cuts[r], cuts[r + 1]], "voxels": cnt, "leaves": st["leaves"], "hits": st["hits"],
                  "ms": round(wall, 3), "stages": {k: round(v, 3) for k, v in t.items() if k.endswith("_ms")}})

@@ -26,12 +26,14 @@ struct SharedExchange {
     std::mutex m;
     std::condition_variable cv;
     uint32_t world = 1, arrived = 0, generation = 0;
+    bool aborted = false;  // a rank failed outside a collective: nobody may wait for it any more
     std::vector<void *> bufs;
 
-    // calls `last` on exactly one thread once all ranks have deposited `buf`; returns after it has run
-    void rendezvous(uint32_t rank, void *buf, const std::function<void(std::vector<void *> &)> &last)
+    // calls `last` on exactly one thread once all ranks have deposited `buf`; returns after it has run (false: aborted)
+    bool rendezvous(uint32_t rank, void *buf, const std::function<void(std::vector<void *> &)> &last)
     {
         std::unique_lock<std::mutex> lock{m};
+        if (aborted) return false;
         bufs[rank] = buf;
         const uint32_t gen = generation;
         if (++arrived == world) {
@@ -41,8 +43,22 @@ struct SharedExchange {
             cv.notify_all();
         }
         else {
-            cv.wait(lock, [&] { return generation != gen; });
+            cv.wait(lock, [&] { return generation != gen || aborted; });
         }
+        return !aborted;
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lock{m};
+        aborted = true;
+        arrived = 0;
+        cv.notify_all();
+    }
+    void reset()
+    {
+        std::lock_guard<std::mutex> lock{m};
+        aborted = false;
+        arrived = 0;
     }
 };
 
@@ -55,13 +71,12 @@ template <typename T, typename Op>
 int shared_allreduce(void *user, T *buf, size_t n, Op op)
 {
     RankLink *l = static_cast<RankLink *>(user);
-    l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
+    return l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
         T *first = static_cast<T *>(bufs[0]);
         for (uint32_t r = 1; r < l->x->world; ++r)
             for (size_t i = 0; i < n; ++i) first[i] = op(first[i], static_cast<T *>(bufs[r])[i]);
         for (uint32_t r = 1; r < l->x->world; ++r) std::memcpy(bufs[r], first, n * sizeof(T));
-    });
-    return 0;
+    }) ? 0 : 1;
 }
 int shared_min_u32(void *u, uint32_t *b, size_t n) { return shared_allreduce(u, b, n, [](uint32_t a, uint32_t c) { return std::min(a, c); }); }
 int shared_max_u32(void *u, uint32_t *b, size_t n) { return shared_allreduce(u, b, n, [](uint32_t a, uint32_t c) { return std::max(a, c); }); }
@@ -69,22 +84,20 @@ int shared_sum_u64(void *u, uint64_t *b, size_t n) { return shared_allreduce(u, 
 int shared_allgather(void *user, void *buf, size_t bytes)
 {
     RankLink *l = static_cast<RankLink *>(user);
-    l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
+    return l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
         for (uint32_t src = 0; src < l->x->world; ++src)
             for (uint32_t dst = 0; dst < l->x->world; ++dst)
                 if (src != dst)
                     std::memcpy(static_cast<char *>(bufs[dst]) + src * bytes, static_cast<char *>(bufs[src]) + src * bytes, bytes);
-    });
-    return 0;
+    }) ? 0 : 1;
 }
 int shared_broadcast(void *user, void *buf, size_t bytes, int root)
 {
     RankLink *l = static_cast<RankLink *>(user);
-    l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
+    return l->x->rendezvous(l->rank, buf, [&](std::vector<void *> &bufs) {
         for (uint32_t dst = 0; dst < l->x->world; ++dst)
             if ((int) dst != root) std::memcpy(bufs[dst], bufs[root], bytes);
-    });
-    return 0;
+    }) ? 0 : 1;
 }
 
 }  // namespace
@@ -104,8 +117,14 @@ struct o2v_hip_group {
         const uint32_t n = (uint32_t) ctx.size();
         std::vector<int> rc(n, 0);
         std::vector<std::thread> threads;
-        for (uint32_t r = 1; r < n; ++r) threads.emplace_back([&, r] { rc[r] = fn(r); });
-        rc[0] = fn(0);
+        exchange.reset();
+        // a rank that fails must not leave the others waiting for it in a host-memory collective
+        auto run = [&](uint32_t r) {
+            rc[r] = fn(r);
+            if (rc[r] && !rccl) exchange.abort();
+        };
+        for (uint32_t r = 1; r < n; ++r) threads.emplace_back([&, r] { run(r); });
+        run(0);
         for (std::thread &t : threads) t.join();
         for (uint32_t r = 0; r < n; ++r)
             if (rc[r]) {

@@ -43,6 +43,24 @@ def _equal(got, want):
     assert len(bad) == 0, f"{len(bad)} colours differ, first: {got[bad[0]]} vs {want[bad[0]]}"
 
 
+def test_config0_and_config1_spot_standin(dv, all_cores):
+    """configs[0] "Spot cow (~6k tris) at 64^3, max-blend" and configs[1] "Spot cow at 512^3, weighted-blend": the survey's
+    stand-in (uv-sphere nv=39 -> 5 928 triangles), per-triangle colours with MAX at 64^3, textured with BLEND at 512^3."""
+    from obj2voxel_amd import hip
+    v, uv = meshes.uv_sphere(39, with_uv=True)
+    T = len(v)
+    kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T))
+    dv.set_triangles(v, **kw)
+    _equal(dv.voxelize(64, strategy=hip.STRATEGY_MAX), all_cores.voxelize(v, 64, strategy=0, **kw))
+    tex = [(meshes.checker_texture(256, 16), 1)]
+    kw = dict(uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32), texids=np.zeros(T, np.int32))
+    dv.set_textures(tex)
+    dv.set_triangles(v, **kw)
+    got = dv.voxelize(512, strategy=hip.STRATEGY_BLEND)
+    _equal(got, all_cores.voxelize(v, 512, strategy=1, textures=tex, **kw))
+    assert len(got) > 1_200_000
+
+
 def test_config2_dragon_standin_1024_materialless_max(dv, all_cores):
     """The bench workload itself: 870 488 MATERIALLESS triangles at 1024^3, MAX (every hit takes the direct MAX path)."""
     v = meshes.uv_sphere(467)

@@ -295,13 +295,17 @@ constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf
 //            beyond a later plane (dropped with its whole subtree), or to be cut again.  So lanes spend their
 //            iterations on cuts only (5.9 per voxel job on the bench mesh; 8.4 events before); lanes that run out of
 //            pieces pop the next survivor, so the wavefront stays full.
-// Register budget: 4 waves per SIMD without uv arithmetic, 3 with it (the allocator spills a handful of cold values;
-// measured faster than running one wave fewer on the bench mesh and on the large textured workloads).
+// Register budget: 4 waves per SIMD for both variants (120 VGPRs without uv arithmetic; with it the allocator spills two
+// dozen cold values - measured faster than 3 waves without spills on the large textured workloads: configs[3] 31.5 ->
+// 30.1 ms).  5 waves without uv (96 VGPRs, 16 spilled) measured the same as 4.
 #ifndef O2V_K2_WAVES
 #define O2V_K2_WAVES 4
 #endif
+#ifndef O2V_K2_WAVES_UV
+#define O2V_K2_WAVES_UV 4
+#endif
 template <bool UV>
-__global__ __launch_bounds__(kBlock, (UV ? 3 : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+__global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                                      Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
                                                      uint2 *jobq_all, Params p)
 {

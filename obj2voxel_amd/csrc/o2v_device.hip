@@ -256,8 +256,8 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
 
     {
-        // persistent workgroups; residency is VGPR-bound (about 4 waves per SIMD without UVs, 3 with)
-        const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? 3u : (uint32_t) O2V_K2_WAVES);
+        // persistent workgroups, 4 per CU (one wavefront of each per SIMD)
+        const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? (uint32_t) O2V_K2_WAVES_UV : (uint32_t) O2V_K2_WAVES);
         if (use_uv) {
             hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
@@ -859,7 +859,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
     if (!ctx->d_jobq)
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) O2V_K2_WAVES * kQueueCap * sizeof(uint2)));
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) (O2V_K2_WAVES > O2V_K2_WAVES_UV ? O2V_K2_WAVES : O2V_K2_WAVES_UV) * kQueueCap * sizeof(uint2)));
 
     // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
     uint64_t want_leaves = std::max<uint64_t>(ctx->cap_leaves, ctx->n_tris + ctx->n_tris / 4 + (1u << 16));

@@ -96,5 +96,8 @@ if "config2" in summary:
     cur = {"source": f"profiles/{rnd}/config2_profile.json (rocprofv3 passes of `python bench.py --no-cpu-baseline --no-capi`)",
            "kernels": summary["config2"]["kernels"]}
     json.dump(cur, open("profiles/current.json", "w"), indent=1)
+for extra in ("predict_scaling_8_weak.jsonl", "predict_scaling_8_config4.jsonl"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(out_dir, extra))
 if os.path.exists(os.path.join(src, "bench_line.json")):
     shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(out_dir, "bench_line.json"))

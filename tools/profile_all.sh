@@ -23,6 +23,9 @@ for W in config2 config2_blend config1 config3; do
 done
 # the bench line itself (with the CPU baseline and the C API wall time), unprofiled
 timeout -k 5 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+# predicted multi-GPU balance (one GPU runs the planned slabs of the N = 8 jobs one after the other)
+timeout -k 5 200 python tools/predict_scaling.py 8 weak > $OUT/predict_scaling_8_weak.jsonl 2>&1
+timeout -k 5 400 python tools/predict_scaling.py 8 config4 > $OUT/predict_scaling_8_config4.jsonl 2>&1
 # keep the merge small: only the summaries travel back
 find $OUT -name "*_agent_info.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete
 du -sh $OUT; tail -c 400 $OUT/bench_line.json

@@ -193,12 +193,14 @@ def report(args, n, run, dv, comm):
     alg = {
         "bounds": 36 * T,
         "expand": 36 * T + 96 * L + 8 * tiles,
-        "voxelize": 96 * L + 8 * tiles + (8 + 1) * Hd + (32 + 4 + 1) * Hp,
+        # leaves and tiles staged, a job record written and read per surviving candidate, then per hit: 64-bit atomic + flag
+        # byte (direct) or pool record + counter atomic + flag byte (pooled)
+        "voxelize": 96 * L + 8 * tiles + 16 * st["jobs"] + (8 + 1) * Hd + (32 + 4 + 1) * Hp,
         # counting sort of the pooled hits (nothing to do when every hit was direct)
         "scan": (B + 1024 * D + (16 + 4) * Vr + 32 * slots + (4 + REC) * Hp + 1024 * D) if Hp else 0,
-        # replay of the pooled hits + emission of the 64-bit grid: flag map, the dirty bricks (2 KiB each) read, the
-        # occupied 32-byte lane groups zeroed (counted as the whole brick: an upper bound), records written
-        "resolve": (16 * Vr + REC * Hp if Hp else 0) + ((B + 2 * 2048 * D + 16 * Vr) if direct else 16 * Vr),
+        # replay of the pooled hits + emission of the 64-bit grid: flag map, the dirty bricks (2 KiB each) read, the occupied
+        # 32-byte lane groups zeroed (at most one per voxel), records written
+        "resolve": (16 * Vr + REC * Hp if Hp else 0) + ((B + 2048 * D + 32 * Vr + 16 * Vr) if direct else 16 * Vr),
     }
     stage_kernels = {
         "bounds": ["k_init", "k_bounds", "k_setup"],

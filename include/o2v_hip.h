@@ -83,6 +83,7 @@ typedef struct {
     uint64_t dirty_bricks;/* bricks that received at least one hit */
     uint64_t pool_slots;  /* hit-pool slots reserved (hits + chunk slack) */
     uint64_t direct_hits; /* hits that went straight into the 64-bit max grid (MAX strategy, unsplit triangles) */
+    uint64_t jobs;        /* candidates that passed the plane cull and the separating-axis pre-test: voxel jobs of the clip loop */
 } o2v_hip_stats;
 
 int o2v_hip_device_count(void);

@@ -508,6 +508,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             }
             __syncthreads();  // (workgroup scope: the records written above are visible to every wavefront of the workgroup)
             const uint32_t n_heavy = s_nheavy, n_surv = n_heavy + s_nlight;
+            if (threadIdx.x == 0 && n_surv) atomicAdd(&c->n_jobs, (unsigned long long) n_surv);
 
             O2V_LAP(2);
             // ---- phase 2: persistent lanes ------------------------------------------------------------------

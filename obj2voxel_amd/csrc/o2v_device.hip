@@ -226,7 +226,9 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
     O2V_STAGE("k_init");
     if (!p.bounds_known) {
-        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
+        // one workgroup per CU: every workgroup ends with six atomics on the same six words, which serialise (1024
+        // workgroups: 43 us for 31 MB, 256: 24 us)
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
         O2V_STAGE("k_bounds");
     }
@@ -438,7 +440,7 @@ int ctx_finish_triangles(o2v_hip_ctx *ctx, bool any_textured, const TriHints *hi
     }
     else if (count) {
         hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
-        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count * 9 / 12 + kBlock) / kBlock)),
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (count * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
         hipLaunchKernelGGL(k_tri_extent, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, count, &ctx->d_ctr->pad2);
@@ -1075,7 +1077,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
     if (!p.bounds_known) {
         if (n_range)
-            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (n_range * 9 / 12 + kBlock) / kBlock)),
+            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_range * 9 / 12 + kBlock) / kBlock)),
                                dim3(kBlock), 0, s, ctx->d_verts + tri_begin * 9, n_range * 9, ctx->d_ctr);
         O2V_STAGE("k_bounds");
         if (comm) {

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
 // (weights are positive floats: their bit patterns order like the values).  k_voxelize feeds that cell directly for
 // unsplit triangles, the resolve kernels add the summed-up subdivided ones, and this kernel turns every non-zero
 // cell of the dirty bricks into its (x, y, z, argb) record and zeroes it again (moveUvBufferIntoVoxels + the pack of
-// obj2voxel.cpp:279-297).  Records are staged in LDS so that a workgroup reserves output space once per ~2048 voxels.
+// obj2voxel.cpp:279-297).  Records are staged in LDS so that a workgroup reserves output space once per ~1024 voxels.
 // Textured MAX: every record {cell, key, argb} - left by k_voxelize for direct hits (in the hit pool) and by the replay
 // tiers for the cells they resolved - is compared with the final maximum of its cell; the one that won replaces it by
 // its colour.  Keys are unique per cell, so exactly one record matches and nothing races.
@@ -629,7 +629,8 @@ __global__ __launch_bounds__(kBlock) void k_pick(const HitRec *__restrict__ pool
 
 constexpr uint32_t kEmitBricksPerWave = 2;
 constexpr uint32_t kEmitBricksPerRound = (kBlock / 64) * kEmitBricksPerWave;
-constexpr uint32_t kEmitFlushAt = 2048;
+constexpr uint32_t kEmitFlushAt = 1024;  // 48 KiB of staging: three workgroups per CU keep enough 2 KiB brick loads in flight
+                                         // (2048 / two workgroups: 0.15 ms on the bench mesh, this: 0.12; 512 / four: 0.16)
 constexpr uint32_t kEmitCap = kEmitFlushAt + kEmitBricksPerRound * kBrickCells;
 
 __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict__ dirty_list, Counters *c, Materials m, uint4 *out,

@@ -370,7 +370,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         }
         if (run_emit) {
             // every voxel's winner is in the 64-bit grid now (k_voxelize: unsplit triangles, resolve: the rest)
-            hipLaunchKernelGGL(k_emit_max, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
+            hipLaunchKernelGGL(k_emit_max, dim3((uint32_t) ctx->num_cus * 3u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
                                ctx->d_out, p);
             O2V_STAGE("k_emit_max");
         }

@@ -131,10 +131,17 @@ __device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area
 
 // Pending sibling pieces of the depth-first clip walk: a stack (last in, first out - the sibling pushed last belongs to
 // the deepest level and is next in depth-first order).  Under DISCARD a cut keeps <= 2 pieces, so at most one sibling per
-// level 1..5 is pending.  The first kStackRegs entries live in registers and are accessed with value selects on the stack
-// pointer (every access uses a compile-time slot, so they never leave the VGPR file); deeper entries - 1 % of the pushes
-// on the bench mesh - go to a small per-lane overflow array (scratch memory).
-constexpr uint32_t kStackRegs = 3, kStackOverflow = 2;
+// level 1..5 is pending.  The first entries live in registers and are accessed with value selects on the stack pointer
+// (every access uses a compile-time slot, so they never leave the VGPR file): three without uv (deeper entries are 1 % of
+// the pushes on the bench mesh), two with uv, whose pieces are 15 floats (9 % of the pushes go deeper; measured faster on
+// configs[1] and configs[3] than a third slot and its spills).  Deeper entries go to a small per-lane overflow array
+// (scratch memory).
+#ifndef O2V_STACK_REGS_UV
+#define O2V_STACK_REGS_UV 2
+#endif
+template <bool UV>
+__device__ __forceinline__ constexpr uint32_t stack_regs() { return UV ? O2V_STACK_REGS_UV : 3u; }
+constexpr uint32_t kStackLevels = 5;
 template <bool UV>
 struct PieceStack {
     Piece<UV> s0, s1, s2;
@@ -161,12 +168,13 @@ __device__ __forceinline__ void stack_store(PieceStack<UV> &st, uint32_t slot, c
 {
     st.s0 = sel_piece<UV>(slot == 0, pc, st.s0);
     st.s1 = sel_piece<UV>(slot == 1, pc, st.s1);
-    st.s2 = sel_piece<UV>(slot == 2, pc, st.s2);
+    if (stack_regs<UV>() > 2u) st.s2 = sel_piece<UV>(slot == 2, pc, st.s2);
 }
 template <bool UV>
 __device__ __forceinline__ Piece<UV> stack_load(const PieceStack<UV> &st, uint32_t slot)
 {
-    return sel_piece<UV>(slot == 0, st.s0, sel_piece<UV>(slot == 1, st.s1, st.s2));
+    return stack_regs<UV>() > 2u ? sel_piece<UV>(slot == 0, st.s0, sel_piece<UV>(slot == 1, st.s1, st.s2))
+                                 : sel_piece<UV>(slot == 0, st.s0, st.s1);
 }
 
 // Conservative triangle / voxel overlap test (separating axes: the triangle's plane and the nine edge x axis
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             // ---- phase 2: persistent lanes ------------------------------------------------------------------
             Piece<UV> cur{}, sec{};
             PieceStack<UV> stack{};
-            Piece<UV> overflow[kStackOverflow];
+            Piece<UV> overflow[kStackLevels - stack_regs<UV>()];
             uint32_t sp = 0, my_k = 0;  // sp: pending siblings of this lane's job; my_k: its tile slot
             uint32_t cf = 0;     // planes the current piece does not pass whole (bit = level), see piece_masks
             uint32_t pmask = 0;  // the same for the pending siblings: 6 bits per stack entry
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                     if (sp) {
                         sp -= 1u;
                         cur = stack_load<UV>(stack, sp);
-                        if (sp >= kStackRegs) cur = overflow[sp - kStackRegs];
+                        if (sp >= stack_regs<UV>()) cur = overflow[sp - stack_regs<UV>()];
                         const uint32_t sh = __umul24(sp, 6u);  // 6 bits per entry
                         cf = (pmask >> sh) & 63u;
                         pmask &= ~(63u << sh);
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                             if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v);
                             O2V_EV(12, s_push);
                             stack_store<UV>(stack, s_push ? sp : 7u, sec);  // 7: no slot, nothing stored
-                            if (s_push && sp >= kStackRegs) overflow[sp - kStackRegs] = sec;
+                            if (s_push && sp >= stack_regs<UV>()) overflow[sp - stack_regs<UV>()] = sec;
                             pmask |= s_push ? s_fail << __umul24(sp, 6u) : 0u;
                             sp += s_push ? 1u : 0u;
                             cur = sel_piece<UV>(s_takes_over, sec, cur);

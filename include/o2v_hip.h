@@ -59,7 +59,8 @@ typedef struct {
     float expand_ms;     /* K1  transform, classify, exact subdivision into leaves and tiles */
     float voxelize_ms;   /* K2  AABB walk + plane cull + SAT pre-test + six-plane clip + hit append (dense-grid atomics) */
     float scan_ms;       /* K5  dirty-brick scan, occupied-cell compaction + offsets, hit scatter, brick reset (on the direct
-                            MAX path: the host's look at the counters, plus these kernels only if any hit was pooled) */
+                            MAX path: the flag scan of the 64-bit grid, plus these kernels only if the mesh has subdivided
+                            triangles) */
     float resolve_ms;    /* K3  per-cell ordered replay (MAX / BLEND), colour lookup, ARGB pack; emission of the max grid */
     float total_ms;      /* first event to last event */
     uint32_t passes;     /* 1, or more if a device buffer had to grow and the pipeline was re-run */

@@ -278,7 +278,10 @@ __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float 
     out = small ? (o & planes) : 0u;
 }
 
-constexpr uint32_t kFlushAt = 48;             // parked hits per wavefront that trigger the append section
+#ifndef O2V_FLUSH_AT
+#define O2V_FLUSH_AT 48
+#endif
+constexpr uint32_t kFlushAt = O2V_FLUSH_AT;             // parked hits per wavefront that trigger the append section
 constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
 constexpr uint32_t kQueueCap = 16384;         // job queue records (= candidate voxels at most) per sub-batch and workgroup
 #ifndef O2V_BATCHES_PER_BLOCK
@@ -292,12 +295,13 @@ constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf
 
 // K2.  Persistent workgroups pull batches of tiles.  Per batch:
 //   phase 1  every candidate voxel of the tiles: decode, plane-distance cull (voxelization.cpp:451-458), SAT
-//            pre-test; survivors are queued in LDS (tile slot + index in tile)
-//   phase 2  persistent lanes pop survivors and run computeTrianglesUvInVoxel (voxelization.cpp:383-424) as a
+//            pre-test; survivors become 8-byte job records (position, tile slot, planes the leaf straddles) in the
+//            workgroup's queue in global memory, jobs that straddle many planes (the long ones) first
+//   phase 2  persistent lanes fetch their next job one ahead and run computeTrianglesUvInVoxel (voxelization.cpp:383-424) as a
 //            depth-first walk of the split tree: the reference clips level by level with two 64-entry buffers;
 //            visiting the first emitted piece first reproduces its buffer order, so the running mean of
 //            :414-420 accumulates in the identical sequence.  Under DISCARD every split keeps <= 2 pieces, so at
-//            most one sibling per level 1..5 is pending (register stack).  Every piece carries the set of planes it
+//            most one sibling per level 1..5 is pending (register stack with a scratch overflow).  Every piece carries the set of planes it
 //            does not pass whole (piece_masks); per iteration a lane classifies its piece against the first of them
 //            and cuts it, and the kept pieces are judged at once from their bounding boxes: final (accumulated),
 //            beyond a later plane (dropped with its whole subtree), or to be cut again.  So lanes spend their

@@ -23,7 +23,8 @@
 //                              MAX / BLEND, then packs (x, y, z, argb) (obj2voxel.cpp:279-297);
 //       k_pick / k_emit_max    direct MAX path: winner colours of textured meshes; the 64-bit max grid -> records
 //   plan k_zhist               o2v_hip_plan_slabs: predicted hits per z layer -> work-balanced slabs for N GPUs
-// With the direct MAX path the host looks at the counters once after K2 and launches only the stages that have work.
+// With the direct MAX path K1's counters reach the host while K2 runs, and only the stages that have work are enqueued
+// behind it.  N > 1 GPUs: o2v_hip_voxelize_sharded (bounds / work-histogram passes sharded over the ranks, RCCL).
 //
 // Compile with -ffp-contract=off (see o2v_math.h).
 #include "o2v_math.h"

@@ -103,7 +103,16 @@ def main():
             # the library's own RCCL communicator, on its own stream: rank 0 makes the id, torch ships it
             box = [hip.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            comm = hip.Comm.rccl(box[0], rank, n, dev_index)
+            try:
+                comm = hip.Comm.rccl(box[0], rank, n, dev_index)
+            except Exception as e:   # noqa: BLE001 - any rank without a communicator moves every rank to the fallback
+                print(f"bench: rank {rank}: RCCL communicator failed ({e}); using torch.distributed collectives", file=sys.stderr)
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = hip.Comm.torch_distributed(dist)
         else:
             comm = hip.Comm.torch_distributed(dist)
 

@@ -231,19 +231,22 @@ __device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, float cx, f
 //   fail  planes the piece does not pass whole.  A piece whose vertices all satisfy v >= plane (lo planes) or v < plane
 //         (hi planes) is the loSum == 0 / loSum == 3 case of splitTriangle (voxelization.cpp:194-205) and is handed on
 //         unchanged, so only the `fail` planes need the classification.
-//   out   planes the piece lies entirely beyond, by more than kOutMargin.  Every sub-piece of it then lies beyond that
-//         plane too - a vertex of a sub-piece is (1-t)*a + t*b of two vertices of its parent, off their range by a few
-//         ulp of the coordinates per generation: < 5 * 2 * 2^-10 below 8192, far inside the margin and outside the 2^-16
-//         planarity band - and is discarded there at the latest, contributing nothing before.  The piece is dropped at once.
+//   out   planes the piece lies entirely beyond, by more than the leaf's margin.  Every sub-piece of it then lies beyond
+//         that plane too - a vertex of a sub-piece is (1-t)*a + t*b of two vertices of its parent with t in [0, 1]
+//         (float subtraction is monotonic, so |a - plane| <= |a - b| survives rounding), off their range by the rounding
+//         of s = 1 - t, two products and a sum: < 2 * 2^-23 m per generation, < 1.2e-6 m over the five possible
+//         generations, for a leaf whose largest |coordinate| is m - and is discarded there at the latest, contributing
+//         nothing before.  The margin (out_margin) is eight times that plus twice the 2^-16 planarity band.  The piece is
+//         dropped at once.
 // Both are only computed for jobs whose leaf has all |coordinates| < 8192 (`small`; false for NaN too); other jobs get
 // fail = planes, out = 0, i.e. every plane is classified, which is always exact.
-constexpr float kOutMargin = 0.0625f;
 constexpr float kSmallCoord = 8192.0f;
 
-// (once per staged leaf: q = its nine vertex coordinates)
-__device__ __forceinline__ bool leaf_is_small(const uint32_t *q)
+// (once per staged leaf: q = its nine vertex coordinates; m = the largest |coordinate|)
+__device__ __forceinline__ bool leaf_is_small(const uint32_t *q, float &m)
 {
-    float m = 0.f, sum = 0.f;
+    float sum = 0.f;
+    m = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const float f = __uint_as_float(q[i]);
@@ -253,9 +256,10 @@ __device__ __forceinline__ bool leaf_is_small(const uint32_t *q)
     // sum == sum is false if any coordinate is NaN (fmaxf ignores NaN operands) or inf - inf occurred
     return sum == sum && m < kSmallCoord;
 }
+__device__ __forceinline__ float out_margin(float m) { return 3.0517578125e-5f + 1e-5f * m; }
 
 template <bool UV>
-__device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float fy, float fz, bool small, uint32_t planes,
+__device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float fy, float fz, bool small, float margin, uint32_t planes,
                                             uint32_t &fail, uint32_t &out)
 {
     // all coordinates are finite here (small), so min / max need no NaN rule
@@ -268,12 +272,12 @@ __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float 
     f |= (xx < fx + 1.0f) ? 0u : 8u;
     f |= (xy < fy + 1.0f) ? 0u : 16u;
     f |= (xz < fz + 1.0f) ? 0u : 32u;
-    o |= (xx < fx - kOutMargin) ? 1u : 0u;
-    o |= (xy < fy - kOutMargin) ? 2u : 0u;
-    o |= (xz < fz - kOutMargin) ? 4u : 0u;
-    o |= (nx > fx + (1.0f + kOutMargin)) ? 8u : 0u;
-    o |= (ny > fy + (1.0f + kOutMargin)) ? 16u : 0u;
-    o |= (nz > fz + (1.0f + kOutMargin)) ? 32u : 0u;
+    o |= (xx < fx - margin) ? 1u : 0u;
+    o |= (xy < fy - margin) ? 2u : 0u;
+    o |= (xz < fz - margin) ? 4u : 0u;
+    o |= (nx > fx + (1.0f + margin)) ? 8u : 0u;
+    o |= (ny > fy + (1.0f + margin)) ? 16u : 0u;
+    o |= (nz > fz + (1.0f + margin)) ? 32u : 0u;
     fail = small ? (f & planes) : planes;
     out = small ? (o & planes) : 0u;
 }
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
     __shared__ uint32_t s_tend;
     __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-candidate chunk's first candidate
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
+    __shared__ float s_margin[kTilesPerBatch];  // out_margin of the tile's leaf (piece_masks)
     __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct;
     // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
     // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
@@ -398,7 +403,10 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             const uint32_t rem = dx * dy * dz - s_tstart[threadIdx.x];
             my_count = rem < kTileSize ? rem : kTileSize;
             // bit 31: every coordinate of the leaf is finite and below kSmallCoord (see piece_masks)
-            s_tcount[threadIdx.x] = my_count | (leaf_is_small(lf) ? 0x80000000u : 0u);
+            float m;
+            const bool is_small = leaf_is_small(lf, m);
+            s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u);
+            s_margin[threadIdx.x] = out_margin(m);
             s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
         }
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                         leaf.b = v1;
                         leaf.c = v2;
                         uint32_t cf0, out_unused;
-                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 63u, cf0, out_unused);
+                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused);
                         rec = make_uint2(qx | (qy << 16), qz | (k << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u));
                         heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
                     }
@@ -533,15 +541,32 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             bool active = false, has_job = false, small = false;
             float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
             float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
+            float margin = 0.f;                  // out_margin of the job's leaf
             uint32_t pos_xy = 0, pos_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
             // Every lane holds its next job one ahead: the record is requested from the queue (an LDS ticket, then a load
             // that L2 answers) when the lane starts a job and is only looked at when that job is done.
-            uint2 next_rec = make_uint2(0u, 0u);
+            // The load is issued by hand (global_load into the registers that carry the record around the loop) and waited
+            // for by hand where the record is consumed: written as plain C++, the compiler loads into a temporary and
+            // copies it into the loop-carried registers at once, i.e. waits for L2 in every iteration that fetches a job
+            // (measured: a quarter of the wavefronts' time in s_waitcnt).  Between the two asm statements nothing reads
+            // next_rec, and the compiler's own vmcnt waits only get stricter by one more load in flight.
+            unsigned long long next_rec = 0ull;
             bool next_valid = false;
             auto take_job = [&]() {
                 const uint32_t q = atomicAdd(&s_next, 1u);
                 next_valid = q < n_surv;
-                if (next_valid) next_rec = jobq[q < n_heavy ? q : kQueueCap - 1u - (q - n_heavy)];
+                if (next_valid) {
+                    const uint2 *src = jobq + (q < n_heavy ? q : kQueueCap - 1u - (q - n_heavy));
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(next_rec) : "v"(src) : "memory");
+                }
+            };
+            auto job_record = [&]() {
+                uint2 r;
+                asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
+                             : "=&v"(r.x), "=&v"(r.y)
+                             : "v"((uint32_t) next_rec), "v"((uint32_t) (next_rec >> 32))
+                             : "memory");
+                return r;
             };
             take_job();
             // parked result of this lane's last finished hit
@@ -646,7 +671,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                     }
                     else if (next_valid) {
                         // the next job was fetched while this lane worked on the last one (take_job below)
-                        const uint2 rec = next_rec;
+                        const uint2 rec = job_record();
                         my_k = (rec.y >> 16) & 255u;
                         const uint32_t *lf = &s_leaf[__umul24(my_k, kLeafStride)];
                         pos_xy = rec.x;
@@ -665,6 +690,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                             cur.tc = {__uint_as_float(lf[16]), __uint_as_float(lf[17])};
                         }
                         area = __uint_as_float(lf[23]);
+                        margin = s_margin[my_k];
                         w = 0.f;
                         u = 0.f;
                         v = 0.f;
@@ -718,8 +744,8 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                             // on cuts only.
                             const uint32_t later = 63u & ~((2u << level) - 1u);
                             uint32_t c_fail, c_out, s_fail, s_out;
-                            piece_masks<UV>(cur, fx, fy, fz, small, later, c_fail, c_out);
-                            piece_masks<UV>(sec, fx, fy, fz, small, later, s_fail, s_out);
+                            piece_masks<UV>(cur, fx, fy, fz, small, margin, later, c_fail, c_out);
+                            piece_masks<UV>(sec, fx, fy, fz, small, margin, later, s_fail, s_out);
                             const bool has_sec = n == 2u;
                             const bool c_done = c_fail == 0u, c_drop = c_out != 0u;
                             const bool s_done = has_sec && s_fail == 0u, s_drop = has_sec && s_out != 0u;

@@ -260,9 +260,11 @@ class Comm:
     @classmethod
     def torch_distributed(cls, dist):
         """Host-memory collectives over an initialised torch.distributed group (gloo): for the CPU-side tests of the
-        N > 1 path and for ranks that share one GPU, where RCCL cannot be used."""
+        N > 1 path and for ranks that share one GPU, where RCCL cannot be used.  With the nccl backend the host
+        buffers travel through device tensors (bench.py's fallback if the library's own communicator cannot be made)."""
         import torch
         rank, world = dist.get_rank(), dist.get_world_size()
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
 
         def array(ptr, n, ctype):
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
@@ -270,24 +272,24 @@ class Comm:
         def allreduce(op, ctype):
             def fn(user, buf, n):
                 a = array(buf, n, ctype)
-                t = torch.from_numpy(a.astype(np.int64))  # gloo has no unsigned reductions; the values fit int64
+                t = torch.from_numpy(a.astype(np.int64)).to(dev)  # gloo has no unsigned reductions; the values fit int64
                 dist.all_reduce(t, op=op)
-                a[:] = t.numpy().astype(a.dtype)
+                a[:] = t.cpu().numpy().astype(a.dtype)
                 return 0
             return fn
 
         def allgather(user, buf, bytes_per_rank):
             a = array(buf, bytes_per_rank * world, C.c_uint8)
-            parts = [torch.empty(bytes_per_rank, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(parts, torch.from_numpy(a[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy()))
-            a[:] = torch.cat(parts).numpy()
+            parts = [torch.empty(bytes_per_rank, dtype=torch.uint8, device=dev) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(a[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy()).to(dev))
+            a[:] = torch.cat(parts).cpu().numpy()
             return 0
 
         def broadcast(user, buf, n, root):
             a = array(buf, n, C.c_uint8)
-            t = torch.from_numpy(a.copy())
+            t = torch.from_numpy(a.copy()).to(dev)
             dist.broadcast(t, src=root)
-            a[:] = t.numpy()
+            a[:] = t.cpu().numpy()
             return 0
 
         F = dict(_Callbacks._fields_)

@@ -44,6 +44,18 @@ __host__ __device__ constexpr uint32_t classify_flags(uint32_t idx)
     return 2u | (r << kClsRotShift) | (iso_lo ? kClsFlagLo : 0u);
 }
 
+// Number of pieces splitTriangle<DISCARD_*> keeps (voxelization.cpp:190-232, 236-331) for the same index; keep_lo selects
+// DISCARD_HI: a whole triangle is kept or not, the one-planar case keeps one of its two pieces, the regular case keeps
+// the isolated vertex's triangle (1) or the quad on the other side, emitted as two triangles (2).
+__host__ __device__ constexpr uint32_t classify_kept(uint32_t idx, bool keep_lo)
+{
+    const uint32_t cls = classify_flags(idx);
+    const uint32_t mode = cls & kClsModeMask;
+    if (mode == 0u) return ((cls & kClsSideLo) != 0u) == keep_lo ? 1u : 0u;
+    if (mode == 1u) return 1u;
+    return ((cls & kClsFlagLo) != 0u) == keep_lo ? 1u : 2u;
+}
+
 // SplittingValues, voxelization.cpp:121-131: the six flags of a piece against an axis plane
 __device__ __forceinline__ uint32_t classify_index(float c0, float c1, float c2, float plane)
 {
@@ -238,8 +250,9 @@ __device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, float cx, f
 //         generations, for a leaf whose largest |coordinate| is m - and is discarded there at the latest, contributing
 //         nothing before.  The margin (out_margin) is eight times that plus twice the 2^-16 planarity band.  The piece is
 //         dropped at once.
-// Both are only computed for jobs whose leaf has all |coordinates| < 8192 (`small`; false for NaN too); other jobs get
-// fail = planes, out = 0, i.e. every plane is classified, which is always exact.
+//   near  planes the piece does not pass whole by more than the same margin (a superset of fail), see single_plane.
+// All are only computed for jobs whose leaf has all |coordinates| < 8192 (`small`; false for NaN too); other jobs get
+// fail = near = planes, out = 0, i.e. every plane is classified, which is always exact.
 constexpr float kSmallCoord = 8192.0f;
 
 // (once per staged leaf: q = its nine vertex coordinates; m = the largest |coordinate|)
@@ -260,7 +273,7 @@ __device__ __forceinline__ float out_margin(float m) { return 3.0517578125e-5f +
 
 template <bool UV>
 __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float fy, float fz, bool small, float margin, uint32_t planes,
-                                            uint32_t &fail, uint32_t &out)
+                                            uint32_t &fail, uint32_t &out, uint32_t &near)
 {
     // all coordinates are finite here (small), so min / max need no NaN rule
     const float nx = fminf(fminf(q.a.x, q.b.x), q.c.x), ny = fminf(fminf(q.a.y, q.b.y), q.c.y), nz = fminf(fminf(q.a.z, q.b.z), q.c.z);
@@ -278,8 +291,31 @@ __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float 
     o |= (nx > fx + (1.0f + margin)) ? 8u : 0u;
     o |= (ny > fy + (1.0f + margin)) ? 16u : 0u;
     o |= (nz > fz + (1.0f + margin)) ? 32u : 0u;
+    uint32_t r = 0;
+    r |= (nx >= fx + margin) ? 0u : 1u;
+    r |= (ny >= fy + margin) ? 0u : 2u;
+    r |= (nz >= fz + margin) ? 0u : 4u;
+    r |= (xx < fx + (1.0f - margin)) ? 0u : 8u;
+    r |= (xy < fy + (1.0f - margin)) ? 0u : 16u;
+    r |= (xz < fz + (1.0f - margin)) ? 0u : 32u;
     fail = small ? (f & planes) : planes;
     out = small ? (o & planes) : 0u;
+    near = small ? (r & planes) : planes;
+}
+
+// A piece that fails exactly one of the planes ahead and passes the others by more than the margin (fail == near, one
+// bit): the pieces its cut at that plane keeps pass every later plane whole (same bound as for `out`), i.e. they are final.
+// Without uv only their number matters (each adds the leaf's area, voxelization.cpp:414-420), and the number follows from
+// the classification alone - no intersection points, no further iteration.
+__device__ __forceinline__ bool single_plane(uint32_t fail, uint32_t near) { return fail != 0u && (fail & (fail - 1u)) == 0u && near == fail; }
+template <bool UV>
+__device__ __forceinline__ uint32_t single_plane_kept(const Piece<UV> &q, uint32_t fail, float fx, float fy, float fz, const uint8_t *s_kept)
+{
+    const uint32_t level = (uint32_t) __ffs((int) fail) - 1u;
+    const bool keep_lo = level >= 3u;
+    const uint32_t axis = keep_lo ? level - 3u : level;
+    const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
+    return s_kept[classify_index(comp(q.a, axis), comp(q.b, axis), comp(q.c, axis), plane) | (keep_lo ? 64u : 0u)];
 }
 
 #ifndef O2V_FLUSH_AT
@@ -341,7 +377,8 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
     // voxel (the long ones) are filed from the front, the others from the back, and the queue is served front to back:
     // longest jobs first keeps the end of a sub-batch, when lanes run out of work, short.
     uint2 *jobq = jobq_all + (size_t) blockIdx.x * kQueueCap;
-    __shared__ uint8_t s_cls[64];  // classify_flags
+    __shared__ uint8_t s_cls[64];    // classify_flags
+    __shared__ uint8_t s_kept[128];  // classify_kept: index | keep_lo << 6
 
     if (expand_overflowed(c, p)) return;
     const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
@@ -375,6 +412,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
         s_direct = 0;
     }
     if (threadIdx.x < 64u) s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
+    if (threadIdx.x < 128u) s_kept[threadIdx.x] = (uint8_t) classify_kept(threadIdx.x & 63u, threadIdx.x >= 64u);
 
     for (;;) {
         __syncthreads();
@@ -504,8 +542,8 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                         leaf.a = v0;
                         leaf.b = v1;
                         leaf.c = v2;
-                        uint32_t cf0, out_unused;
-                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused);
+                        uint32_t cf0, out_unused, near_unused;
+                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused, near_unused);
                         rec = make_uint2(qx | (qy << 16), qz | (k << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u));
                         heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
                     }
@@ -743,16 +781,30 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                             // its sub-pieces with it (dropped now), anything else goes on.  So a lane spends its iterations
                             // on cuts only.
                             const uint32_t later = 63u & ~((2u << level) - 1u);
-                            uint32_t c_fail, c_out, s_fail, s_out;
-                            piece_masks<UV>(cur, fx, fy, fz, small, margin, later, c_fail, c_out);
-                            piece_masks<UV>(sec, fx, fy, fz, small, margin, later, s_fail, s_out);
+                            uint32_t c_fail, c_out, c_near, s_fail, s_out, s_near;
+                            piece_masks<UV>(cur, fx, fy, fz, small, margin, later, c_fail, c_out, c_near);
+                            piece_masks<UV>(sec, fx, fy, fz, small, margin, later, s_fail, s_out, s_near);
                             const bool has_sec = n == 2u;
-                            const bool c_done = c_fail == 0u, c_drop = c_out != 0u;
-                            const bool s_done = has_sec && s_fail == 0u, s_drop = has_sec && s_out != 0u;
+                            bool c_done = c_fail == 0u, s_done = has_sec && s_fail == 0u;
+                            const bool c_drop = c_out != 0u, s_drop = has_sec && s_out != 0u;
+                            uint32_t c_kept = c_done ? 1u : 0u, s_kept_n = s_done ? 1u : 0u;  // (without uv) final pieces they stand for
+                            if (!UV) {
+                                // a kept piece with one plane left is settled here and now: see single_plane
+                                const bool c_single = !c_drop && single_plane(c_fail, c_near);
+                                const bool s_single = has_sec && !s_drop && single_plane(s_fail, s_near);
+                                O2V_EV(9, c_single);
+                                O2V_EV(11, s_single);
+                                if (c_single) {
+                                    c_kept = single_plane_kept<UV>(cur, c_fail, fx, fy, fz, s_kept);
+                                    c_done = true;
+                                }
+                                if (s_single) {
+                                    s_kept_n = single_plane_kept<UV>(sec, s_fail, fx, fy, fz, s_kept);
+                                    s_done = true;
+                                }
+                            }
                             O2V_EV(8, c_done);
-                            O2V_EV(9, !c_done && c_drop);
                             O2V_EV(10, s_done);
-                            O2V_EV(11, has_sec && !s_done && s_drop);
                             // (value selects, not control flow: see sel_piece)
                             const bool c_over = c_done || c_drop;            // the first piece's subtree is finished
                             const bool s_live = has_sec && !s_done && !s_drop;  // the second piece needs more cuts
@@ -762,8 +814,18 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                             const bool s_acc_now = s_done && (!UV || c_over);
                             const bool s_push = has_sec && !s_drop && !c_over && !s_acc_now;
                             const bool s_takes_over = c_over && s_live;  // next in depth-first order
-                            if (c_done) accumulate_piece<UV>(cur, area, w, u, v);
-                            if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v);
+                            if (UV) {
+                                if (c_done) accumulate_piece<UV>(cur, area, w, u, v);
+                                if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v);
+                            }
+                            else {
+                                // w += area once per final piece (util.hpp:160-165 with equal addends: the order is immaterial)
+                                const uint32_t kept = c_kept + s_kept_n;
+                                w = kept >= 1u ? w + area : w;
+                                w = kept >= 2u ? w + area : w;
+                                w = kept >= 3u ? w + area : w;
+                                w = kept >= 4u ? w + area : w;
+                            }
                             O2V_EV(12, s_push);
                             stack_store<UV>(stack, s_push ? sp : 7u, sec);  // 7: no slot, nothing stored
                             if (s_push && sp >= stack_regs<UV>()) overflow[sp - stack_regs<UV>()] = sec;

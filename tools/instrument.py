@@ -11,8 +11,8 @@ import numpy as np
 from obj2voxel_amd import hip, meshes
 
 NAMES = ["wave_iterations", "lane_events", "acc_passes_all(event)", "whole_keep(event)", "iterations with <= 16 active lanes",
-         "whole_discard(event)", "iterations with <= 32 active lanes", "cut(event)", "cut: first piece final", "cut: first piece dropped",
-         "cut: second piece final", "cut: second piece dropped", "cycles: staging + barriers (sum over waves)", "cycles: phase 2 loop",
+         "whole_discard(event)", "iterations with <= 32 active lanes", "cut(event)", "cut: first piece final (incl. settled)", "cut: first piece settled by its single plane",
+         "cut: second piece final (incl. settled)", "cut: second piece settled by its single plane", "cycles: staging + barriers (sum over waves)", "cycles: phase 2 loop",
          "cycles: phase 1", "cycles: whole kernel"]
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 467
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

@@ -131,7 +131,7 @@ struct Params {
     uint64_t n_tris;
     uint32_t S;            // sample resolution = resolution * supersampling
     uint32_t G;            // output resolution
-    uint32_t NBx, NBy;     // bricks per grid row / per z layer (brick = 16 x 4 x 4 cells, stored contiguously)
+    uint32_t NBx, NBy;     // bricks per grid row / per z layer (brick = 4 x 8 x 8 cells, stored contiguously)
     uint32_t ss_shift;     // 0, or 1 for 2x supersampling
     uint32_t zs0, zs1;     // slab in sample space
     uint32_t zo0;          // slab begin in output space
@@ -189,15 +189,36 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float(b);
 }
 
-// Dense grid layout: bricks of 16 (x) x 4 (y) x 4 (z) cells, each brick 256 consecutive u32 (1 KiB), bricks ordered
-// x fastest.  A surface marks ~12 cells' worth of brick volume per unit area in this shape (the same as 8^3 bricks)
-// while every brick row is a full 64-byte line; one wavefront reads a brick with a single 16-byte load per lane.
-constexpr uint32_t kBrickX = 16, kBrickY = 4, kBrickZ = 4, kBrickCells = 256;
+// Dense grid layout: bricks of 4 (x) x 8 (y) x 8 (z) cells, each brick 256 consecutive u32 (1 KiB; 2 KiB in the 64-bit
+// grid), bricks ordered x fastest; one wavefront reads a brick with a single 16-byte load per lane.  A surface of area A
+// meets about A/2 * (1/(sy sz) + 1/(sx sz) + 1/(sx sy)) bricks of extents (sx, sy, sz), so the nearly cubic shape means
+// the fewest dirty bricks for the scan / emission passes to read: measured against 16 x 4 x 4 (round 1) -15 % in
+// k_emit_max on the bench mesh, -25 % on the box room, and 8 x 8 x 4 / 8 x 4 x 8 in between.
+#ifndef O2V_BRICK_XS
+#define O2V_BRICK_XS 2
+#define O2V_BRICK_YS 3
+#define O2V_BRICK_ZS 3
+#endif
+constexpr uint32_t kBrickXs = O2V_BRICK_XS, kBrickYs = O2V_BRICK_YS, kBrickZs = O2V_BRICK_ZS;  // log2 of the brick's extents
+constexpr uint32_t kBrickX = 1u << kBrickXs, kBrickY = 1u << kBrickYs, kBrickZ = 1u << kBrickZs, kBrickCells = 256;
+static_assert(kBrickXs + kBrickYs + kBrickZs == 8, "a brick is 256 cells");
 
 __device__ __forceinline__ uint64_t cell_index(uint32_t ox, uint32_t oy, uint32_t oz_rel, const Params &p, uint32_t &brick)
 {
-    brick = ((oz_rel >> 2) * p.NBy + (oy >> 2)) * p.NBx + (ox >> 4);
-    return (uint64_t) brick * kBrickCells + (((oz_rel & 3u) * 4u + (oy & 3u)) * 16u + (ox & 15u));
+    brick = ((oz_rel >> kBrickZs) * p.NBy + (oy >> kBrickYs)) * p.NBx + (ox >> kBrickXs);
+    return (uint64_t) brick * kBrickCells +
+           ((((oz_rel & (kBrickZ - 1u)) << kBrickYs) + (oy & (kBrickY - 1u))) << kBrickXs) + (ox & (kBrickX - 1u));
+}
+// position of a brick's cell `local` in a grid whose bricks are numbered x fastest (z relative to the slab)
+__device__ __forceinline__ void cell_position(uint32_t brick, uint32_t local, const Params &p, uint32_t &x, uint32_t &y, uint32_t &z_rel)
+{
+    const uint32_t row = brick / p.NBx;
+    const uint32_t bx = brick - row * p.NBx;
+    const uint32_t bz = row / p.NBy;
+    const uint32_t by = row - bz * p.NBy;
+    x = (bx << kBrickXs) + (local & (kBrickX - 1u));
+    y = (by << kBrickYs) + ((local >> kBrickXs) & (kBrickY - 1u));
+    z_rel = (bz << kBrickZs) + (local >> (kBrickXs + kBrickYs));
 }
 
 // exclusive scan of one uint32 per thread over a 256-thread block; returns the block total in `total`

@@ -55,12 +55,8 @@ struct CellFold {
 __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const Params &p)
 {
     const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
-    const uint32_t brick = (uint32_t) (cell >> 8), local = (uint32_t) cell & 255u;
-    const uint32_t row = brick / p.NBx;
-    const uint32_t bx = brick - row * p.NBx;
-    const uint32_t bz = row / p.NBy;
-    const uint32_t by = row - bz * p.NBy;
-    const uint32_t x = bx * kBrickX + (local & 15u), y = by * kBrickY + ((local >> 4) & 3u), z = bz * kBrickZ + (local >> 6);
+    uint32_t x, y, z;
+    cell_position((uint32_t) (cell >> 8), (uint32_t) cell & 255u, p, x, y, z);
     return make_uint4(x, y, z + p.zo0, argb);
 }
 
@@ -694,8 +690,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
                             argb = pack_argb(cr, cg, cb);
                         }
                         const uint32_t slot = atomicAdd(&s_n, 1u);
-                        s_rec[slot] = make_uint4(bx * kBrickX + (local & 15u), by * kBrickY + ((local >> 4) & 3u),
-                                                 bz * kBrickZ + (local >> 6) + p.zo0, argb);
+                        s_rec[slot] = make_uint4((bx << kBrickXs) + (local & (kBrickX - 1u)),
+                                                 (by << kBrickYs) + ((local >> kBrickXs) & (kBrickY - 1u)),
+                                                 (bz << kBrickZs) + (local >> (kBrickXs + kBrickYs)) + p.zo0, argb);
                     }
                 }
                 // leave the cells clean for the next run

@@ -193,48 +193,83 @@ __device__ __forceinline__ Piece<UV> stack_load(const PieceStack<UV> &st, uint32
 // directions; the three box axes are implied by the AABB walk).  The box is inflated by kSatMargin, far more than
 // the float32 rounding of the clip (<= a few ulp of the coordinate, 5e-4 at 4096) and than its planarity epsilon
 // (2^-16), so every voxel the exact clip can mark is kept: this only removes work, never results.  The test's own
-// rounding is covered too: everything is evaluated in the voxel-centred frame, the plane axis uses the unnormalised
-// normal e0 x e1 with an explicit error bound (for a sliver, whose normal direction is numerically meaningless, the
-// bound exceeds the radius and the plane axis simply never separates), and all comparisons are written so that a
-// NaN rejects nothing.
+// rounding is covered too (below); the plane axis uses the unnormalised normal e0 x e1 with an explicit error bound (for
+// a sliver, whose normal direction is numerically meaningless, the bound exceeds the radius and the plane axis simply
+// never separates), and all comparisons are written so that a NaN rejects nothing.  Not reference arithmetic.
 constexpr float kSatMargin = 0.02f;
 
-// (not reference arithmetic: fused multiply-adds are fine here, the margin covers their rounding as well)
-__device__ __forceinline__ float sat_axis_excess(float ea, float eb, float ua, float ub, float wa, float wb)
-{
-    // axis = (coordinate axis) x edge; p0, p1 = projections of a vertex on the edge and of the vertex opposite it; the
-    // triangle's interval [min, max] of the two misses the box interval [-rad, rad] iff |p0 + p1| - |p0 - p1| > 2 rad
-    const float p0 = __builtin_fmaf(ea, ub, -(eb * ua)), p1 = __builtin_fmaf(ea, wb, -(eb * wa));
-    const float rad2 = (2.0f * (0.5f + kSatMargin)) * (abs_f(ea) + abs_f(eb));
-    return (abs_f(p0 + p1) - abs_f(p0 - p1)) - rad2;  // > 0: this axis separates
-}
-
-// Only for leaves whose coordinates are all finite (`small`): with a NaN anywhere the maxima below would ignore it.
-__device__ __forceinline__ bool sat_may_overlap(V3 v0, V3 v1, V3 v2, float cx, float cy, float cz)
+// The test is solved for x: for one row of candidate voxels (fixed y and z of the leaf's clamped AABB) every axis is a
+// linear function of the voxel centre's x, so it bounds x to an interval; the row's candidates are the voxels whose centre
+// lies in the intersection of the intervals.  Evaluated in the leaf's own frame (origin = the AABB's first voxel, so all
+// magnitudes are extents, not positions).  The box is inflated by kSatMargin in projection space, which covers the
+// rounding of the projections (a few 1e-7 of extent x edge length against 0.02 x edge length); the division by the axis'
+// x component adds a relative 1e-7, covered by `slack` voxels on either side.  An axis whose x component (nearly)
+// vanishes is not used (the x x edge axes, which do not depend on x at all, reject whole rows).
+struct RowClip {
+    float lo, hi;  // interval of admissible voxel centres (x, leaf frame)
+    bool any;
+    __device__ __forceinline__ void bound(float a, float lo_ax, float hi_ax, float slack)
+    {
+        // a * x within [lo_ax, hi_ax]
+        if (abs_f(a) > 1e-20f) {
+            const float r = __builtin_amdgcn_rcpf(a);  // (1 ulp: part of the relative error `slack` covers)
+            const float x0 = lo_ax * r, x1 = hi_ax * r;
+            lo = fmaxf(lo, fminf(x0, x1) - slack);
+            hi = fminf(hi, fmaxf(x0, x1) + slack);
+        }
+    }
+};
+__device__ __forceinline__ void row_clip_edge(RowClip &rc, V3 E, V3 U, V3 W, float cy, float cz, float slack)
 {
     const float h = 0.5f + kSatMargin;
-    const V3 c{cx, cy, cz};
-    const V3 a = v0 - c, b = v1 - c, d = v2 - c;
-    const V3 e0 = b - a, e1 = d - b, e2 = a - d;
-    // plane axis: |n . a| <= h * |n|_1, n = e0 x e1.  Each component of n carries an absolute rounding error of a
-    // few ulp of |e0|_1 |e1|_1 (cancellation), which the bound below over-estimates by more than 10x.
-    const V3 n = cross(e0, e1);
-    const float dist = n.x * a.x + n.y * a.y + n.z * a.z;
-    const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z));
-    const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
-    const float la = abs_f(a.x) + abs_f(a.y) + abs_f(a.z);
-    const float err = 1e-5f * l0 * l1 * (la + 1.0f);
-    float worst = abs_f(dist) - (rad + err);
-    // the nine edge axes, branch-free: the largest excess decides
-#define O2V_SAT_EDGE(E, U, W)                                                            \
-    worst = fmaxf(worst, fmaxf(fmaxf(sat_axis_excess(E.z, E.y, U.z, U.y, W.z, W.y),      \
-                                     sat_axis_excess(E.x, E.z, U.x, U.z, W.x, W.z)),     \
-                               sat_axis_excess(E.y, E.x, U.y, U.x, W.y, W.x)));
-    O2V_SAT_EDGE(e0, a, d)
-    O2V_SAT_EDGE(e1, b, a)
-    O2V_SAT_EDGE(e2, d, b)
-#undef O2V_SAT_EDGE
-    return !(worst > 0.f);
+    // axis x x E = (0, -E.z, E.y): the same for every voxel of the row
+    {
+        const float pu = E.z * (U.y - cy) - E.y * (U.z - cz), pw = E.z * (W.y - cy) - E.y * (W.z - cz);
+        const float rad = h * (abs_f(E.z) + abs_f(E.y));
+        if (fminf(pu, pw) > rad || fmaxf(pu, pw) < -rad) rc.any = false;
+    }
+    // axis y x E = (E.z, 0, -E.x): q(P) = E.x (P.z - cz) - E.z (P.x - cx) = alpha(P) + E.z cx
+    {
+        const float au = E.x * (U.z - cz) - E.z * U.x, aw = E.x * (W.z - cz) - E.z * W.x;
+        const float rad = h * (abs_f(E.x) + abs_f(E.z));
+        rc.bound(E.z, -rad - fmaxf(au, aw), rad - fminf(au, aw), slack);
+    }
+    // axis z x E = (-E.y, E.x, 0): q(P) = E.y (P.x - cx) - E.x (P.y - cy) = beta(P) - E.y cx
+    {
+        const float bu = E.y * U.x - E.x * (U.y - cy), bw = E.y * W.x - E.x * (W.y - cy);
+        const float rad = h * (abs_f(E.y) + abs_f(E.x));
+        rc.bound(-E.y, -rad - fmaxf(bu, bw), rad - fminf(bu, bw), slack);
+    }
+}
+// p0, p1, p2: the leaf's vertices relative to the AABB origin; cy, cz: the row's voxel centre; [xlo, xhi]: the row's
+// voxels that belong to the tile.  Returns the first admissible voxel and their number.
+__device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, float cz, uint32_t xlo, uint32_t xhi, float extent,
+                                             uint32_t &first)
+{
+    const float h = 0.5f + kSatMargin;
+    const float slack = 0.01f + 4e-6f * extent;
+    RowClip rc{(float) xlo + 0.5f, (float) xhi + 0.5f, true};
+    const V3 e0 = p1 - p0, e1 = p2 - p1, e2 = p0 - p2;
+    {
+        // plane axis n = e0 x e1: |n . (c - p0)| <= h |n|_1 + err, with sat_may_overlap's error bound for the farthest voxel
+        const V3 n = cross(e0, e1);
+        const float rest = n.y * (cy - p0.y) + n.z * (cz - p0.z) - n.x * p0.x;  // n . (c - p0) = n.x cx + rest
+        const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
+        const float far = extent + abs_f(p0.x) + abs_f(p0.y) + abs_f(p0.z);  // >= |c - p0|_1 for every voxel of the AABB
+        const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) + 1e-5f * l0 * l1 * (far + 1.0f);
+        rc.bound(n.x, -rad - rest, rad - rest, slack);
+    }
+    row_clip_edge(rc, e0, p0, p2, cy, cz, slack);
+    row_clip_edge(rc, e1, p1, p0, cy, cz, slack);
+    row_clip_edge(rc, e2, p2, p1, cy, cz, slack);
+    // voxel x has its centre at x + 0.5; the interval is clamped to the row before the conversion
+    const float fa = ceilf(rc.lo - 0.5f), fb = floorf(rc.hi - 0.5f);
+    if (!rc.any || !(fa <= fb)) {
+        first = xlo;
+        return 0u;
+    }
+    first = (uint32_t) fa;
+    return (uint32_t) fb - (uint32_t) fa + 1u;
 }
 
 
@@ -377,6 +412,8 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
     __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-candidate chunk's first candidate
     __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
     __shared__ float s_margin[kTilesPerBatch];  // out_margin of the tile's leaf (piece_masks)
+    __shared__ uint32_t s_trow0[kTilesPerBatch];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
+    __shared__ uint32_t s_rprefix[kTilesPerBatch + 6];  // rows before tile k (+ total + padding, as s_tprefix)
     __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct;
     // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
     // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
@@ -446,7 +483,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             s_leaf[k * kLeafStride + j] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
         }
         __syncthreads();
-        uint32_t my_count = 0;
+        uint32_t my_count = 0, my_rows = 0;
         if (threadIdx.x < nt) {
             const uint32_t *lf = &s_leaf[threadIdx.x * kLeafStride];
             const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
@@ -459,6 +496,12 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             s_margin[threadIdx.x] = out_margin(m);
             s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
+            if (my_count) {
+                const uint32_t start = s_tstart[threadIdx.x];
+                const uint32_t r0 = start / dx;
+                s_trow0[threadIdx.x] = r0;
+                my_rows = (start + my_count - 1u) / dx - r0 + 1u;
+            }
         }
         {
             // exclusive prefix of the tile sizes: s_tprefix[k] = candidates before tile k, s_tprefix[nt] = total
@@ -467,6 +510,12 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             if (threadIdx.x < nt) s_tprefix[threadIdx.x] = ex;
             if (threadIdx.x == 0) s_tprefix[nt] = total;  // (nt may equal the number of threads)
             if (threadIdx.x < 5u) s_tprefix[nt + 1u + threadIdx.x] = 0xffffffffu;  // never <= a candidate index
+            // the same for the tiles' rows
+            __syncthreads();
+            const uint32_t exr = block_exscan(my_rows, s_scan, total);
+            if (threadIdx.x < nt) s_rprefix[threadIdx.x] = exr;
+            if (threadIdx.x == 0) s_rprefix[nt] = total;
+            if (threadIdx.x < 5u) s_rprefix[nt + 1u + threadIdx.x] = 0xffffffffu;
         }
 
         // sub-batches of whole tiles with at most kQueueCap candidates
@@ -488,43 +537,41 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             __syncthreads();
             const uint32_t t_end = s_tend;
 
-            // ---- phase 1: the sub-batch's candidates flattened over the lanes ------------------------------
-            // Candidate g (in sub-batch order) belongs to the tile k with s_tprefix[k] <= g < s_tprefix[k + 1].  A small
-            // table gives every 64-candidate chunk the tile its first candidate falls in; a lane then walks forward a
-            // few tiles at most, so the 64 lanes stay busy however small the tiles are.
-            const uint32_t n_cand = s_tprefix[t_end] - base_cand;
+            // ---- phase 1: the sub-batch's candidate rows flattened over the lanes ---------------------------
+            // A tile's candidates are a run of the leaf's clamped AABB in x-fastest order, i.e. a few rows (fixed y, z) of it.
+            // A lane takes one row, solves the separating-axis test for x (row_span) and so names the row's surviving
+            // voxels without visiting the others; the survivors of the wavefront's 64 rows are then flattened over the
+            // lanes again (prefix sum + search), one voxel each, for the reference's plane cull and the job record.
+            // Row g (in sub-batch order) belongs to the tile k with s_rprefix[k] <= g < s_rprefix[k + 1]; a small table
+            // gives every 64-row chunk the tile its first row falls in and a lane walks forward a few tiles at most.
+            const uint32_t base_row = s_rprefix[t_begin];
+            const uint32_t n_rows = s_rprefix[t_end] - base_row;
             if (threadIdx.x >= t_begin && threadIdx.x < t_end) {
-                const uint32_t lo = s_tprefix[threadIdx.x] - base_cand, hi = s_tprefix[threadIdx.x + 1] - base_cand;
+                const uint32_t lo = s_rprefix[threadIdx.x] - base_row, hi = s_rprefix[threadIdx.x + 1] - base_row;
                 if (hi > lo)
                     for (uint32_t ch = (lo + 63u) / 64u; ch * 64u < hi; ++ch) s_chunk_tile[ch] = (uint8_t) threadIdx.x;
             }
             __syncthreads();
             O2V_LAP(0);
-            for (uint32_t g0 = wave * 64u; g0 < n_cand; g0 += kBlock) {
+            // Few long rows (large axis-aligned leaves): every wavefront looks at the same 64 rows and they share the
+            // survivors, 64 at a time; otherwise each wavefront has its own rows.
+            const bool shared_rows = s_tprefix[t_end] - base_cand > 32u * n_rows;
+            for (uint32_t g0 = shared_rows ? 0u : wave * 64u; g0 < n_rows; g0 += shared_rows ? 64u : kBlock) {
                 const uint32_t g = g0 + lane;
-                bool keep = false, heavy = false;
-                uint2 rec = make_uint2(0u, 0u);
-                uint32_t k = s_chunk_tile[g0 / 64u], i = 0;
-                if (g < n_cand) {
-                    // the chunk starts in tile k; this lane's tile is at most a few further on: count the tile ends at or
-                    // before g among the next four (one LDS round trip), walk on only if all four are (tiny tiles)
-                    const uint32_t e1 = s_tprefix[k + 1], e2 = s_tprefix[k + 2], e3 = s_tprefix[k + 3], e4 = s_tprefix[k + 4];
-                    const uint32_t gg = g + base_cand;
+                uint32_t k = s_chunk_tile[g0 / 64u];
+                uint32_t n_out = 0, x_first = 0, ly = 0, lz = 0;
+                if (g < n_rows) {
+                    const uint32_t e1 = s_rprefix[k + 1], e2 = s_rprefix[k + 2], e3 = s_rprefix[k + 3], e4 = s_rprefix[k + 4];
+                    const uint32_t gg = g + base_row;
                     k += (e1 <= gg ? 1u : 0u) + (e2 <= gg ? 1u : 0u) + (e3 <= gg ? 1u : 0u) + (e4 <= gg ? 1u : 0u);
                     if (e4 <= gg)
-                        while (s_tprefix[k + 1] <= gg) ++k;
-                    i = g - (s_tprefix[k] - base_cand);
+                        while (s_rprefix[k + 1] <= gg) ++k;
+                    const uint32_t i_row = gg - s_rprefix[k], last_row = s_rprefix[k + 1] - s_rprefix[k] - 1u;
                     const uint32_t *lf = &s_leaf[k * kLeafStride];
-                    const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu;
-                    const uint32_t j = s_tstart[k] + i;
-                    uint32_t row, lx, lz, ly;
-                    if (j < (1u << 24)) {
-                        // exact quotient from a float estimate (j < 2^24, divisor < 2^16): off by at most one
-                        row = (uint32_t) ((float) j * s_inv_dx[k]);
-                        int32_t rx = (int32_t) (j - row * dx);
-                        if (rx < 0) { row -= 1; rx += (int32_t) dx; }
-                        else if ((uint32_t) rx >= dx) { row += 1; rx -= (int32_t) dx; }
-                        lx = (uint32_t) rx;
+                    const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
+                    const uint32_t row = s_trow0[k] + i_row;
+                    if (row < (1u << 24)) {
+                        // exact quotient from a float estimate (row < 2^24, divisor < 2^16): off by at most one
                         lz = (uint32_t) ((float) row * s_inv_dy[k]);
                         int32_t ry = (int32_t) (row - lz * dy);
                         if (ry < 0) { lz -= 1; ry += (int32_t) dy; }
@@ -532,47 +579,96 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                         ly = (uint32_t) ry;
                     }
                     else {
-                        row = j / dx;
-                        lx = j - row * dx;
                         lz = row / dy;
                         ly = row - lz * dy;
                     }
-                    const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
-                    const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
-                    const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
-                    const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
-                    const float cx = (float) ((lf[20] & 0xffffu) + lx) + 0.5f, cy = (float) ((lf[20] >> 16) + ly) + 0.5f,
-                                cz = (float) ((lf[21] & 0xffffu) + lz) + 0.5f;
-                    // plane distance cull, voxelization.cpp:451-458
-                    const float sd = dot(nrm, V3{cx, cy, cz} - v0);
-                    const bool small = (s_tcount[k] >> 31) != 0u;
-                    keep = !(abs_f(sd) > kPlaneDistanceLimit) && (!small || sat_may_overlap(v0, v1, v2, cx, cy, cz));
-                    if (keep) {
-                        // the job record: position, tile slot, the planes of this voxel the leaf does not pass whole
-                        const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + ly, qz = (lf[21] & 0xffffu) + lz;
-                        Piece<false> leaf;
-                        leaf.a = v0;
-                        leaf.b = v1;
-                        leaf.c = v2;
-                        uint32_t cf0, out_unused, near_unused;
-                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused, near_unused);
-                        rec = make_uint2(qx | (qy << 16), qz | (k << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u));
-                        heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
+                    // the part of the row that belongs to this tile
+                    const uint32_t start = s_tstart[k], count = s_tcount[k] & 0x7fffffffu;
+                    const uint32_t xlo = i_row == 0u ? start - s_trow0[k] * dx : 0u;
+                    const uint32_t xhi = i_row == last_row ? (start + count - 1u) - row * dx : dx - 1u;
+                    x_first = xlo;
+                    n_out = xhi - xlo + 1u;
+                    if (s_tcount[k] >> 31) {
+                        const float ox = (float) (lf[20] & 0xffffu), oy = (float) (lf[20] >> 16), oz = (float) (lf[21] & 0xffffu);
+                        const V3 p0{__uint_as_float(lf[0]) - ox, __uint_as_float(lf[1]) - oy, __uint_as_float(lf[2]) - oz};
+                        const V3 p1{__uint_as_float(lf[3]) - ox, __uint_as_float(lf[4]) - oy, __uint_as_float(lf[5]) - oz};
+                        const V3 p2{__uint_as_float(lf[6]) - ox, __uint_as_float(lf[7]) - oy, __uint_as_float(lf[8]) - oz};
+                        n_out = row_span(p0, p1, p2, (float) ly + 0.5f, (float) lz + 0.5f, xlo, xhi, (float) (dx + dy + dz), x_first);
                     }
                 }
-                const unsigned long long mh = __ballot(keep && heavy), ml = __ballot(keep && !heavy);
-                if (mh | ml) {
-                    uint32_t base_h = 0, base_l = 0;
-                    if (lane == 0) {
-                        if (mh) base_h = atomicAdd(&s_nheavy, (uint32_t) __popcll(mh));
-                        if (ml) base_l = atomicAdd(&s_nlight, (uint32_t) __popcll(ml));
+                // inclusive prefix of the rows' survivor counts over the wavefront
+                uint32_t inc = n_out;
+#pragma unroll
+                for (uint32_t d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += o;
+                }
+                const uint32_t total = __shfl(inc, 63, 64);
+                const uint32_t exc = inc - n_out, xk = x_first | (k << 16), yz = ly | (lz << 16);
+                // (long rows - large axis-aligned leaves - are followed with a wave-uniform cursor instead of the search:
+                // a chunk of 64 survivors then usually comes from one row)
+                const bool long_rows = total > 512u;
+                uint32_t row_b = 0;  // wave-uniform: the row (lane) the survivor b belongs to
+                for (uint32_t b = shared_rows ? wave * 64u : 0u; b < total; b += shared_rows ? kBlock : 64u) {
+                    const uint32_t o = b + lane;  // this lane's survivor
+                    // its row: the first lane whose inclusive prefix exceeds o
+                    uint32_t src = 0;
+                    bool search = true;
+                    if (long_rows) {
+                        while (__builtin_amdgcn_readlane(inc, row_b) <= b) ++row_b;
+                        src = row_b;
+                        search = __builtin_amdgcn_readlane(inc, row_b) < (b + 64u < total ? b + 64u : total);
                     }
-                    base_h = __shfl(base_h, 0, 64);
-                    base_l = __shfl(base_l, 0, 64);
-                    if (keep) {
-                        const uint32_t at = heavy ? base_h + __builtin_amdgcn_mbcnt_hi((uint32_t) (mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mh, 0u))
-                                                  : kQueueCap - 1u - (base_l + __builtin_amdgcn_mbcnt_hi((uint32_t) (ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ml, 0u)));
-                        jobq[at] = rec;
+                    if (search) {
+                        src = 0;
+#pragma unroll
+                        for (uint32_t step = 32; step >= 1; step >>= 1) {
+                            const uint32_t probe = __shfl(inc, (int) (src + step - 1u), 64);
+                            if (probe <= o) src += step;
+                        }
+                        src &= 63u;  // (lanes beyond the total look at lane 63; they are masked below)
+                    }
+                    const uint32_t r_exc = __shfl(exc, (int) src, 64), r_xk = __shfl(xk, (int) src, 64), r_yz = __shfl(yz, (int) src, 64);
+                    bool keep = false, heavy = false;
+                    uint2 rec = make_uint2(0u, 0u);
+                    if (o < total) {
+                        const uint32_t kk = r_xk >> 16, lx = (r_xk & 0xffffu) + (o - r_exc);
+                        const uint32_t *lf = &s_leaf[kk * kLeafStride];
+                        const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + (r_yz & 0xffffu), qz = (lf[21] & 0xffffu) + (r_yz >> 16);
+                        const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                        const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                        const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                        const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
+                        // plane distance cull, voxelization.cpp:451-458
+                        const float sd = dot(nrm, V3{(float) qx + 0.5f, (float) qy + 0.5f, (float) qz + 0.5f} - v0);
+                        keep = !(abs_f(sd) > kPlaneDistanceLimit);
+                        if (keep) {
+                            // the job record: position, tile slot, the planes of this voxel the leaf does not pass whole
+                            const bool small = (s_tcount[kk] >> 31) != 0u;
+                            Piece<false> leaf;
+                            leaf.a = v0;
+                            leaf.b = v1;
+                            leaf.c = v2;
+                            uint32_t cf0, out_unused, near_unused;
+                            piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused, near_unused);
+                            rec = make_uint2(qx | (qy << 16), qz | (kk << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u));
+                            heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
+                        }
+                    }
+                    const unsigned long long mh = __ballot(keep && heavy), ml = __ballot(keep && !heavy);
+                    if (mh | ml) {
+                        uint32_t base_h = 0, base_l = 0;
+                        if (lane == 0) {
+                            if (mh) base_h = atomicAdd(&s_nheavy, (uint32_t) __popcll(mh));
+                            if (ml) base_l = atomicAdd(&s_nlight, (uint32_t) __popcll(ml));
+                        }
+                        base_h = __shfl(base_h, 0, 64);
+                        base_l = __shfl(base_l, 0, 64);
+                        if (keep) {
+                            const uint32_t at = heavy ? base_h + __builtin_amdgcn_mbcnt_hi((uint32_t) (mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mh, 0u))
+                                                      : kQueueCap - 1u - (base_l + __builtin_amdgcn_mbcnt_hi((uint32_t) (ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ml, 0u)));
+                            jobq[at] = rec;
+                        }
                     }
                 }
             }

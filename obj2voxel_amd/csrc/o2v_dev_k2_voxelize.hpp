@@ -148,11 +148,14 @@ __device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area
 // the pushes on the bench mesh), two with uv, whose pieces are 15 floats (9 % of the pushes go deeper; measured faster on
 // configs[1] and configs[3] than a third slot and its spills).  Deeper entries go to a small per-lane overflow array
 // (scratch memory).
+#ifndef O2V_STACK_REGS
+#define O2V_STACK_REGS 3
+#endif
 #ifndef O2V_STACK_REGS_UV
 #define O2V_STACK_REGS_UV 2
 #endif
 template <bool UV>
-__device__ __forceinline__ constexpr uint32_t stack_regs() { return UV ? O2V_STACK_REGS_UV : 3u; }
+__device__ __forceinline__ constexpr uint32_t stack_regs() { return UV ? O2V_STACK_REGS_UV : O2V_STACK_REGS; }
 constexpr uint32_t kStackLevels = 5;
 template <bool UV>
 struct PieceStack {

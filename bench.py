@@ -198,6 +198,7 @@ def report(args, n, run, dv, comm):
     Vr = st["voxels"]                      # this rank's voxels
     Hp = H - Hd                            # hits that took the pool -> counting sort -> ordered replay route
     REC = 16                               # sorted record: 16 bytes for a mesh without textured triangles (these workloads)
+    CPB = st["grid_cells"] // max(st["bricks"], 1)   # cells per brick of the dense grids (o2v_dev_common.hpp: kBrickCells)
     direct = Hd > 0
     alg = {
         "bounds": 36 * T,
@@ -206,10 +207,10 @@ def report(args, n, run, dv, comm):
         # byte (direct) or pool record + counter atomic + flag byte (pooled)
         "voxelize": 96 * L + 8 * tiles + 16 * st["jobs"] + (8 + 1) * Hd + (32 + 4 + 1) * Hp,
         # counting sort of the pooled hits (nothing to do when every hit was direct)
-        "scan": (B + 1024 * D + (16 + 4) * Vr + 32 * slots + (4 + REC) * Hp + 1024 * D) if Hp else 0,
-        # replay of the pooled hits + emission of the 64-bit grid: flag map, the dirty bricks (2 KiB each) read, the occupied
+        "scan": (B + 4 * CPB * D + (16 + 4) * Vr + 32 * slots + (4 + REC) * Hp + 4 * CPB * D) if Hp else 0,
+        # replay of the pooled hits + emission of the 64-bit grid: flag map, the dirty bricks (8 bytes per cell) read, the occupied
         # 32-byte lane groups zeroed (at most one per voxel), records written
-        "resolve": (16 * Vr + REC * Hp if Hp else 0) + ((B + 2048 * D + 32 * Vr + 16 * Vr) if direct else 16 * Vr),
+        "resolve": (16 * Vr + REC * Hp if Hp else 0) + ((B + 8 * CPB * D + 32 * Vr + 16 * Vr) if direct else 16 * Vr),
     }
     stage_kernels = {
         "bounds": ["k_init", "k_bounds", "k_setup"],

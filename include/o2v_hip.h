@@ -78,7 +78,7 @@ typedef struct {
     uint64_t candidates;  /* (leaf, voxel) pairs examined */
     uint64_t hits;        /* (leaf, voxel) pairs with non-zero weight */
     uint64_t voxels;      /* occupied output voxels */
-    uint64_t grid_cells;  /* dense grid cells owned by this context (bricks of 4x8x8, padded) */
+    uint64_t grid_cells;  /* dense grid cells owned by this context (bricks of 4x4x4, padded) */
     uint64_t grid_bytes;  /* bytes of the dense grid allocation incl. the per-brick dirty flags */
     uint64_t bricks;      /* bricks of the slab */
     uint64_t dirty_bricks;/* bricks that received at least one hit */

@@ -85,7 +85,7 @@ struct SortedView {
 };
 
 struct __attribute__((aligned(16))) Occ {  // 16 B: one occupied cell
-    uint32_t cell_lo, cell_hi;  // brick * 256 + cell in brick
+    uint32_t cell_lo, cell_hi;  // brick * kBrickCells + cell in brick
     uint32_t offset;            // first SortedRec of the cell
     uint32_t count;             // number of hits
 };
@@ -125,19 +125,21 @@ enum : uint32_t {
     kErrLeafTooLarge = 1u,
     kErrDepth = 2u,
     kErrRank = 4u,
+    kErrDirtyList = 8u,  // more dirty bricks than the dirty list holds (Params::cap_dirty)
 };
 
 struct Params {
     uint64_t n_tris;
     uint32_t S;            // sample resolution = resolution * supersampling
     uint32_t G;            // output resolution
-    uint32_t NBx, NBy;     // bricks per grid row / per z layer (brick = 4 x 8 x 8 cells, stored contiguously)
+    uint32_t NBx, NBy;     // bricks per grid row / per z layer (brick = 4 x 4 x 4 cells, stored contiguously)
     uint32_t ss_shift;     // 0, or 1 for 2x supersampling
     uint32_t zs0, zs1;     // slab in sample space
     uint32_t zo0;          // slab begin in output space
     uint32_t blend;
     uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
     uint32_t n_bricks;     // bricks of this slab
+    uint32_t cap_dirty;    // entries of each dirty-brick list
     uint32_t bounds_known;
     float bounds[6];
     int32_t unit[9];
@@ -189,19 +191,26 @@ __device__ __forceinline__ float ord2f(uint32_t o)
     return __uint_as_float(b);
 }
 
-// Dense grid layout: bricks of 4 (x) x 8 (y) x 8 (z) cells, each brick 256 consecutive u32 (1 KiB; 2 KiB in the 64-bit
-// grid), bricks ordered x fastest; one wavefront reads a brick with a single 16-byte load per lane.  A surface of area A
-// meets about A/2 * (1/(sy sz) + 1/(sx sz) + 1/(sx sy)) bricks of extents (sx, sy, sz), so the nearly cubic shape means
-// the fewest dirty bricks for the scan / emission passes to read: measured against 16 x 4 x 4 (round 1) -15 % in
-// k_emit_max on the bench mesh, -25 % on the box room, and 8 x 8 x 4 / 8 x 4 x 8 in between.
+// Dense grid layout: bricks of 4 x 4 x 4 cells, each brick 64 consecutive u32 (256 B; 512 B in the 64-bit grid), bricks
+// ordered x fastest, one dirty byte per brick.  A surface of area A meets about A/2 * (1/(sy sz) + 1/(sx sz) + 1/(sx sy))
+// bricks of extents (sx, sy, sz), so small cubic bricks mean the fewest cells of dirty bricks for the scan / emission
+// passes to read: measured on the bench mesh, k_emit_max 0.121 ms with 16 x 4 x 4 bricks (round 1), 0.103 with 4 x 8 x 8,
+// 0.092 with 4 x 4 x 8, 0.078 with 4 x 4 x 4 (the flag map grows to 1/64 byte per cell: k_scan_flags 0.013 -> 0.020 ms).
 #ifndef O2V_BRICK_XS
 #define O2V_BRICK_XS 2
-#define O2V_BRICK_YS 3
-#define O2V_BRICK_ZS 3
+#define O2V_BRICK_YS 2
+#define O2V_BRICK_ZS 2
 #endif
 constexpr uint32_t kBrickXs = O2V_BRICK_XS, kBrickYs = O2V_BRICK_YS, kBrickZs = O2V_BRICK_ZS;  // log2 of the brick's extents
-constexpr uint32_t kBrickX = 1u << kBrickXs, kBrickY = 1u << kBrickYs, kBrickZ = 1u << kBrickZs, kBrickCells = 256;
-static_assert(kBrickXs + kBrickYs + kBrickZs == 8, "a brick is 256 cells");
+constexpr uint32_t kBrickShift = kBrickXs + kBrickYs + kBrickZs;
+constexpr uint32_t kBrickX = 1u << kBrickXs, kBrickY = 1u << kBrickYs, kBrickZ = 1u << kBrickZs, kBrickCells = 1u << kBrickShift;
+// The kernels that read whole bricks give every lane four consecutive cells (one 16-byte load in the 32-bit grid, two in
+// the 64-bit one), so one wavefront load covers 256 cells = kBricksPerLoad bricks.
+constexpr uint32_t kLanesPerBrick = kBrickCells / 4u, kBricksPerLoad = 64u / kLanesPerBrick;
+// Entries of a dirty-brick list: one per brick of the slab, but no more than this (0.5 GiB; a 4096^3 grid on one GPU has
+// 2^30 bricks, of which a surface dirties a few million - more is reported as a limit, see kErrDirtyList).
+constexpr uint64_t kDirtyListMax = 1ull << 27;
+static_assert(kBrickShift >= 4 && kBrickShift <= 8, "a brick is 16 .. 256 cells (HitRec keeps the cell in 8 bits)");
 
 __device__ __forceinline__ uint64_t cell_index(uint32_t ox, uint32_t oy, uint32_t oz_rel, const Params &p, uint32_t &brick)
 {

@@ -764,7 +764,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                             // triangle is unsplit, so (d_u, d_v) already is its whole uv mean in this voxel
                             float cr, cg, cb;
                             color_at(p.mat, lf[18], d_u, d_v, cr, cg, cb);
-                            pool[mine] = HitRec{brick, ((uint32_t) cell & 255u) << 24, keyhi, pack_argb(cr, cg, cb), d_w, 0.f, 0.f, kPickRecord};
+                            pool[mine] = HitRec{brick, ((uint32_t) cell & (kBrickCells - 1u)) << 24, keyhi, pack_argb(cr, cg, cb), d_w, 0.f, 0.f, kPickRecord};
                         }
                     }
                     else if (mine < p.cap_hits) {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                         if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
                         brick_dirty[brick] = 1;  // benign race: every writer stores the same value
                         if (use_direct) p.dirty_max[brick] = 1;  // the resolve kernels will add this cell's result
-                        pool[mine] = HitRec{brick, (((uint32_t) cell & 255u) << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w,
+                        pool[mine] = HitRec{brick, (((uint32_t) cell & (kBrickCells - 1u)) << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w,
                                             d_u, d_v, 0u};
                     }
                 }

@@ -56,7 +56,7 @@ __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const 
 {
     const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
     uint32_t x, y, z;
-    cell_position((uint32_t) (cell >> 8), (uint32_t) cell & 255u, p, x, y, z);
+    cell_position((uint32_t) (cell >> kBrickShift), (uint32_t) cell & (kBrickCells - 1u), p, x, y, z);
     return make_uint4(x, y, z + p.zo0, argb);
 }
 
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void k_pick(const HitRec *__restrict__ pool
 }
 
 constexpr uint32_t kEmitBricksPerWave = 2;
-constexpr uint32_t kEmitBricksPerRound = (kBlock / 64) * kEmitBricksPerWave;
+constexpr uint32_t kEmitBricksPerRound = (kBlock / 64) * kEmitBricksPerWave * kBricksPerLoad;
 constexpr uint32_t kEmitFlushAt = 1024;  // 48 KiB of staging: three workgroups per CU keep enough 2 KiB brick loads in flight
                                          // (2048 / two workgroups: 0.15 ms on the bench mesh, this: 0.12; 512 / four: 0.16)
 constexpr uint32_t kEmitCap = kEmitFlushAt + kEmitBricksPerRound * kBrickCells;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
     if (!direct_active(c, p)) return;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const uint32_t n_dirty = c->n_dirty_max;
+    const uint32_t n_dirty = c->n_dirty_max < p.cap_dirty ? c->n_dirty_max : p.cap_dirty;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t n_rounds = (n_dirty + kEmitBricksPerRound - 1) / kEmitBricksPerRound;
     auto flush = [&](uint32_t n) {
@@ -655,14 +655,14 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
         ulonglong2 lo[kEmitBricksPerWave], hi[kEmitBricksPerWave];
 #pragma unroll
         for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
-            const uint32_t item = r * kEmitBricksPerRound + wave * kEmitBricksPerWave + k;
+            const uint32_t item = r * kEmitBricksPerRound + (wave * kEmitBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
             brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
         }
 #pragma unroll
         for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
             lo[k] = hi[k] = make_ulonglong2(0, 0);
             if (brick[k] != 0xffffffffu) {
-                const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p.maxgrid + (uint64_t) brick[k] * kBrickCells) + lane * 2u;
+                const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p.maxgrid + (uint64_t) brick[k] * kBrickCells) + (lane % kLanesPerBrick) * 2u;
                 lo[k] = q[0];
                 hi[k] = q[1];
             }
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
 #pragma unroll
                 for (uint32_t e = 0; e < 4; ++e) {
                     if (v4[e]) {
-                        const uint32_t local = lane * 4u + e;
+                        const uint32_t local = (lane % kLanesPerBrick) * 4u + e;
                         uint32_t argb;
                         if (v4[e] & kPickTag) {
                             argb = (uint32_t) v4[e];  // textured mesh: k_pick already put the winner's colour here
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
                     }
                 }
                 // leave the cells clean for the next run
-                ulonglong2 *q = reinterpret_cast<ulonglong2 *>(p.maxgrid + (uint64_t) brick[k] * kBrickCells) + lane * 2u;
+                ulonglong2 *q = reinterpret_cast<ulonglong2 *>(p.maxgrid + (uint64_t) brick[k] * kBrickCells) + (lane % kLanesPerBrick) * 2u;
                 q[0] = make_ulonglong2(0, 0);
                 q[1] = make_ulonglong2(0, 0);
             }

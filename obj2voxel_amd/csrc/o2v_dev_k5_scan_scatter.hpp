@@ -9,21 +9,42 @@
 // per lane), compacts the occupied cells into `occ` through an LDS staging buffer (one global atomic per flush,
 // not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.
 
-__global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uint32_t *n_dirty, uint32_t *dirty_list, Params p)
+constexpr uint32_t kFlagLoads = 2;  // 16-byte loads of the flag map per thread and round
+__global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uint32_t *n_dirty, uint32_t *dirty_list, Counters *c, Params p)
 {
-    __shared__ uint32_t s_list[kBlock * 16];
+    // The workgroup collects dirty bricks in LDS over several rounds and reserves their place in the list with one global
+    // atomic per few thousand of them (atomics on one address serialise at ~88 per us: one per round and workgroup was most
+    // of this kernel's time).  Launched with two workgroups per CU.
+    constexpr uint32_t kRoundMax = kBlock * 16 * kFlagLoads;  // bricks one round can add
+    constexpr uint32_t kFlushAbove = 4096;
+    __shared__ uint32_t s_list[kFlushAbove + kRoundMax];
     __shared__ uint32_t s_n, s_base;
     const uint32_t n_groups = (p.n_bricks + 15u) / 16u;  // the flag map is padded to a multiple of 16 bytes
     uint4 *f4 = reinterpret_cast<uint4 *>(brick_dirty);
-    for (uint32_t g0 = blockIdx.x * kBlock; g0 < n_groups; g0 += gridDim.x * kBlock) {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    auto flush = [&](uint32_t n) {
+        if (threadIdx.x == 0) s_base = atomicAdd(n_dirty, n);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+            if (s_base + i < p.cap_dirty) dirty_list[s_base + i] = s_list[i];
+        if (threadIdx.x == 0 && s_base + n > p.cap_dirty) atomicOr(&c->err_flags, kErrDirtyList);
         __syncthreads();
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
-        const uint32_t g = g0 + threadIdx.x;
-        if (g < n_groups) {
-            const uint4 f = f4[g];
-            if (f.x | f.y | f.z | f.w) {
-                const uint32_t w[4] = {f.x, f.y, f.z, f.w};
+    };
+    for (uint32_t g0 = blockIdx.x * kBlock * kFlagLoads; g0 < n_groups; g0 += gridDim.x * kBlock * kFlagLoads) {
+        uint4 f[kFlagLoads];
+#pragma unroll
+        for (uint32_t u = 0; u < kFlagLoads; ++u) {
+            const uint32_t g = g0 + u * kBlock + threadIdx.x;
+            f[u] = g < n_groups ? f4[g] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kFlagLoads; ++u) {
+            if (f[u].x | f[u].y | f[u].z | f[u].w) {
+                const uint32_t g = g0 + u * kBlock + threadIdx.x;
+                const uint32_t w[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
 #pragma unroll
                 for (uint32_t k = 0; k < 16; ++k)
                     if ((w[k >> 2] >> ((k & 3u) * 8u)) & 0xffu) s_list[atomicAdd(&s_n, 1u)] = g * 16u + k;
@@ -32,16 +53,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uin
         }
         __syncthreads();
         const uint32_t n = s_n;
-        if (n) {
-            if (threadIdx.x == 0) s_base = atomicAdd(n_dirty, n);
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < n; i += kBlock) dirty_list[s_base + i] = s_list[i];
-        }
+        if (n > kFlushAbove) flush(n);  // (the next round may add kRoundMax more)
     }
+    const uint32_t n = s_n;
+    if (n) flush(n);
 }
 
 constexpr uint32_t kScanBricksPerWave = 4;                                   // independent 1 KiB loads in flight per wave
-constexpr uint32_t kScanBricksPerRound = (kBlock / 64) * kScanBricksPerWave;  // 16 bricks = 4096 cells per block round
+constexpr uint32_t kScanBricksPerRound = (kBlock / 64) * kScanBricksPerWave * kBricksPerLoad;  // 4096 cells per block round
 constexpr uint32_t kScanFlushAt = 2048;
 constexpr uint32_t kScanCap = kScanFlushAt + kScanBricksPerRound * kBrickCells;
 
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
     if (threadIdx.x == 0) s_n = 0;
     if (threadIdx.x < kResolveClasses) s_cls[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t n_dirty = c->n_dirty;
+    const uint32_t n_dirty = c->n_dirty < p.cap_dirty ? c->n_dirty : p.cap_dirty;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t n_rounds = (n_dirty + kScanBricksPerRound - 1) / kScanBricksPerRound;
     for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
@@ -149,12 +168,13 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
         uint4 h[kScanBricksPerWave];
 #pragma unroll
         for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
-            const uint32_t item = r * kScanBricksPerRound + wave * kScanBricksPerWave + k;
+            // (a load covers kBricksPerLoad bricks: kLanesPerBrick lanes each)
+            const uint32_t item = r * kScanBricksPerRound + (wave * kScanBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
             brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
         }
 #pragma unroll
         for (uint32_t k = 0; k < kScanBricksPerWave; ++k)
-            h[k] = brick[k] != 0xffffffffu ? reinterpret_cast<const uint4 *>(grid + (uint64_t) brick[k] * kBrickCells)[lane]
+            h[k] = brick[k] != 0xffffffffu ? reinterpret_cast<const uint4 *>(grid + (uint64_t) brick[k] * kBrickCells)[lane % kLanesPerBrick]
                                            : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
 #pragma unroll
                 for (uint32_t e = 0; e < 4; ++e) {
                     if (hv[e]) {
-                        const uint64_t cell = (uint64_t) brick[k] * kBrickCells + lane * 4u + e;
+                        const uint64_t cell = (uint64_t) brick[k] * kBrickCells + (lane % kLanesPerBrick) * 4u + e;
                         const uint32_t slot = atomicAdd(&s_n, 1u);
                         s_lo[slot] = (uint32_t) cell;
                         s_hi[slot] = (uint32_t) (cell >> 32);
@@ -211,13 +231,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ p
     }
 }
 
-// Zeroes the dirty bricks (whole 1 KiB bricks, one 16-byte store per lane): leaves the dense grid clean for the next
+// Zeroes the dirty bricks (whole bricks, one 16-byte store per lane): leaves the dense grid clean for the next
 // voxelization.  Runs after k_scatter has read the per-cell offsets.
 __global__ __launch_bounds__(kBlock) void k_reset_bricks(uint32_t *grid, const uint32_t *__restrict__ dirty_list,
-                                                         const Counters *c)
+                                                         const Counters *c, Params p)
 {
-    const uint32_t n_dirty = c->n_dirty;
+    const uint32_t n_dirty = c->n_dirty < p.cap_dirty ? c->n_dirty : p.cap_dirty;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t item = blockIdx.x * (kBlock / 64) + wave; item < n_dirty; item += gridDim.x * (kBlock / 64))
-        reinterpret_cast<uint4 *>(grid + (uint64_t) dirty_list[item] * kBrickCells)[lane] = make_uint4(0, 0, 0, 0);
+    for (uint32_t item = (blockIdx.x * (kBlock / 64) + wave) * kBricksPerLoad + lane / kLanesPerBrick; item < n_dirty;
+         item += gridDim.x * (kBlock / 64) * kBricksPerLoad)
+        reinterpret_cast<uint4 *>(grid + (uint64_t) dirty_list[item] * kBrickCells)[lane % kLanesPerBrick] = make_uint4(0, 0, 0, 0);
 }

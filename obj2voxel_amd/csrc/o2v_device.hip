@@ -286,16 +286,16 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         run_general = !run_emit || h.n_nodes[0] != 0;
         if (run_emit) {
             const uint32_t groups = (p.n_bricks + 15u) / 16u;
-            hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (groups + kBlock - 1) / kBlock)),
-                               dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, p);
+            hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
+                               dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, ctx->d_ctr, p);
             O2V_STAGE("k_scan_flags (max)");
         }
     }
 
     if (run_general) {
         const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
-        hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 4u, (flag_groups + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, p);
+        hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
+                           dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, ctx->d_ctr, p);
         O2V_STAGE("k_scan_flags");
         const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
                                  ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
@@ -306,7 +306,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
         O2V_STAGE("k_scatter");
         hipLaunchKernelGGL(k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
-                           ctx->d_dirty_list, ctx->d_ctr);
+                           ctx->d_dirty_list, ctx->d_ctr, p);
         O2V_STAGE("k_reset_bricks");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
@@ -766,6 +766,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         return O2V_HIP_ERR_LIMIT;
     }
     p.n_bricks = (uint32_t) n_bricks;
+    p.cap_dirty = (uint32_t) std::min<uint64_t>((n_bricks + 15u) & ~15ull, kDirtyListMax);
     p.ss_shift = ss == 2 ? 1u : 0u;
     p.zs0 = z0 * ss;
     p.zs1 = z1 * ss;
@@ -794,7 +795,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         ctx->grid_cells = cells;
         ctx->brick_cap = (n_bricks + 15u) & ~15ull;
         O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_brick_dirty), ctx->brick_cap));
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list), ctx->brick_cap * sizeof(uint32_t)));
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list), std::min<uint64_t>(ctx->brick_cap, kDirtyListMax) * sizeof(uint32_t)));
         ctx->grid_dirty = true;
     }
     if (ctx->grid_dirty) {
@@ -830,7 +831,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
                 // whose later allocation failed must not look ready
                 const uint64_t brick_cap = (n_bricks + 15u) & ~15ull, map_bytes = brick_cap;
                 const bool ok = hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), map_bytes) == hipSuccess &&
-                                hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), brick_cap * sizeof(uint32_t)) == hipSuccess;
+                                hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), std::min<uint64_t>(brick_cap, kDirtyListMax) * sizeof(uint32_t)) == hipSuccess;
                 if (!ok) {
                     (void) hipGetLastError();
                     for (void *q : {(void *) ctx->d_maxgrid, (void *) ctx->d_dirty_max, (void *) ctx->d_dirty_list_max})
@@ -960,9 +961,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         const Counters &h = *ctx->h_ctr;
         ctx->timings.passes = pass;
         if (h.err_flags) {
-            ctx->grid_dirty = false;
+            // (a dirty-list overflow leaves bricks behind that no list names: the grids stay marked for a full clear)
+            if (!(h.err_flags & kErrDirtyList)) ctx->grid_dirty = false;
             ctx->err = (h.err_flags & kErrLeafTooLarge) ? "a leaf's voxel AABB has 2^32 or more candidate voxels"
                        : (h.err_flags & kErrDepth)      ? "subdivision deeper than 15 levels"
+                       : (h.err_flags & kErrDirtyList)  ? "more than 2^27 bricks of the slab hold voxels; use more z-slabs"
                                                         : "a voxel received 2^24 or more hits";
             return O2V_HIP_ERR_LIMIT;
         }

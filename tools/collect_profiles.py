@@ -81,7 +81,7 @@ for w in ("config2", "config2_blend", "config1", "config3"):
                        "launch: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (--kernel-trace only), counters in KiB, "
                        "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half "
                        "the bytes of wide coalesced reads; calibrated in round 1 on k_bounds = 36 B x triangles read and "
-                       "k_reset_bricks = 1 KiB per dirty brick written); sq: two --pmc passes of 8 SQ counters, averages per launch "
+                       "k_reset_bricks = the dirty bricks written); sq: two --pmc passes of 8 SQ counters, averages per launch "
                        "(SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles).",
            "workload": w, "command": "python bench.py --no-cpu-baseline --no-capi" if w == "config2" else f"python tools/run_workload.py {w}",
            "result_line": line, "hbm_bytes_per_step_all_kernels": round(step_traffic), "kernels": kernels}

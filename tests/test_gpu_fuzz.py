@@ -173,8 +173,8 @@ def test_dense_cells_case(dv, oracle, seed):
 
 
 def test_extended_sweep(dv, oracle):
-    """Opt-in long sweep (O2V_FUZZ_EXTRA=N): N more random cases, N/4 more planar-stress cases and N/25 more
-    dense-cell cases beyond the fixed seeds above; reports every failing seed instead of stopping at the first."""
+    """Opt-in long sweep (O2V_FUZZ_EXTRA=N): N more random cases, N/4 more planar-stress cases and N/100 more
+    far-corner cases beyond the fixed seeds above; reports every failing seed instead of stopping at the first."""
     import os
     n = int(os.environ.get("O2V_FUZZ_EXTRA", "0"))
     if n == 0:
@@ -196,4 +196,16 @@ def test_extended_sweep(dv, oracle):
         want = meshes.sorted_voxels(oracle.voxelize(v, res, **mat, **kw))
         if got.shape != want.shape or not np.array_equal(got, want):
             bad.append(("planar", seed))
+    from obj2voxel_amd import hip
+    for seed in range(4, 4 + n // 100):
+        v, res, kw, mat = _far_corner_case(seed)
+        d = hip.DeviceVoxelizer(0)
+        try:
+            d.set_triangles(v, **mat)
+            got = meshes.sorted_voxels(d.voxelize(res, **kw))
+        finally:
+            d.close()
+        want = meshes.sorted_voxels(oracle.voxelize(v, res, **mat, **kw))
+        if got.shape != want.shape or not np.array_equal(got, want):
+            bad.append(("far corner", seed))
     assert not bad, bad

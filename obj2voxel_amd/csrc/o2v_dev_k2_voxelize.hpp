@@ -362,19 +362,29 @@ __device__ __forceinline__ uint32_t single_plane_kept(const Piece<UV> &q, uint32
 #endif
 constexpr uint32_t kFlushAt = O2V_FLUSH_AT;             // parked hits per wavefront that trigger the append section
 constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
-constexpr uint32_t kQueueCap = 16384;         // job queue records (= candidate voxels at most) per sub-batch and workgroup
-#ifndef O2V_BATCHES_PER_BLOCK
-#define O2V_BATCHES_PER_BLOCK 4
+// Launch shape of k_voxelize.  Without uv: 256-thread workgroups (four wavefronts share a leaf table and a job queue).  With
+// uv: one wavefront per workgroup with its own table and queue (no workgroup barriers; measured -8 % on configs[3], -5 % on
+// configs[1]; without uv the same change costs 4 %).  A workgroup stages at most one tile per thread and its queue holds
+// 64 candidates per thread; it takes its tiles from the cursor in batches - about `batches` per workgroup, `batches_large`
+// for large jobs (if a batch then still holds `finer_min` tiles): few large batches leave workgroups idle at the end of the
+// kernel, many small ones pay the per-batch staging, barriers and tails too often.
+#ifndef O2V_VOX_BLOCK
+#define O2V_VOX_BLOCK 256
+#endif
+#ifndef O2V_VOX_BLOCK_UV
+#define O2V_VOX_BLOCK_UV 64
 #endif
 #ifndef O2V_HEAVY_PLANES
 #define O2V_HEAVY_PLANES 5
 #endif
-constexpr uint32_t kBatchesPerBlockLarge = 6;   // ... if the batches then still hold kFinerBatchMinTiles tiles
-#ifndef O2V_FINER_MIN
-#define O2V_FINER_MIN 32
-#endif
-constexpr uint32_t kFinerBatchMinTiles = O2V_FINER_MIN;
-constexpr uint32_t kBatchesPerBlock = O2V_BATCHES_PER_BLOCK;      // aimed-at number of batches per workgroup (see tiles_per_batch)
+template <bool UV>
+struct VoxShape {
+    static constexpr uint32_t block = UV ? O2V_VOX_BLOCK_UV : O2V_VOX_BLOCK;  // threads per workgroup
+    static constexpr uint32_t tiles = block;                                  // tiles staged at once (at most)
+    static constexpr uint32_t queue = 64u * block;  // job queue records (= candidate voxels at most) per sub-batch and workgroup
+    static constexpr uint32_t batches = block >= 256u ? 4u : 2u, batches_large = block >= 256u ? 6u : 3u;
+    static constexpr uint32_t finer_min = 32u * block / 256u;
+};
 constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf straddles at least this many voxel planes is queued first
 
 // K2.  Persistent workgroups pull batches of tiles.  Per batch:
@@ -400,23 +410,51 @@ constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf
 #ifndef O2V_K2_WAVES_UV
 #define O2V_K2_WAVES_UV 4
 #endif
+// exclusive scan of one uint32 per thread over k_voxelize's workgroup; returns the total in `total`
+template <uint32_t kVoxBlock>
+__device__ __forceinline__ uint32_t vox_exscan(uint32_t v, uint32_t *s_wave /*[kVoxBlock / 64]*/, uint32_t &total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kVoxBlock / 64; ++w) {
+        const uint32_t cnt = s_wave[w];
+        if (w < wave) base += cnt;
+        tot += cnt;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
 template <bool UV>
-__global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+__global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                                      Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
                                                      uint2 *jobq_all, Params p)
 {
-    __shared__ uint32_t s_leaf[kTilesPerBatch * kLeafStride];
-    __shared__ uint32_t s_tleaf[kTilesPerBatch];
-    __shared__ uint32_t s_tstart[kTilesPerBatch];
-    __shared__ uint32_t s_tcount[kTilesPerBatch];
-    __shared__ uint32_t s_tprefix[kTilesPerBatch + 6];  // + total + padding for the four-entry window of phase 1
-    __shared__ uint32_t s_scan[kBlock / 64];
+    constexpr uint32_t kVoxBlock = VoxShape<UV>::block, kVoxTiles = VoxShape<UV>::tiles, kQueueCap = VoxShape<UV>::queue;
+    constexpr uint32_t kBatchesPerBlock = VoxShape<UV>::batches, kBatchesPerBlockLarge = VoxShape<UV>::batches_large;
+    constexpr uint32_t kFinerBatchMinTiles = VoxShape<UV>::finer_min;
+    __shared__ uint32_t s_leaf[kVoxTiles * kLeafStride];
+    __shared__ uint32_t s_tleaf[kVoxTiles];
+    __shared__ uint32_t s_tstart[kVoxTiles];
+    __shared__ uint32_t s_tcount[kVoxTiles];
+    __shared__ uint32_t s_tprefix[kVoxTiles + 6];  // + total + padding for the four-entry window of phase 1
+    __shared__ uint32_t s_scan[kVoxBlock / 64];
     __shared__ uint32_t s_tend;
     __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-candidate chunk's first candidate
-    __shared__ float s_inv_dx[kTilesPerBatch], s_inv_dy[kTilesPerBatch];
-    __shared__ float s_margin[kTilesPerBatch];  // out_margin of the tile's leaf (piece_masks)
-    __shared__ uint32_t s_trow0[kTilesPerBatch];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
-    __shared__ uint32_t s_rprefix[kTilesPerBatch + 6];  // rows before tile k (+ total + padding, as s_tprefix)
+    __shared__ float s_inv_dx[kVoxTiles], s_inv_dy[kVoxTiles];
+    __shared__ float s_margin[kVoxTiles];  // out_margin of the tile's leaf (piece_masks)
+    __shared__ uint32_t s_trow0[kVoxTiles];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
+    __shared__ uint32_t s_rprefix[kVoxTiles + 6];  // rows before tile k (+ total + padding, as s_tprefix)
     __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct;
     // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
     // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
@@ -441,7 +479,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
         if (finer >= kFinerBatchMinTiles) tiles_per_batch = finer;
     }
     tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
-                      : (tiles_per_batch > kTilesPerBatch ? kTilesPerBatch : tiles_per_batch);
+                      : (tiles_per_batch > kVoxTiles ? kVoxTiles : tiles_per_batch);
     const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
@@ -464,7 +502,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
         s_direct = 0;
     }
     if (threadIdx.x < 64u) s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
-    if (threadIdx.x < 128u) s_kept[threadIdx.x] = (uint8_t) classify_kept(threadIdx.x & 63u, threadIdx.x >= 64u);
+    for (uint32_t i = threadIdx.x; i < 128u; i += kVoxBlock) s_kept[i] = (uint8_t) classify_kept(i & 63u, i >= 64u);
 
     for (;;) {
         __syncthreads();
@@ -481,7 +519,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
         }
         __syncthreads();
         // stage the leaves of this batch in LDS
-        for (uint32_t i = threadIdx.x; i < nt * 24u; i += kBlock) {
+        for (uint32_t i = threadIdx.x; i < nt * 24u; i += kVoxBlock) {
             const uint32_t k = i / 24u, j = i - k * 24u;
             s_leaf[k * kLeafStride + j] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
         }
@@ -509,13 +547,13 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
         {
             // exclusive prefix of the tile sizes: s_tprefix[k] = candidates before tile k, s_tprefix[nt] = total
             uint32_t total;
-            const uint32_t ex = block_exscan(my_count, s_scan, total);
+            const uint32_t ex = vox_exscan<kVoxBlock>(my_count, s_scan, total);
             if (threadIdx.x < nt) s_tprefix[threadIdx.x] = ex;
             if (threadIdx.x == 0) s_tprefix[nt] = total;  // (nt may equal the number of threads)
             if (threadIdx.x < 5u) s_tprefix[nt + 1u + threadIdx.x] = 0xffffffffu;  // never <= a candidate index
             // the same for the tiles' rows
             __syncthreads();
-            const uint32_t exr = block_exscan(my_rows, s_scan, total);
+            const uint32_t exr = vox_exscan<kVoxBlock>(my_rows, s_scan, total);
             if (threadIdx.x < nt) s_rprefix[threadIdx.x] = exr;
             if (threadIdx.x == 0) s_rprefix[nt] = total;
             if (threadIdx.x < 5u) s_rprefix[nt + 1u + threadIdx.x] = 0xffffffffu;
@@ -559,7 +597,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
             // Few long rows (large axis-aligned leaves): every wavefront looks at the same 64 rows and they share the
             // survivors, 64 at a time; otherwise each wavefront has its own rows.
             const bool shared_rows = s_tprefix[t_end] - base_cand > 32u * n_rows;
-            for (uint32_t g0 = shared_rows ? 0u : wave * 64u; g0 < n_rows; g0 += shared_rows ? 64u : kBlock) {
+            for (uint32_t g0 = shared_rows ? 0u : wave * 64u; g0 < n_rows; g0 += shared_rows ? 64u : kVoxBlock) {
                 const uint32_t g = g0 + lane;
                 uint32_t k = s_chunk_tile[g0 / 64u];
                 uint32_t n_out = 0, x_first = 0, ly = 0, lz = 0;
@@ -612,7 +650,7 @@ __global__ __launch_bounds__(kBlock, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void
                 // a chunk of 64 survivors then usually comes from one row)
                 const bool long_rows = total > 512u;
                 uint32_t row_b = 0;  // wave-uniform: the row (lane) the survivor b belongs to
-                for (uint32_t b = shared_rows ? wave * 64u : 0u; b < total; b += shared_rows ? kBlock : 64u) {
+                for (uint32_t b = shared_rows ? wave * 64u : 0u; b < total; b += shared_rows ? kVoxBlock : 64u) {
                     const uint32_t o = b + lane;  // this lane's survivor
                     // its row: the first lane whose inclusive prefix exceeds o
                     uint32_t src = 0;

@@ -103,7 +103,7 @@ struct o2v_hip_ctx {
     Tile *d_tiles = nullptr;
     BigLeaf *d_big = nullptr;
     Node *d_nodes[2] = {nullptr, nullptr};
-    uint2 *d_jobq = nullptr;  // k_voxelize's job queues: kQueueCap records per workgroup
+    uint2 *d_jobq = nullptr;  // k_voxelize's job queues: VoxShape::queue records per workgroup
     HitRec *d_pool = nullptr;
     SortedRec *d_sorted = nullptr;  // cap_hits records (read through SortedView: 24 or 16 bytes per record)
     uint32_t sorted_stride = 6;
@@ -259,14 +259,15 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
 
     {
-        // persistent workgroups, 4 per CU (one wavefront of each per SIMD)
-        const uint32_t blocks = (uint32_t) ctx->num_cus * (use_uv ? (uint32_t) O2V_K2_WAVES_UV : (uint32_t) O2V_K2_WAVES);
+        // persistent workgroups: four wavefronts per SIMD, in workgroups of VoxShape<UV>::block threads
         if (use_uv) {
-            hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
+            const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES_UV * (kBlock / VoxShape<true>::block);
+            hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         else {
-            hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_tiles,
+            const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
+            hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         O2V_STAGE("k_voxelize");
@@ -863,7 +864,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
     if (!ctx->d_jobq)
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) (O2V_K2_WAVES > O2V_K2_WAVES_UV ? O2V_K2_WAVES : O2V_K2_WAVES_UV) * kQueueCap * sizeof(uint2)));
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) (O2V_K2_WAVES > O2V_K2_WAVES_UV ? O2V_K2_WAVES : O2V_K2_WAVES_UV) * (kBlock / 64u) * (64u * 64u) * sizeof(uint2)));  // = workgroups x VoxShape::queue for every shape
 
     // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
     uint64_t want_leaves = std::max<uint64_t>(ctx->cap_leaves, ctx->n_tris + ctx->n_tris / 4 + (1u << 16));

@@ -254,7 +254,7 @@ __device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, floa
     RowClip rc{(float) xlo + 0.5f, (float) xhi + 0.5f, true};
     const V3 e0 = p1 - p0, e1 = p2 - p1, e2 = p0 - p2;
     {
-        // plane axis n = e0 x e1: |n . (c - p0)| <= h |n|_1 + err, with sat_may_overlap's error bound for the farthest voxel
+        // plane axis n = e0 x e1: |n . (c - p0)| <= h |n|_1 + err, with an error bound (see above) for the farthest voxel
         const V3 n = cross(e0, e1);
         const float rest = n.y * (cy - p0.y) + n.z * (cz - p0.z) - n.x * p0.x;  // n . (c - p0) = n.x cx + rest
         const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
@@ -388,20 +388,22 @@ struct VoxShape {
 constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf straddles at least this many voxel planes is queued first
 
 // K2.  Persistent workgroups pull batches of tiles.  Per batch:
-//   phase 1  every candidate voxel of the tiles: decode, plane-distance cull (voxelization.cpp:451-458), SAT
-//            pre-test; survivors become 8-byte job records (position, tile slot, planes the leaf straddles) in the
-//            workgroup's queue in global memory, jobs that straddle many planes (the long ones) first
+//   phase 1  the tiles' candidate rows: the separating-axis test solved for x per row (row_span), the rows' survivors
+//            flattened over the lanes, plane-distance cull (voxelization.cpp:451-458); survivors become 8-byte job
+//            records (position, tile slot, planes the leaf straddles) in the workgroup's queue in global memory, jobs
+//            that straddle many planes (the long ones) first
 //   phase 2  persistent lanes fetch their next job one ahead and run computeTrianglesUvInVoxel (voxelization.cpp:383-424) as a
 //            depth-first walk of the split tree: the reference clips level by level with two 64-entry buffers;
 //            visiting the first emitted piece first reproduces its buffer order, so the running mean of
 //            :414-420 accumulates in the identical sequence.  Under DISCARD every split keeps <= 2 pieces, so at
-//            most one sibling per level 1..5 is pending (register stack with a scratch overflow).  Every piece carries the set of planes it
-//            does not pass whole (piece_masks); per iteration a lane classifies its piece against the first of them
-//            and cuts it, and the kept pieces are judged at once from their bounding boxes: final (accumulated),
-//            beyond a later plane (dropped with its whole subtree), or to be cut again.  So lanes spend their
-//            iterations on cuts only (5.9 per voxel job on the bench mesh; 8.4 events before); lanes that run out of
-//            pieces pop the next survivor, so the wavefront stays full.
-// Register budget: 4 waves per SIMD for both variants (120 VGPRs without uv arithmetic; with it the allocator spills two
+//            most one sibling per level 1..5 is pending (register stack with a scratch overflow).  Every piece carries
+//            the set of planes it does not pass whole (piece_masks); per iteration a lane classifies its piece against
+//            the first of them and cuts it, and the kept pieces are judged at once from their bounding boxes: final
+//            (accumulated), beyond a later plane (dropped with its whole subtree), one plane left (without uv: settled
+//            from its classification, see single_plane), or to be cut again.  So lanes spend their iterations only on
+//            cuts whose pieces are needed (3.8 per voxel job on the bench mesh; 5.9 before the single-plane rule, 8.4
+//            events before the masks); lanes that run out of pieces pop the next survivor, so the wavefront stays full.
+// Register budget: 4 waves per SIMD for both variants (125 VGPRs without uv arithmetic; with it the allocator spills two
 // dozen cold values - measured faster than 3 waves without spills on the large textured workloads: configs[3] 31.5 ->
 // 30.1 ms).  5 waves without uv (96 VGPRs, 16 spilled) measured the same as 4.
 #ifndef O2V_K2_WAVES
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
     if (expand_overflowed(c, p)) return;
     const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
-    // Batch size: about kBatchesPerBlock batches per workgroup, between one tile per wavefront and what the LDS staging holds.  Few
+    // Batch size: about kBatchesPerBlock batches per workgroup (VoxShape), between one tile per wavefront and what the LDS staging holds.  Few
     // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
     // of the machine busy); many small ones pay the per-batch staging and barriers too often.  Measured on seven
     // workload shapes.

@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void k_pick(const HitRec *__restrict__ pool
 
 constexpr uint32_t kEmitBricksPerWave = 2;
 constexpr uint32_t kEmitBricksPerRound = (kBlock / 64) * kEmitBricksPerWave * kBricksPerLoad;
-constexpr uint32_t kEmitFlushAt = 1024;  // 48 KiB of staging: three workgroups per CU keep enough 2 KiB brick loads in flight
+constexpr uint32_t kEmitFlushAt = 1024;  // 48 KiB of staging: three workgroups per CU keep enough brick loads (2 KiB per wavefront) in flight
                                          // (2048 / two workgroups: 0.15 ms on the bench mesh, this: 0.12; 512 / four: 0.16)
 constexpr uint32_t kEmitCap = kEmitFlushAt + kEmitBricksPerRound * kBrickCells;
 

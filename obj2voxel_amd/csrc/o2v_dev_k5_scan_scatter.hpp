@@ -5,7 +5,7 @@
 
 // ---- K5a: scan + compact + reset ---------------------------------------------------------------------------
 // Two steps.  k_scan_flags streams the one-byte-per-brick dirty map (n_bricks bytes, 4 MiB at 1024^3), lists the
-// dirty bricks and clears their flags.  k_scan_bricks then reads only those bricks (1 KiB each, one 16-byte load
+// dirty bricks and clears their flags.  k_scan_bricks then reads only those bricks (four cells = one 16-byte load
 // per lane), compacts the occupied cells into `occ` through an LDS staging buffer (one global atomic per flush,
 // not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.
 
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uin
     if (n) flush(n);
 }
 
-constexpr uint32_t kScanBricksPerWave = 4;                                   // independent 1 KiB loads in flight per wave
+constexpr uint32_t kScanBricksPerWave = 4;                                   // independent 1 KiB loads (four bricks each) in flight per wave
 constexpr uint32_t kScanBricksPerRound = (kBlock / 64) * kScanBricksPerWave * kBricksPerLoad;  // 4096 cells per block round
 constexpr uint32_t kScanFlushAt = 2048;
 constexpr uint32_t kScanCap = kScanFlushAt + kScanBricksPerRound * kBrickCells;

@@ -4,7 +4,7 @@
 // translation unit: the stages share records and launch parameters).  Not a stand-alone header.
 
 // ---- K5a: scan + compact + reset ---------------------------------------------------------------------------
-// Two steps.  k_scan_flags streams the one-byte-per-brick dirty map (n_bricks bytes, 4 MiB at 1024^3), lists the
+// Two steps.  k_scan_flags streams the one-byte-per-brick dirty map (n_bricks bytes, 16 MiB at 1024^3), lists the
 // dirty bricks and clears their flags.  k_scan_bricks then reads only those bricks (four cells = one 16-byte load
 // per lane), compacts the occupied cells into `occ` through an LDS staging buffer (one global atomic per flush,
 // not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.

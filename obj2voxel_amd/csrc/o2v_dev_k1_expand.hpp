@@ -170,7 +170,10 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
     // One reservation (a handful of global atomics on the same few addresses, which serialise at ~88 per us) per
     // kRootBatch sub-batches of 256 triangles: the sub-batches are classified twice - first only to count what they
     // emit, then, with the slots known, to write it.
-    constexpr uint32_t kRootBatch = 4;
+#ifndef O2V_ROOT_BATCH
+#define O2V_ROOT_BATCH 3
+#endif
+    constexpr uint32_t kRootBatch = O2V_ROOT_BATCH;
     const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
     const uint64_t n_super = (n_blocks + kRootBatch - 1) / kRootBatch;
 

@@ -190,6 +190,9 @@ def report(args, n, run, dv, comm):
             prof = json.load(open(PROFILE_SUMMARY))
         except Exception:
             prof = None
+    ref_stats = (prof or {}).get("workload_stats") or {}
+    if prof and ref_stats and (ref_stats.get("triangles"), ref_stats.get("jobs")) != (st.get("triangles"), st.get("jobs")):
+        prof = None   # --resolution / --nv changed the workload: the counters were not measured on this one
     kern = (prof or {}).get("kernels", {})
 
     # ---- per-stage accounting: algorithmic bytes per launch and measured HBM traffic (PMC) ------
@@ -244,6 +247,23 @@ def report(args, n, run, dv, comm):
                 "algorithmic_bytes": dom["algorithmic_bytes"], "kernel_ms": dom["ms"]}
     roofline = hbm_view
     sq = kern.get(dom_kernel, {}).get("sq") if kern else None
+    if dom["stage"] == "voxelize" and not sq:
+        # Not the profiled workload (N > 1, another mesh): the kernel is bound the same way, by instruction issue; its
+        # instruction count is estimated from the profiled one in proportion to the voxel jobs (labelled as an estimate).
+        try:
+            ref = json.load(open(PROFILE_SUMMARY))
+            ref_sq = ref["kernels"]["k_voxelize<false>"]["sq"]
+            ref_jobs = ref["workload_stats"]["jobs"]
+            if ref_jobs and st.get("jobs"):
+                scale = st["jobs"] / ref_jobs
+                ginstr = ref_sq["SQ_INSTS_VALU"] * scale / (dom["ms"] * 1e-3) / 1e9
+                roofline = {"bound": "valu", "kernel": dom_kernel, "achieved": round(ginstr, 1), "peak": VALU_PEAK_GINSTR,
+                            "unit": "G wave64-instr/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 4), "estimated": True,
+                            "valu_instructions_per_launch": int(ref_sq["SQ_INSTS_VALU"] * scale), "traffic": None, "kernel_ms": dom["ms"],
+                            "source": "SQ_INSTS_VALU of the profiled N = 1 bench workload (profiles/current.json) x this rank's "
+                                      "voxel jobs / that workload's voxel jobs"}
+        except Exception:
+            pass
     if dom["stage"] == "voxelize" and sq and sq.get("SQ_INSTS_VALU"):
         # The clip loop is float32 VALU work: what bounds it is the rate at which the SIMDs issue wave64 VALU instructions
         # (one per 2 cycles per SIMD), not HBM.  Instruction count: rocprofv3 --pmc SQ_INSTS_VALU of this command
@@ -277,6 +297,8 @@ def report(args, n, run, dv, comm):
                                                              "plan_ms_rank0": round(stages_ms["plan_ms"], 4),
                                                              "collective_ms_rank0": round(stages_ms["collective_ms"], 4)}},
         "roofline": roofline, "roofline_hbm_view": hbm_view if roofline is not hbm_view else None, "stages": stages, "pipeline": pipeline,
+        "stats": {k: int(st[k]) for k in ("triangles", "leaves", "tiles", "candidates", "jobs", "hits", "voxels", "bricks", "dirty_bricks")
+                  if k in st},
     }
     if n == 1 and not args.no_capi:
         out["capi_wall"] = capi_wall(nv, res)

@@ -95,6 +95,10 @@ for w in ("config2", "config2_blend", "config1", "config3"):
 if "config2" in summary:
     cur = {"source": f"profiles/{rnd}/config2_profile.json (rocprofv3 passes of `python bench.py --no-cpu-baseline --no-capi`)",
            "kernels": summary["config2"]["kernels"]}
+    # device statistics of the profiled workload (bench.py uses `jobs` to scale the instruction count to other workloads)
+    stats = (summary["config2"].get("result_line") or {}).get("stats")
+    if stats:
+        cur["workload_stats"] = stats
     json.dump(cur, open("profiles/current.json", "w"), indent=1)
 for extra in ("predict_scaling_8_weak.jsonl", "predict_scaling_8_config4.jsonl"):
     if os.path.exists(os.path.join(src, extra)):

@@ -703,6 +703,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
         }
         __syncthreads();
         const uint32_t n = s_n;
+        __syncthreads();  // (every thread has read n before anyone adds to s_n again: the decision below must be uniform)
         if (n >= kEmitFlushAt) flush(n);
     }
     __syncthreads();

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uin
         }
         __syncthreads();
         const uint32_t n = s_n;
+        __syncthreads();  // (every thread has read n before anyone adds to s_n again: the decision below must be uniform)
         if (n > kFlushAbove) flush(n);  // (the next round may add kRoundMax more)
     }
     const uint32_t n = s_n;

@@ -51,7 +51,17 @@ typedef struct {
     uint32_t bounds_known;     /* 1: use bounds[] (obj2voxel_set_mesh_boundaries), 0: reduce them on the device */
     float bounds[6];           /* min xyz, max xyz */
     uint32_t z_begin, z_end;   /* this GPU's slab of output z, [z_begin, z_end); 0,0 = the whole grid */
+    uint32_t flags;            /* O2V_HIP_FLAG_*; 0 = the product's defaults */
 } o2v_hip_params;
+
+/* o2v_hip_params::flags.
+ * EXACT_CLIP: switches off every piece of work-removal logic in the clip kernel that is not the reference's own
+ * arithmetic (the separating-axis row test, the bounding-box plane masks with their margins, the single-plane rule): every
+ * candidate voxel of a leaf's clamped AABB is tested as reference src/voxelization.cpp:446-470 does (plane-distance cull,
+ * then all six planes through the classification of splitTriangle, :190-232).  Slower, results must be identical: the
+ * tests run both on the device and compare (tests/test_gpu_exact_ab.py).  Also forced by O2V_EXACT_CLIP=1 in the
+ * environment. */
+enum { O2V_HIP_FLAG_EXACT_CLIP = 1u };
 
 /* Per-stage device times of the last o2v_hip_voxelize call, measured with hipEvents on the pipeline's stream. */
 typedef struct {

@@ -3,6 +3,7 @@
 
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -35,12 +36,19 @@ RcclApi *rccl_api()
         // A process that already carries an RCCL must keep using that one: torch ships its own copy under the plain
         // name "librccl.so", and dlopen by that name returns the loaded object.  RTLD_LOCAL: the symbols of whatever is
         // loaded here must not capture the nccl* references of libraries loaded later.
+        // O2V_RCCL_LIB=<path or soname>: load that library instead (also how the tests force the failure path)
+        const char *forced = std::getenv("O2V_RCCL_LIB");
+        std::string last_error;
         for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+            if (forced && forced[0]) name = forced;
             api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
+            const char *e = dlerror();  // (one call: dlerror() clears the state it returns)
+            last_error = e ? e : "unknown error";
+            if (forced && forced[0]) break;
         }
         if (!api.handle) {
-            api.err = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "unknown error");
+            api.err = std::string("librccl could not be loaded: ") + last_error;
             return;
         }
         bool ok = true;

@@ -289,8 +289,10 @@ __device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, floa
 //         nothing before.  The margin (out_margin) is eight times that plus twice the 2^-16 planarity band.  The piece is
 //         dropped at once.
 //   near  planes the piece does not pass whole by more than the same margin (a superset of fail), see single_plane.
-// All are only computed for jobs whose leaf has all |coordinates| < 8192 (`small`; false for NaN too); other jobs get
-// fail = near = planes, out = 0, i.e. every plane is classified, which is always exact.
+// All are only computed for jobs whose leaf has all |coordinates| < 8192 (`small`; false for NaN too, and for every leaf
+// in exact mode, Params::exact_clip); other jobs get fail = near = planes, out = 0, i.e. every plane is classified, which
+// is always exact (single_plane then only fires at the last plane, hi z, where no later plane exists and the number of
+// kept pieces is the classification's by definition).
 constexpr float kSmallCoord = 8192.0f;
 
 // (once per staged leaf: q = its nine vertex coordinates; m = the largest |coordinate|)
@@ -534,7 +536,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             my_count = rem < kTileSize ? rem : kTileSize;
             // bit 31: every coordinate of the leaf is finite and below kSmallCoord (see piece_masks)
             float m;
-            const bool is_small = leaf_is_small(lf, m);
+            // (exact mode, O2V_HIP_FLAG_EXACT_CLIP: no leaf is `small`, so neither row_span nor the piece masks are used)
+            const bool is_small = leaf_is_small(lf, m) && !p.exact_clip;
             s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u);
             s_margin[threadIdx.x] = out_margin(m);
             s_inv_dx[threadIdx.x] = 1.0f / (float) dx;

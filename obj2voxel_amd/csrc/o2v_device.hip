@@ -777,6 +777,10 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
     for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];
     p.has_uv = ctx->d_uvs ? 1u : 0u;
+    {
+        const char *exact = std::getenv("O2V_EXACT_CLIP");
+        p.exact_clip = ((params->flags & O2V_HIP_FLAG_EXACT_CLIP) || (exact && exact[0] == '1')) ? 1u : 0u;
+    }
     const bool use_uv = ctx->d_uvs && ctx->any_textured;
     ctx->sorted_stride = use_uv ? 6u : 4u;
 

@@ -12,7 +12,10 @@ STRATEGY_MAX, STRATEGY_BLEND = 0, 1
 class _Params(C.Structure):
     _fields_ = [("resolution", C.c_uint32), ("supersampling", C.c_uint32), ("strategy", C.c_uint32),
                 ("unit_transform", C.c_int32 * 9), ("bounds_known", C.c_uint32), ("bounds", C.c_float * 6),
-                ("z_begin", C.c_uint32), ("z_end", C.c_uint32)]
+                ("z_begin", C.c_uint32), ("z_end", C.c_uint32), ("flags", C.c_uint32)]
+
+
+FLAG_EXACT_CLIP = 1  # o2v_hip_params::flags: the clip kernel without its work-removal shortcuts (include/o2v_hip.h)
 
 
 class _Texture(C.Structure):
@@ -144,8 +147,9 @@ class DeviceVoxelizer:
                     "o2v_hip_set_textures")
 
     @staticmethod
-    def _params(resolution, supersampling, strategy, unit_transform, bounds, zslab):
+    def _params(resolution, supersampling, strategy, unit_transform, bounds, zslab, flags=0):
         p = _Params()
+        p.flags = flags
         p.resolution, p.supersampling, p.strategy = resolution, supersampling, strategy
         ut = (1, 0, 0, 0, 1, 0, 0, 0, 1) if unit_transform is None else tuple(int(x) for x in np.ravel(unit_transform))
         p.unit_transform = (C.c_int32 * 9)(*ut)
@@ -165,8 +169,8 @@ class DeviceVoxelizer:
         return [int(z) for z in cuts], bnd
 
     def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
-                 zslab=(0, 0), read=True):
-        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, zslab)
+                 zslab=(0, 0), read=True, exact_clip=False):
+        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, zslab, FLAG_EXACT_CLIP if exact_clip else 0)
         n = C.c_uint64(0)
         self._check(self._L.o2v_hip_voxelize(self._ctx, C.byref(p), C.byref(n)), "o2v_hip_voxelize")
         self.count = n.value

@@ -136,3 +136,60 @@ def sorted_voxels(vox):
     key = (vox[:, 2].astype(np.uint64) << np.uint64(42)) | (vox[:, 1].astype(np.uint64) << np.uint64(21)) \
         | vox[:, 0].astype(np.uint64)
     return vox[np.argsort(key, kind="stable")]
+
+
+def stress_soup(kind, T, S, seed=0, z_range=None):
+    """Large random triangle soups in VOXEL coordinates of an S^3 sample grid, for the fast-vs-exact comparison of the clip
+    kernel (tests/test_gpu_exact_ab.py) and bench routes.  Use together with `stress_bounds(S)`, under which the mesh
+    transform (reference obj2voxel.cpp:370-402) is x -> x + 0.5 up to rounding.  Vectorised; float64 -> float32 once.
+
+    kind: "small"   triangles of 0.3 .. 8 voxels, any orientation
+          "sliver"  5 .. 120 voxels long, 0.001 .. 0.5 voxels wide (subdivision, near-degenerate normals)
+          "huge"    like "small" plus 300 (at 1024^3; fewer above) polygons of up to S/2 voxels, a third of them axis-aligned
+          "planar"  vertices on integer voxel planes or a few 2^-16 beside them (the splitter's planar cases and epsilon)
+          "mixed"   a quarter of each
+    z_range: (z0, z1) in voxels to confine the triangle centres to (for z-slab runs), default the whole grid.
+    """
+    rng = np.random.default_rng(seed)
+    if kind == "mixed":
+        parts = [stress_soup(k, T // 4, S, seed * 4 + i + 1, z_range) for i, k in enumerate(("small", "sliver", "huge", "planar"))]
+        v = np.concatenate(parts)
+        return v[np.random.default_rng(seed).permutation(len(v))]
+    lo = np.array([2.0, 2.0, 2.0 if z_range is None else z_range[0]])
+    hi = np.array([S - 2.0, S - 2.0, S - 2.0 if z_range is None else z_range[1]])
+    c = lo + (hi - lo) * rng.random((T, 1, 3))
+    if kind in ("small", "huge"):
+        size = np.exp(rng.uniform(np.log(0.3), np.log(8.0), size=(T, 1, 1)))
+        v = c + size * (rng.random((T, 3, 3)) - 0.5)
+        if kind == "huge":
+            n = max(20, int(300 * (1024.0 / S) ** 2))  # about the same number of voxels at every resolution
+            big = c[:n] + (S / 2.0) * (rng.random((n, 3, 3)) - 0.5)
+            for i in range(0, n, 3):
+                big[i][:, rng.integers(0, 3)] = np.round(c[i, 0, 0])  # lies in a voxel plane
+            v[:n] = big
+    elif kind == "sliver":
+        d = rng.normal(size=(T, 1, 3))
+        d /= np.linalg.norm(d, axis=2, keepdims=True)
+        e = rng.normal(size=(T, 1, 3))
+        e -= d * np.sum(d * e, axis=2, keepdims=True)
+        e /= np.linalg.norm(e, axis=2, keepdims=True)
+        length = np.exp(rng.uniform(np.log(5.0), np.log(120.0), size=(T, 1, 1)))
+        width = np.exp(rng.uniform(np.log(1e-3), np.log(0.5), size=(T, 1, 1)))
+        t = np.stack([np.full(T, -0.5), np.full(T, 0.5), rng.uniform(-0.5, 0.5, size=T)], axis=1)[:, :, None]
+        s = np.stack([np.zeros(T), np.zeros(T), np.ones(T)], axis=1)[:, :, None]
+        v = c + d * length * t + e * width * s
+    elif kind == "planar":
+        k = np.round(c) + rng.integers(-3, 4, size=(T, 3, 3))
+        noise = rng.choice([0.0, 0.0, 1e-6, -1e-6, 1.4e-5, -1.4e-5, 1.7e-5, -1.7e-5, 3e-4, 0.25, 0.5], size=(T, 3, 3))
+        v = k - 0.5 + noise
+        flat = np.arange(0, T, 5)
+        ax = rng.integers(0, 3, size=len(flat))
+        v[flat, :, ax] = v[flat, 0, ax][:, None]  # triangles lying in one voxel plane
+    else:
+        raise ValueError(kind)
+    return np.clip(v, 0.0, S - 1.0).astype(np.float32).reshape(-1, 9)
+
+
+def stress_bounds(S):
+    """User bounds that make the mesh transform x -> x + 0.5 (up to rounding) on an S^3 sample grid."""
+    return [-0.25] * 3 + [S - 0.75] * 3

@@ -1,0 +1,109 @@
+"""Fast vs. exact clip kernel on the device, at GPU scale.
+
+k_voxelize carries the only arithmetic that can change occupancy and is not the reference's: the separating-axis row test
+(row_span), the bounding-box plane masks with their margins (piece_masks) and the single-plane rule
+(obj2voxel_amd/csrc/o2v_dev_k2_voxelize.hpp).  They only remove work - by argument.  O2V_HIP_FLAG_EXACT_CLIP
+(include/o2v_hip.h) switches all of it off: every candidate of a leaf's clamped AABB goes through the plane-distance cull
+and all six planes of splitTriangle's classification, as reference src/voxelization.cpp:383-424,446-470 does.  Here both
+modes run on the same >= 1 M-triangle workloads - far beyond what the CPU oracle reaches in a test - and must produce
+identical (x, y, z, argb) records; a sample of every workload is also compared with the oracle.
+"""
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+pytestmark = pytest.mark.gpu
+
+T_FULL = 1_000_000
+
+# name, soup kind, triangles, resolution, supersampling, strategy, materials, z slab (output layers) or None
+#   materials: "none" = MATERIALLESS (k_voxelize<false>, direct MAX path), "color" = UNTEXTURED, "tex" = a third of the
+#   triangles textured (k_voxelize<true>; with MAX the pick variant), the others coloured / materialless
+WORKLOADS = [
+    ("small_1024_max", "small", 1_200_000, 1024, 1, 0, "none", None),
+    ("sliver_2048_blend", "sliver", T_FULL, 2048, 1, 1, "color", None),
+    ("huge_1024_max_tex", "huge", T_FULL, 1024, 1, 0, "tex", None),
+    ("planar_1024_blend_tex", "planar", T_FULL, 1024, 1, 1, "tex", None),
+    ("mixed_2048_ss2_max", "mixed", T_FULL, 2048, 2, 0, "color", None),
+    ("mixed_4096_slab_blend_tex", "mixed", T_FULL, 4096, 1, 1, "tex", (1792, 2304)),
+    ("planar_1024_ss2_max", "planar", T_FULL, 512, 2, 0, "none", None),
+]
+
+
+def _materials(kind, T, seed):
+    rng = np.random.default_rng(900 + seed)
+    if kind == "none":
+        return {}, []
+    if kind == "color":
+        return dict(types=np.full(T, 2, np.uint32), colors=rng.random((T, 3)).astype(np.float32)), []
+    types = rng.integers(1, 4, size=T).astype(np.uint32)
+    mat = dict(types=types, colors=rng.random((T, 3)).astype(np.float32),
+               uvs=(rng.random((T, 6)) * 2.5 - 0.7).astype(np.float32), texids=rng.integers(0, 2, size=T).astype(np.int32))
+    textures = [(rng.integers(0, 256, size=(37, 53, 3)).astype(np.uint8), 1), (rng.integers(0, 256, size=(16, 8, 4)).astype(np.uint8), 0)]
+    return mat, textures
+
+
+def _subset(mat, idx):
+    return {k: v[idx] for k, v in mat.items()}
+
+
+@pytest.mark.parametrize("name,kind,T,res,ss,strategy,materials,zslab", WORKLOADS, ids=[w[0] for w in WORKLOADS])
+def test_fast_equals_exact(oracle, name, kind, T, res, ss, strategy, materials, zslab):
+    from obj2voxel_amd import hip
+    seed = [w[0] for w in WORKLOADS].index(name)
+    S = res * ss
+    z_range = None if zslab is None else (zslab[0] * ss - 40.0, zslab[1] * ss + 40.0)
+    v = meshes.stress_soup(kind, T, S, seed=seed, z_range=z_range)
+    mat, textures = _materials(materials, len(v), seed)
+    kw = dict(supersampling=ss, strategy=strategy, bounds=meshes.stress_bounds(S))
+    if zslab is not None:
+        kw["zslab"] = zslab
+    d = hip.DeviceVoxelizer(0)   # own context: the grids of the large resolutions are released again
+    try:
+        d.set_textures(textures)
+        d.set_triangles(v, **mat)
+        fast = meshes.sorted_voxels(d.voxelize(res, **kw))
+        st_fast = d.stats()
+        exact = meshes.sorted_voxels(d.voxelize(res, exact_clip=True, **kw))
+        st_exact = d.stats()
+        # the switch really changes the kernel's work: without the row test every candidate of the AABBs is a job candidate
+        assert st_exact["jobs"] > st_fast["jobs"], (st_fast, st_exact)
+        assert st_fast["hits"] == st_exact["hits"], (name, st_fast["hits"], st_exact["hits"])
+        assert len(fast) > 1_000_000, len(fast)
+        assert fast.shape == exact.shape, (name, fast.shape, exact.shape)
+        assert np.array_equal(fast, exact), name
+        # ... and a sample against the oracle (every 40th triangle: what the CPU finishes in seconds)
+        idx = np.arange(0, len(v), 40)
+        d.set_triangles(v[idx], **_subset(mat, idx))
+        got = meshes.sorted_voxels(d.voxelize(res, **kw))
+    finally:
+        d.close()
+    oracle.set_threads(32)
+    try:
+        want = meshes.sorted_voxels(oracle.voxelize(v[idx], res, textures=textures, **_subset(mat, idx), **kw))
+    finally:
+        oracle.set_threads(1)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.array_equal(got, want), name
+
+
+def test_exact_flag_via_environment(monkeypatch):
+    """O2V_EXACT_CLIP=1 forces the same mode for callers that cannot set the flag (obj2voxel_voxelize(), the CLI)."""
+    from obj2voxel_amd import hip
+    v = meshes.stress_soup("mixed", 40_000, 256, seed=11)
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_triangles(v)
+        kw = dict(bounds=meshes.stress_bounds(256))
+        fast = meshes.sorted_voxels(d.voxelize(256, **kw))
+        jobs_fast = d.stats()["jobs"]
+        monkeypatch.setenv("O2V_EXACT_CLIP", "1")
+        exact = meshes.sorted_voxels(d.voxelize(256, **kw))
+        jobs_env = d.stats()["jobs"]
+        monkeypatch.delenv("O2V_EXACT_CLIP")
+        flagged = meshes.sorted_voxels(d.voxelize(256, exact_clip=True, **kw))
+        assert d.stats()["jobs"] == jobs_env > jobs_fast
+    finally:
+        d.close()
+    assert np.array_equal(fast, exact) and np.array_equal(fast, flagged)

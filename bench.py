@@ -14,6 +14,12 @@ deterministic meshes of SURVEY.md section 8d):
              2896, 6.97 M triangles) is timed in the same run and reported under "weak_scaling_companion".
              (--workload weak|config4 overrides the choice for any N > 1.)
 
+N = 1 also times, after the headline, the other routes of the pipeline on their own workloads (obj2voxel_amd/workloads.py:
+the configs[2] mesh coloured with MAX, with BLEND, textured with MAX; the configs[1] and configs[3] stand-ins) and reports them
+under "routes", each with its kernels' live event times and the dominant kernel's fraction of the HBM and VALU-issue peaks.
+If $O2V_ASSETS holds spot.obj / dragon.obj / sponza.obj those are run as well: dragon.obj replaces the
+stand-in as the headline workload (config.workload says so), the others appear under "routes".
+
 One step = one pass of the whole device pipeline over triangles already resident in HBM, the (x, y, z, argb) records left
 in HBM.  N = 1: o2v_hip_voxelize (bounds -> transform -> exact subdivision -> AABB walk + clip -> per-voxel combine ->
 records).  N > 1: one process per GPU (torch.distributed; backend nccl = RCCL), every rank holding the triangle list, and
@@ -35,6 +41,36 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0     # wave64 VALU instructions / ns: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G/s
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "current.json")   # rocprofv3 PMC summary of this command (tools/collect_profiles.py)
+
+
+def load_profile():
+    try:
+        return json.load(open(PROFILE_SUMMARY))
+    except Exception:
+        return None
+
+
+def profile_for(prof, workload, stats=None):
+    """(kernels, stale) of the committed PMC summary for a named workload: `kernels` is None if the summary does not hold
+    the workload or was measured on another mesh; stale = the summary was recorded with a library built from other device
+    sources than the running one (o2v_hip_build_id), i.e. its counters describe other kernels."""
+    if not prof:
+        return None, False
+    entry = prof if workload == "config2" else (prof.get("workloads") or {}).get(workload)
+    if not entry or not entry.get("kernels"):
+        return None, False
+    ref = entry.get("workload_stats") or {}
+    if stats is not None and ref and (ref.get("triangles"), ref.get("voxels")) != (stats.get("triangles"), stats.get("voxels")):
+        return None, False
+    try:
+        from obj2voxel_amd import hip
+        running = hip.build_id()
+    except Exception:
+        running = None
+    stale = bool(prof.get("build_id")) and running is not None and prof["build_id"] != running
+    if not prof.get("build_id"):
+        stale = True   # a summary from before build ids were recorded cannot be matched to a library
+    return entry["kernels"], stale
 
 
 def workload_for(n_gpus, kind="auto"):
@@ -62,6 +98,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-capi", action="store_true", help="skip the obj2voxel_voxelize() wall-time leg")
+    ap.add_argument("--no-routes", action="store_true", help="skip the other routes / assets timed after the headline (N = 1)")
+    ap.add_argument("--route-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise "
                     "the N > 1 code path on a single-GPU box: the collectives then run over host memory)")
     ap.add_argument("--same-device", action="store_true", help="debugging: every rank uses GPU 0 (needs --backend gloo)")
@@ -94,7 +132,7 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
-    from obj2voxel_amd import hip, meshes, slab as slabs
+    from obj2voxel_amd import hip, meshes, slab as slabs, workloads
 
     dv = hip.DeviceVoxelizer(dev_index if n > 1 else 0)
     comm = None
@@ -121,11 +159,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def time_workload(name, res, nv, steps, warmup):
-        verts = meshes.uv_sphere(nv)
-        dv.set_triangles(verts)
+    def time_workload(name, res, nv, steps, warmup, loaded=None):
+        kw, text = {}, None
+        if loaded is not None:     # a real asset (N = 1): (verts, materials, textures, resolution, keywords, description)
+            verts, mat, textures, res, kw, text = loaded
+            dv.set_textures(textures or [])
+            dv.set_triangles(verts, **mat)
+        else:
+            verts = meshes.uv_sphere(nv)
+            dv.set_triangles(verts)
         if n == 1:
-            step = lambda: (dv.voxelize(res, read=False), None)            # noqa: E731
+            step = lambda: (dv.voxelize(res, read=False, **kw), None)            # noqa: E731
         else:
             def step():
                 count, counts, cuts = dv.voxelize_sharded(comm, res, read=False)
@@ -146,15 +190,44 @@ def main():
         elapsed = time.perf_counter() - t0
         total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed,
                                                       device="cuda" if (dist is not None and args.backend == "nccl") else None)
-        return {"name": name, "res": res, "nv": nv, "T": len(verts), "verts": verts, "voxels": total_voxels,
-                "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / steps for k in names}, "stats": dv.stats()}
+        run = {"name": name, "res": res, "nv": nv, "T": len(verts), "verts": verts, "voxels": total_voxels, "text": text, "kw": kw,
+               "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / steps for k in names}, "stats": dv.stats()}
+        if n == 1:
+            # per-kernel times: two further steps with an event pair around every launch (outside the timed region: the
+            # brackets cost a few microseconds per launch)
+            kernels = {}
+            for _ in range(2):
+                dv.voxelize(res, read=False, kernel_times=True, **kw)
+                for k, (ms, launches) in dv.kernel_times().items():
+                    e = kernels.setdefault(k, [0.0, 0])
+                    e[0] += ms
+                    e[1] += launches
+            run["kernels_ms"] = {k: {"ms": round(ms / 2, 4), "launches": launches // 2} for k, (ms, launches) in kernels.items()}
+        return run
 
     name, res, nv = workload_for(n, args.workload)
     if args.resolution:
         res = args.resolution
     if args.nv:
         nv = args.nv
-    main_run = time_workload(name, res, nv, args.steps, args.warmup)
+    loaded = None
+    if n == 1 and not (args.resolution or args.nv) and workloads.asset_path("dragon"):
+        loaded = workloads.load("asset:dragon")      # BASELINE configs[2] names this asset: it is the headline when present
+        name = "asset:dragon"
+    main_run = time_workload(name, res, nv, args.steps, args.warmup, loaded)
+    routes = None
+    if n == 1 and not args.no_routes and not (args.resolution or args.nv):
+        names = list(workloads.BENCH_ROUTES)
+        if loaded is not None:
+            names.insert(0, "config2")               # the stand-in beside the real asset
+        names += [f"asset:{stem}" for stem in ("spot", "sponza") if workloads.asset_path(stem)]
+        prof = load_profile()
+        routes = []
+        for r in names:
+            try:
+                routes.append(route_entry(workloads.run(r, steps=args.route_steps, warmup=2, dv=dv, kernel_steps=2), prof))
+            except Exception as e:   # noqa: BLE001 - a route that cannot run must not take the headline down
+                routes.append({"workload": r, "error": f"{type(e).__name__}: {e}"})
     companion = None
     if n > 1 and name == "config4" and args.workload == "auto":
         main_run["verts"] = None   # 1.8 GB of host memory
@@ -164,6 +237,8 @@ def main():
 
     if rank == 0:
         out = report(args, n, main_run, dv, comm)
+        if routes is not None:
+            out["routes"] = routes
         if companion:
             sec = companion["seconds_per_step"]
             out["weak_scaling_companion"] = {
@@ -180,19 +255,53 @@ def main():
         dist.destroy_process_group()
 
 
+def kernel_view(name, ms, launches, alg_bytes, prof_kernels, stale):
+    """One kernel of a run: live event time, algorithmic bytes, and - from the committed PMC summary of the same workload -
+    measured HBM traffic and VALU instructions, each as a fraction of its peak over the live time."""
+    row = {"kernel": name, "ms": round(ms, 4), "launches": launches, "algorithmic_bytes": alg_bytes,
+           "hbm_frac_algorithmic": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (alg_bytes and ms > 0) else None,
+           "traffic_bytes": None, "hbm_frac_traffic": None, "valu_instructions": None, "valu_frac": None}
+    k = (prof_kernels or {}).get(name)
+    if k and ms > 0:
+        per_step = k.get("launches_per_step", 1) or 1
+        if k.get("hbm_bytes") is not None:
+            row["traffic_bytes"] = int(k["hbm_bytes"] * per_step)
+            row["hbm_frac_traffic"] = round(row["traffic_bytes"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        sq = k.get("sq") or {}
+        if sq.get("SQ_INSTS_VALU"):
+            row["valu_instructions"] = int(sq["SQ_INSTS_VALU"] * per_step)
+            row["valu_frac"] = round(row["valu_instructions"] / (ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4)
+            if sq.get("SQ_THREAD_CYCLES_VALU"):
+                row["active_lane_fraction"] = round(sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_INSTS_VALU"] / 64.0, 3)
+        row["counters"] = "profiles/current.json"
+        if stale:
+            row["stale"] = True   # recorded with a library built from other device sources: not this kernel's counters
+    return row
+
+
+def route_entry(r, prof):
+    """The bench line's entry for one workload run by obj2voxel_amd.workloads.run()."""
+    from obj2voxel_amd import workloads
+    kern, stale = profile_for(prof, r["workload"], r["stats"])
+    alg = workloads.kernel_algorithmic_bytes(r["stats"], r["textured"], r["strategy"] == "BLEND")
+    rows = [kernel_view(k, v["ms"], v["launches"], alg.get(k), kern, stale) for k, v in (r.get("kernels_ms") or {}).items()]
+    rows.sort(key=lambda x: -x["ms"])
+    return {"workload": r["workload"], "what": r["what"], "triangles": r["tris"], "resolution": r["res"], "supersampling": r["supersampling"],
+            "strategy": r["strategy"], "voxels": r["voxels"], "ms_per_step": r["ms"], "mvoxels_per_s": r["mvox_s"], "mtris_per_s": r["mtris_s"],
+            "passes": r["passes"], "stages_ms": r["stages_ms"], "dominant_kernel": rows[0] if rows else None, "top_kernels": rows[:4],
+            "kernels_ms": {x["kernel"]: x["ms"] for x in rows}}
+
+
 def report(args, n, run, dv, comm):
     T, res, nv, V = run["T"], run["res"], run["nv"], run["voxels"]
     sec = run["seconds_per_step"]
     stages_ms, st = run["stages_ms"], run["stats"]
-    prof = None
-    if n == 1 and run["name"] == "config2" and os.path.exists(PROFILE_SUMMARY):   # the committed PMC passes measured this workload
-        try:
-            prof = json.load(open(PROFILE_SUMMARY))
-        except Exception:
-            prof = None
-    ref_stats = (prof or {}).get("workload_stats") or {}
-    if prof and ref_stats and (ref_stats.get("triangles"), ref_stats.get("jobs")) != (st.get("triangles"), st.get("jobs")):
-        prof = None   # --resolution / --nv changed the workload: the counters were not measured on this one
+    prof, stale = None, False
+    if n == 1 and run["name"] == "config2":   # the committed PMC passes measured this workload
+        prof = load_profile()
+        kern_ok, stale = profile_for(prof, "config2", st)
+        if kern_ok is None:
+            prof = None   # --resolution / --nv changed the workload: the counters were not measured on this one
     kern = (prof or {}).get("kernels", {})
 
     # ---- per-stage accounting: algorithmic bytes per launch (DESIGN.md section 4) and measured HBM traffic (PMC) ------
@@ -241,7 +350,8 @@ def report(args, n, run, dv, comm):
 
     # ---- roofline of the dominant kernel ----------------------------------------------------------------------------------
     dom = max(stages, key=lambda r: r["ms"])
-    dom_kernel = "k_voxelize<false>" if dom["stage"] == "voxelize" else "+".join(dom["kernels"])
+    vox_kernel = "k_voxelize<true>" if "k_voxelize<true>" in (run.get("kernels_ms") or {}) else "k_voxelize<false>"
+    dom_kernel = vox_kernel if dom["stage"] == "voxelize" else "+".join(dom["kernels"])
     hbm_view = {"bound": "hbm", "kernel": dom_kernel, "achieved": dom["gbs_algorithmic"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round((dom["gbs_algorithmic"] or 0) / HBM_PEAK_GBS, 5), "traffic": dom["traffic_bytes"],
                 "algorithmic_bytes": dom["algorithmic_bytes"], "kernel_ms": dom["ms"]}
@@ -274,6 +384,11 @@ def report(args, n, run, dv, comm):
                     "active_lane_fraction": round(sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_INSTS_VALU"] / 64.0, 3) if sq.get("SQ_THREAD_CYCLES_VALU") else None,
                     "valu_instructions_per_launch": int(sq["SQ_INSTS_VALU"]), "traffic": dom["traffic_bytes"], "kernel_ms": dom["ms"],
                     "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU: " + (prof or {}).get("source", "profiles/current.json")}
+        if stale:
+            # the summary was recorded with a library built from other device sources (o2v_hip_build_id differs): the count is
+            # another kernel's - kept for orientation, labelled, to be re-measured (tools/profile_all.sh)
+            roofline["stale"] = True
+            roofline["estimated"] = True
     measured_total = sum(r["traffic_bytes"] for r in stages if r["traffic_bytes"]) if kern else None
     # the fixed whole-pipeline numerator of SURVEY.md section 8d (a dense 32-bit grid cleared and compacted): 8*G^3 + 16*V + 76*T.
     # The bricked grid touches only the dirty bricks, so this is a figure of merit for the design, not a bandwidth measurement.
@@ -291,7 +406,7 @@ def report(args, n, run, dv, comm):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "mtris_per_s": round(T / sec / 1e6, 2),
-        "config": {"workload": WORKLOAD_TEXT[run["name"]].format(nv=nv, T=T, res=res, n=n), "resolution": res, "triangles": T,
+        "config": {"workload": run.get("text") or WORKLOAD_TEXT[run["name"]].format(nv=nv, T=T, res=res, n=n), "resolution": res, "triangles": T,
                    "voxels": V, "parallelism": f"zslab{n}",
                    "collectives": None if comm is None else {"backend": comm.kind, "world": comm.world,
                                                              "plan_ms_rank0": round(stages_ms["plan_ms"], 4),
@@ -300,10 +415,18 @@ def report(args, n, run, dv, comm):
         "stats": {k: int(st[k]) for k in ("triangles", "leaves", "tiles", "candidates", "jobs", "hits", "voxels", "bricks", "dirty_bricks")
                   if k in st},
     }
+    if run.get("kernels_ms"):
+        out["kernels_ms"] = {k: v["ms"] for k, v in sorted(run["kernels_ms"].items(), key=lambda kv: -kv[1]["ms"])}
+    try:
+        from obj2voxel_amd import hip
+        out["build_id"] = hip.build_id()
+        out["profile_build_id"] = (load_profile() or {}).get("build_id")
+    except Exception:
+        pass
     if n == 1 and not args.no_capi:
-        out["capi_wall"] = capi_wall(nv, res)
+        out["capi_wall"] = capi_wall(467, 1024) if run["name"] != "config2" else capi_wall(nv, res)   # (always the stand-in mesh)
     if n == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(run["verts"], res, V)
+        out["cpu_baseline"] = cpu_baseline(run["verts"], res, V, (run.get("kw") or {}).get("supersampling", 1))
     return out
 
 
@@ -332,7 +455,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(verts, res, expect_voxels):
+def cpu_baseline(verts, res, expect_voxels, supersampling=1):
     """The CPU oracle (a port of the reference algorithm, oracle/o2v_oracle.c) timed on this host's cores on the
     same workload, chunk-parallel like the reference's worker pool: once with one thread (the whole workload), three
     times with one thread per core (median).  Baseline only, not the optimisation target."""
@@ -343,7 +466,7 @@ def cpu_baseline(verts, res, expect_voxels):
     def once(threads):
         oracle.set_threads(threads)
         t0 = time.perf_counter()
-        vox = oracle.voxelize(verts, res)
+        vox = oracle.voxelize(verts, res, supersampling=supersampling)   # (occupancy does not depend on materials)
         return len(vox), time.perf_counter() - t0
 
     once(cores)  # warm-up: page in the library, spawn the thread pool

@@ -60,8 +60,10 @@ typedef struct {
  * candidate voxel of a leaf's clamped AABB is tested as reference src/voxelization.cpp:446-470 does (plane-distance cull,
  * then all six planes through the classification of splitTriangle, :190-232).  Slower, results must be identical: the
  * tests run both on the device and compare (tests/test_gpu_exact_ab.py).  Also forced by O2V_EXACT_CLIP=1 in the
- * environment. */
-enum { O2V_HIP_FLAG_EXACT_CLIP = 1u };
+ * environment.
+ * KERNEL_TIMES: brackets every kernel launch of the pipeline with two HIP events on the stream it is launched on;
+ * o2v_hip_get_kernel_times then returns the per-kernel device times of the call (summed over the launches of one kernel). */
+enum { O2V_HIP_FLAG_EXACT_CLIP = 1u, O2V_HIP_FLAG_KERNEL_TIMES = 2u };
 
 /* Per-stage device times of the last o2v_hip_voxelize call, measured with hipEvents on the pipeline's stream. */
 typedef struct {
@@ -160,6 +162,16 @@ void o2v_release_cached_device_memory(void);
 int o2v_hip_voxels_device_ptr(o2v_hip_ctx *ctx, const uint32_t **out_ptr, uint64_t *out_count);
 
 int o2v_hip_get_timings(const o2v_hip_ctx *ctx, o2v_hip_timings *out);
+/* Per-kernel device times of the last o2v_hip_voxelize call made with O2V_HIP_FLAG_KERNEL_TIMES (else none): up to
+ * max_entries entries are written, *out_count receives how many there are. */
+typedef struct {
+    char name[48];     /* kernel name as rocprofv3 prints it, e.g. "k_voxelize<false>" */
+    float ms;          /* summed over the launches of the call's last pass */
+    uint32_t launches;
+} o2v_hip_kernel_time;
+int o2v_hip_get_kernel_times(const o2v_hip_ctx *ctx, o2v_hip_kernel_time *out, uint32_t max_entries, uint32_t *out_count);
+/* Hash of the device sources this library was built from: profiles record it, bench.py refuses counters of another build. */
+const char *o2v_hip_build_id(void);
 int o2v_hip_get_stats(const o2v_hip_ctx *ctx, o2v_hip_stats *out);
 /* The mesh transform of the last run: row-major 3x3 then translation (reference obj2voxel.cpp:370-402). */
 int o2v_hip_get_transform(const o2v_hip_ctx *ctx, float out12[12]);
@@ -250,6 +262,18 @@ void o2v_hip_cuts_from_histogram(const uint64_t *hist, uint32_t n_bins, uint32_t
                                  uint32_t n_slabs, uint32_t *out_z);
 int o2v_hip_comm_callbacks_selftest(const o2v_hip_comm_callbacks *callbacks, int rank, int world);
 int o2v_hip_group_exchange_selftest(uint32_t n_threads);
+
+/* A triangle file (OBJ with MTL + PNG textures, binary STL; `type` = extension or NULL to take the path's) read by the
+ * library's own readers into the flat host arrays o2v_hip_set_triangles takes - what obj2voxel_voxelize() does with
+ * obj2voxel_set_input_file (reference src/io.cpp:244-312,395-435), without the voxelization.  bench.py uses it to run the
+ * real Spot / Dragon / Sponza assets when $O2V_ASSETS holds them.  Arrays a mesh does not need are NULL; the pointers and
+ * the texture pixels stay valid until o2v_mesh_free. */
+typedef struct o2v_mesh o2v_mesh;
+int o2v_mesh_load_file(const char *path, const char *type, o2v_mesh **out);
+uint64_t o2v_mesh_arrays(const o2v_mesh *mesh, const float **verts, const float **uvs, const uint32_t **types,
+                         const float **colors, const int32_t **texids, uint32_t *n_textures); /* returns the triangle count */
+int o2v_mesh_texture(const o2v_mesh *mesh, uint32_t index, o2v_hip_texture *out);
+void o2v_mesh_free(o2v_mesh *mesh);
 
 /* Debugging aid for kernel work: 16 event counters of the clip loop of the last run.  All zero unless the library was
  * built with -DO2V_INSTRUMENT (make INSTR=1, tools/instrument.sh); the meaning of each slot is documented there. */

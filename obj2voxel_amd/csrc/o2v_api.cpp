@@ -596,7 +596,54 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
 
 // ---- exported API ---------------------------------------------------------------------------------------
 
+// o2v_mesh (include/o2v_hip.h): a triangle file drained into the flat arrays of the device C-ABI by the same readers and the
+// same cache code obj2voxel_voxelize() uses.  The source stays alive: it owns the textures of an OBJ's materials.
+struct o2v_mesh {
+    std::unique_ptr<TriangleSource> source;
+    MeshArrays arrays;
+};
+
 extern "C" {
+
+int o2v_mesh_load_file(const char *path, const char *type, o2v_mesh **out)
+{
+    if (!path || !out) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    const FileFormat f = detect_format(path, type);
+    std::unique_ptr<TriangleSource> src;
+    if (f == FileFormat::OBJ) src = open_obj_file(path, nullptr);
+    else if (f == FileFormat::STL) src = open_stl_file(path);
+    if (!src) return O2V_HIP_ERR_BAD_ARGUMENT;
+    o2v_mesh *m = new o2v_mesh;
+    m->source = std::move(src);
+    while (const HostTriangle *t = m->source->next()) m->arrays.push(*t);
+    *out = m;
+    return O2V_HIP_OK;
+}
+
+void o2v_mesh_free(o2v_mesh *mesh) { delete mesh; }
+
+uint64_t o2v_mesh_arrays(const o2v_mesh *mesh, const float **verts, const float **uvs, const uint32_t **types, const float **colors,
+                         const int32_t **texids, uint32_t *n_textures)
+{
+    if (!mesh) return 0;
+    const MeshArrays &a = mesh->arrays;
+    if (verts) *verts = a.verts.empty() ? nullptr : a.verts.data();
+    if (uvs) *uvs = a.uvs.empty() ? nullptr : a.uvs.data();
+    if (types) *types = a.types.empty() ? nullptr : a.types.data();
+    if (colors) *colors = a.colors.empty() ? nullptr : a.colors.data();
+    if (texids) *texids = a.texids.empty() ? nullptr : a.texids.data();
+    if (n_textures) *n_textures = (uint32_t) a.tex_list.size();
+    return a.n;
+}
+
+int o2v_mesh_texture(const o2v_mesh *mesh, uint32_t index, o2v_hip_texture *out)
+{
+    if (!mesh || !out || index >= mesh->arrays.tex_list.size()) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const obj2voxel_texture *t = mesh->arrays.tex_list[index];
+    *out = o2v_hip_texture{t->pixels.data(), (uint32_t) t->width, (uint32_t) t->height, (uint32_t) t->channels, t->wrap};
+    return O2V_HIP_OK;
+}
 
 obj2voxel_instance *obj2voxel_alloc(void) { return new obj2voxel_instance; }
 

@@ -33,6 +33,10 @@
 #include "o2v_comm.hpp"
 #include "o2v_device_internal.hpp"
 
+#ifndef O2V_BUILD_ID
+#define O2V_BUILD_ID "unknown"  // the Makefile passes the hash of the device sources
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -139,6 +143,16 @@ struct o2v_hip_ctx {
     o2v_hip_stats stats = {};
     float xform[12] = {};
     uint64_t dbg[16] = {};  // Counters::dbg of the last run (instrumented builds only)
+
+    // O2V_HIP_FLAG_KERNEL_TIMES: an event pair around every launch of a pass
+    struct KernelBracket {
+        const char *name = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+    };
+    std::vector<KernelBracket> ktimes;
+    size_t ktimes_used = 0;
+    bool ktimes_on = false;
+    std::vector<o2v_hip_kernel_time> kernel_times;  // of the last run: one entry per kernel name
 };
 
 namespace {
@@ -210,6 +224,31 @@ bool debug_sync_enabled() { return debug_sync_level() != 0; }
         }                                                                        \
     } while (0)
 
+// One kernel launch of the pipeline.  With O2V_HIP_FLAG_KERNEL_TIMES the launch is bracketed by two events on the stream
+// it goes to (o2v_hip_get_kernel_times; the brackets cost a few microseconds per launch, so bench.py times its steps
+// without the flag and collects the per-kernel times in extra steps).
+#define O2V_LAUNCH(name, stream, ...)                                            \
+    do {                                                                         \
+        const int kt_ = ktime_begin(ctx, name, stream);                          \
+        hipLaunchKernelGGL(__VA_ARGS__);                                         \
+        if (kt_ >= 0) (void) hipEventRecord(ctx->ktimes[(size_t) kt_].e1, stream); \
+        O2V_STAGE(name);                                                         \
+    } while (0)
+
+int ktime_begin(o2v_hip_ctx *ctx, const char *name, hipStream_t stream)
+{
+    if (!ctx->ktimes_on) return -1;
+    if (ctx->ktimes_used == ctx->ktimes.size()) {
+        o2v_hip_ctx::KernelBracket b{};
+        if (hipEventCreate(&b.e0) != hipSuccess || hipEventCreate(&b.e1) != hipSuccess) return -1;
+        ctx->ktimes.push_back(b);
+    }
+    o2v_hip_ctx::KernelBracket &b = ctx->ktimes[ctx->ktimes_used];
+    b.name = name;
+    if (hipEventRecord(b.e0, stream) != hipSuccess) return -1;
+    return (int) ctx->ktimes_used++;
+}
+
 float ord2f_host(uint32_t o)
 {
     const uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
@@ -223,33 +262,28 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 {
     hipStream_t s = ctx->stream;
     const uint32_t persistent = (uint32_t) ctx->num_cus * 8u;
+    ctx->ktimes_used = 0;
     O2V_CHECK(hipEventRecord(ctx->ev[0], s));
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
-    O2V_STAGE("k_init");
+    O2V_LAUNCH("k_init", s, k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
     if (!p.bounds_known) {
         // one workgroup per CU: every workgroup ends with six atomics on the same six words, which serialise (1024
         // workgroups: 43 us for 31 MB, 256: 24 us)
-        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
+        O2V_LAUNCH("k_bounds", s, k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
-        O2V_STAGE("k_bounds");
     }
-    hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
-    O2V_STAGE("k_setup");
+    O2V_LAUNCH("k_setup", s, k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
     O2V_CHECK(hipEventRecord(ctx->ev[1], s));
 
-    hipLaunchKernelGGL(k_expand_roots, dim3(std::min<uint64_t>(persistent, (p.n_tris + kBlock - 1) / kBlock)),
+    O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, (p.n_tris + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
                        ctx->d_big, ctx->d_nodes[0], ctx->zrange_generation == ctx->tri_generation ? ctx->d_zrange : nullptr,
                        ctx->d_zrange_xform, p);
-    O2V_STAGE("k_expand_roots");
     for (uint32_t round = 0; round < n_rounds; ++round) {
         // most rounds are empty or small: a narrow grid keeps an empty launch short (the kernel strides over its input)
-        hipLaunchKernelGGL(k_expand_nodes, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
+        O2V_LAUNCH("k_expand_nodes", s, k_expand_nodes, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
-        O2V_STAGE("k_expand_nodes");
     }
-    hipLaunchKernelGGL(k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
-    O2V_STAGE("k_expand_big");
+    O2V_LAUNCH("k_expand_big", s, k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
     O2V_CHECK(hipEventRecord(ctx->ev[2], s));
     if (p.direct_max) {
         // K1's counters go to the host on an auxiliary stream while k_voxelize runs (see below)
@@ -262,15 +296,14 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         // persistent workgroups: four wavefronts per SIMD, in workgroups of VoxShape<UV>::block threads
         if (use_uv) {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES_UV * (kBlock / VoxShape<true>::block);
-            hipLaunchKernelGGL(k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
+            O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         else {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
-            hipLaunchKernelGGL(k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
+            O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
-        O2V_STAGE("k_voxelize");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
 
@@ -287,28 +320,23 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         run_general = !run_emit || h.n_nodes[0] != 0;
         if (run_emit) {
             const uint32_t groups = (p.n_bricks + 15u) / 16u;
-            hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
+            O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
                                dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, ctx->d_ctr, p);
-            O2V_STAGE("k_scan_flags (max)");
         }
     }
 
     if (run_general) {
         const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
-        hipLaunchKernelGGL(k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
+        O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
                            dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, ctx->d_ctr, p);
-        O2V_STAGE("k_scan_flags");
         const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
                                  ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
-        hipLaunchKernelGGL(k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
+        O2V_LAUNCH("k_scan_bricks", s, k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, lists, p);
-        O2V_STAGE("k_scan_bricks");
-        hipLaunchKernelGGL(k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
+        O2V_LAUNCH("k_scatter", s, k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
-        O2V_STAGE("k_scatter");
-        hipLaunchKernelGGL(k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
+        O2V_LAUNCH("k_reset_bricks", s, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr, p);
-        O2V_STAGE("k_reset_bricks");
     }
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
 
@@ -327,37 +355,29 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             for (hipStream_t a : ctx->aux) O2V_CHECK(hipStreamWaitEvent(a, ctx->ev_fork, 0));
         }
         if (use_uv)
-            hipLaunchKernelGGL(k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+            O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
                                ctx->d_out, p);
         else
-            hipLaunchKernelGGL(k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+            O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
                                ctx->d_out, p);
-        O2V_STAGE("k_resolve");
-        hipLaunchKernelGGL(k_resolve_wave<16>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
+        O2V_LAUNCH("k_resolve_wave<16>", sw, k_resolve_wave<16>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
                            &ctx->d_ctr->n_lane16, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_STAGE("k_resolve_wave<16>");
-        hipLaunchKernelGGL(k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane,
+        O2V_LAUNCH("k_resolve_wave<32>", sw, k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane,
                            &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_STAGE("k_resolve_wave<32>");
-        hipLaunchKernelGGL(k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_w64,
+        O2V_LAUNCH("k_resolve_wave<64>", sm, k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_w64,
                            &ctx->d_ctr->n_w64, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_STAGE("k_resolve_wave<64>");
-        hipLaunchKernelGGL((k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 8u), dim3(64), 0, sm,
+        O2V_LAUNCH("k_resolve_sorted<64,256>", sm, (k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 8u), dim3(64), 0, sm,
                            ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
-        O2V_STAGE("k_resolve_sorted");
-        hipLaunchKernelGGL((k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sl,
+        O2V_LAUNCH("k_resolve_sorted<256,2048>", sl, (k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sl,
                            ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
-        O2V_STAGE("k_resolve_sorted");
-        hipLaunchKernelGGL(k_resolve_big, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBigThreads), kBigList * 12u, sl, ctx->d_list_big,
+        O2V_LAUNCH("k_resolve_big", sl, k_resolve_big, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBigThreads), kBigList * 12u, sl, ctx->d_list_big,
                            ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_STAGE("k_resolve_big");
         if (ctx->d_scratch_key) {
-            hipLaunchKernelGGL(k_resolve_huge, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBlock), 0, sl, ctx->d_list_huge,
+            O2V_LAUNCH("k_resolve_huge", sl, k_resolve_huge, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBlock), 0, sl, ctx->d_list_huge,
                                ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, ctx->d_scratch_key,
                                ctx->d_scratch_idx, ctx->cap_scratch, p.cap_vox, p);
-            O2V_STAGE("k_resolve_huge");
         }
         if (fork)
             for (int j = 0; j < 3; ++j) {
@@ -367,20 +387,34 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
     {
         if (run_emit && p.pick_max) {
-            hipLaunchKernelGGL(k_pick, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_ctr, p);
-            O2V_STAGE("k_pick");
+            O2V_LAUNCH("k_pick", s, k_pick, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_ctr, p);
         }
         if (run_emit) {
             // every voxel's winner is in the 64-bit grid now (k_voxelize: unsplit triangles, resolve: the rest)
-            hipLaunchKernelGGL(k_emit_max, dim3((uint32_t) ctx->num_cus * 3u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
+            O2V_LAUNCH("k_emit_max", s, k_emit_max, dim3((uint32_t) ctx->num_cus * 3u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
                                ctx->d_out, p);
-            O2V_STAGE("k_emit_max");
         }
     }
     O2V_CHECK(hipEventRecord(ctx->ev[5], s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipStreamSynchronize(s));
     O2V_CHECK(hipGetLastError());
+    ctx->kernel_times.clear();
+    for (size_t i = 0; i < ctx->ktimes_used; ++i) {
+        const o2v_hip_ctx::KernelBracket &b = ctx->ktimes[i];
+        float ms = 0.f;
+        O2V_CHECK(hipEventElapsedTime(&ms, b.e0, b.e1));
+        auto it = std::find_if(ctx->kernel_times.begin(), ctx->kernel_times.end(),
+                               [&](const o2v_hip_kernel_time &k) { return std::strcmp(k.name, b.name) == 0; });
+        if (it == ctx->kernel_times.end()) {
+            o2v_hip_kernel_time k{};
+            std::snprintf(k.name, sizeof(k.name), "%s", b.name);
+            ctx->kernel_times.push_back(k);
+            it = ctx->kernel_times.end() - 1;
+        }
+        it->ms += ms;
+        it->launches += 1;
+    }
     return O2V_HIP_OK;
 }
 
@@ -540,6 +574,10 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
         if (e) (void) hipEventDestroy(e);
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
+    for (auto &b : ctx->ktimes) {
+        if (b.e0) (void) hipEventDestroy(b.e0);
+        if (b.e1) (void) hipEventDestroy(b.e1);
+    }
     if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_k1) (void) hipEventDestroy(ctx->ev_k1);
     for (int j = 0; j < 3; ++j) {
@@ -780,6 +818,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     {
         const char *exact = std::getenv("O2V_EXACT_CLIP");
         p.exact_clip = ((params->flags & O2V_HIP_FLAG_EXACT_CLIP) || (exact && exact[0] == '1')) ? 1u : 0u;
+        ctx->ktimes_on = (params->flags & O2V_HIP_FLAG_KERNEL_TIMES) != 0;
+        ctx->kernel_times.clear();
     }
     const bool use_uv = ctx->d_uvs && ctx->any_textured;
     ctx->sorted_stride = use_uv ? 6u : 4u;
@@ -1422,6 +1462,17 @@ int o2v_hip_get_timings(const o2v_hip_ctx *ctx, o2v_hip_timings *out)
     *out = ctx->timings;
     return O2V_HIP_OK;
 }
+
+int o2v_hip_get_kernel_times(const o2v_hip_ctx *ctx, o2v_hip_kernel_time *out, uint32_t max_entries, uint32_t *out_count)
+{
+    if (!ctx || !out_count || (max_entries && !out)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    const uint32_t n = (uint32_t) std::min<size_t>(ctx->kernel_times.size(), max_entries);
+    for (uint32_t i = 0; i < n; ++i) out[i] = ctx->kernel_times[i];
+    *out_count = (uint32_t) ctx->kernel_times.size();
+    return O2V_HIP_OK;
+}
+
+const char *o2v_hip_build_id(void) { return O2V_BUILD_ID; }
 
 int o2v_hip_get_stats(const o2v_hip_ctx *ctx, o2v_hip_stats *out)
 {

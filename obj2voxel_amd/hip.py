@@ -15,6 +15,7 @@ class _Params(C.Structure):
                 ("z_begin", C.c_uint32), ("z_end", C.c_uint32), ("flags", C.c_uint32)]
 
 
+FLAG_KERNEL_TIMES = 2  # ... every launch bracketed by events: DeviceVoxelizer.kernel_times()
 FLAG_EXACT_CLIP = 1  # o2v_hip_params::flags: the clip kernel without its work-removal shortcuts (include/o2v_hip.h)
 
 
@@ -38,6 +39,10 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("launches", C.c_uint32)]
 
 
 class DeviceError(RuntimeError):
@@ -82,7 +87,53 @@ def _bind():
     L.o2v_hip_group_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.o2v_hip_group_voxelize.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_void_p, C.c_void_p]
     L.o2v_hip_plan_slabs.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_uint32, C.c_void_p, C.c_void_p]
+    L.o2v_hip_get_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.o2v_hip_build_id.restype = C.c_char_p
+    L.o2v_mesh_load_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.o2v_mesh_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.POINTER(C.c_uint32)]
+    L.o2v_mesh_arrays.restype = C.c_uint64
+    L.o2v_mesh_texture.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_Texture)]
+    L.o2v_mesh_free.argtypes = [C.c_void_p]
     return L
+
+
+def build_id():
+    """Hash of the device sources the loaded library was built from (o2v_hip_build_id)."""
+    return _bind().o2v_hip_build_id().decode()
+
+
+def load_mesh_file(path):
+    """o2v_mesh_load_file: (verts [T, 9], materials dict for set_triangles, textures list for set_textures) of an OBJ / STL
+    file, read by the library's own readers."""
+    L = _bind()
+    h = C.c_void_p()
+    if L.o2v_mesh_load_file(str(path).encode(), None, C.byref(h)) != 0:
+        raise DeviceError(f"o2v_mesh_load_file({path}) failed: unknown type or unreadable file")
+    try:
+        ptrs = [C.c_void_p() for _ in range(5)]
+        ntex = C.c_uint32(0)
+        T = int(L.o2v_mesh_arrays(h, *[C.byref(q) for q in ptrs], C.byref(ntex)))
+
+        def arr(q, ctype, width, dtype):
+            if not q.value or not T:
+                return None
+            return np.ctypeslib.as_array(C.cast(q, C.POINTER(ctype)), shape=(T * width,)).astype(dtype).reshape(T, width).copy()
+        verts = arr(ptrs[0], C.c_float, 9, np.float32)
+        mat = {}
+        for key, q, ctype, width, dtype in (("uvs", ptrs[1], C.c_float, 6, np.float32), ("types", ptrs[2], C.c_uint32, 1, np.uint32),
+                                            ("colors", ptrs[3], C.c_float, 3, np.float32), ("texids", ptrs[4], C.c_int32, 1, np.int32)):
+            a = arr(q, ctype, width, dtype)
+            if a is not None:
+                mat[key] = a.reshape(T) if width == 1 else a
+        textures = []
+        for i in range(ntex.value):
+            t = _Texture()
+            L.o2v_mesh_texture(h, i, C.byref(t))
+            pix = np.ctypeslib.as_array(C.cast(t.pixels, C.POINTER(C.c_uint8)), shape=(t.height, t.width, t.channels)).copy()
+            textures.append((pix, int(t.wrap)))
+        return (np.zeros((0, 9), np.float32) if verts is None else verts), mat, textures
+    finally:
+        L.o2v_mesh_free(h)
 
 
 def device_count():
@@ -169,8 +220,9 @@ class DeviceVoxelizer:
         return [int(z) for z in cuts], bnd
 
     def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
-                 zslab=(0, 0), read=True, exact_clip=False):
-        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, zslab, FLAG_EXACT_CLIP if exact_clip else 0)
+                 zslab=(0, 0), read=True, exact_clip=False, kernel_times=False):
+        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, zslab,
+                         (FLAG_EXACT_CLIP if exact_clip else 0) | (FLAG_KERNEL_TIMES if kernel_times else 0))
         n = C.c_uint64(0)
         self._check(self._L.o2v_hip_voxelize(self._ctx, C.byref(p), C.byref(n)), "o2v_hip_voxelize")
         self.count = n.value
@@ -201,6 +253,13 @@ class DeviceVoxelizer:
         t = Timings()
         self._L.o2v_hip_get_timings(self._ctx, C.byref(t))
         return t.as_dict()
+
+    def kernel_times(self):
+        """{kernel name: (ms, launches)} of the last voxelize(kernel_times=True) call."""
+        buf = (KernelTime * 64)()
+        n = C.c_uint32(0)
+        self._L.o2v_hip_get_kernel_times(self._ctx, buf, 64, C.byref(n))
+        return {buf[i].name.decode(): (float(buf[i].ms), int(buf[i].launches)) for i in range(min(n.value, 64))}
 
     def stats(self):
         s = Stats()

@@ -1,0 +1,63 @@
+"""bench.py on the GPU: the routes of the N = 1 line, per-kernel event times, and the $O2V_ASSETS hook (SURVEY.md section 8d:
+"if $O2V_ASSETS/{spot,dragon,sponza}.obj exist on the GPU box, also run those")."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from obj2voxel_amd import meshes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_obj(path, v):
+    lines = []
+    for t in v:
+        for k in range(3):
+            lines.append("v %r %r %r" % tuple(float(x) for x in t[k * 3:k * 3 + 3]))
+    lines += [f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}" for i in range(len(v))]
+    path.write_text("\n".join(lines) + "\n")
+
+
+def test_kernel_times_cover_the_pipeline():
+    from obj2voxel_amd import hip
+    d = hip.DeviceVoxelizer(0)
+    try:
+        v = meshes.uv_sphere(60)
+        d.set_triangles(v, types=np.full(len(v), 2, np.uint32), colors=meshes.triangle_colors(len(v)))
+        d.voxelize(256, strategy=1, read=False)
+        assert d.kernel_times() == {}                       # only on request
+        d.voxelize(256, strategy=1, read=False, kernel_times=True)
+        kt = d.kernel_times()
+        tm = d.timings()
+    finally:
+        d.close()
+    for k in ("k_bounds", "k_expand_roots", "k_voxelize<false>", "k_scan_bricks", "k_scatter", "k_resolve<4>"):
+        assert k in kt and kt[k][0] > 0 and kt[k][1] >= 1, (k, kt)
+    assert abs(kt["k_voxelize<false>"][0] - tm["voxelize_ms"]) < 0.05 + 0.2 * tm["voxelize_ms"]
+
+
+def test_bench_line_routes_and_assets(tmp_path):
+    _write_obj(tmp_path / "dragon.obj", meshes.uv_sphere(40))
+    _write_obj(tmp_path / "spot.obj", meshes.uv_sphere(16))
+    env = dict(os.environ, O2V_ASSETS=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--route-steps", "1",
+                        "--no-cpu-baseline", "--no-capi"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "dragon.obj" in line["config"]["workload"] and line["config"]["triangles"] == len(meshes.uv_sphere(40))
+    names = [x["workload"] for x in line["routes"]]
+    assert names[0] == "config2" and "asset:spot" in names and "asset:sponza" not in names
+    for want in ("config2_colored_max", "config2_blend", "config2_textured_max", "config1", "config3"):
+        assert want in names
+    for x in line["routes"]:
+        assert "error" not in x, x
+        assert x["ms_per_step"] > 0 and x["voxels"] > 0 and x["dominant_kernel"]["ms"] > 0
+        assert x["dominant_kernel"]["kernel"] in x["kernels_ms"]
+    blend = line["routes"][names.index("config2_blend")]
+    assert {"k_scatter", "k_scan_bricks", "k_resolve<4>"} <= set(blend["kernels_ms"])
+    assert line["build_id"] and "kernels_ms" in line

@@ -11,7 +11,7 @@ import re
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = "gpurun_out/prof"
 out_dir = os.path.join("profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
@@ -42,7 +42,7 @@ def counters(path):
 
 
 summary = {}
-for w in ("config2", "config2_blend", "config1", "config3"):
+for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_max", "config1", "config3"):
     stats = find(f"{src}/{w}_stats/**/s_kernel_stats.csv")
     if not stats:
         continue
@@ -83,7 +83,7 @@ for w in ("config2", "config2_blend", "config1", "config3"):
                        "the bytes of wide coalesced reads; calibrated in round 1 on k_bounds = 36 B x triangles read and "
                        "k_reset_bricks = the dirty bricks written); sq: two --pmc passes of 8 SQ counters, averages per launch "
                        "(SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles).",
-           "workload": w, "command": "python bench.py --no-cpu-baseline --no-capi" if w == "config2" else f"python tools/run_workload.py {w}",
+           "workload": w, "command": "python bench.py --no-cpu-baseline --no-capi --no-routes" if w == "config2" else f"python tools/run_workload.py {w}",
            "result_line": line, "hbm_bytes_per_step_all_kernels": round(step_traffic), "kernels": kernels}
     json.dump(doc, open(os.path.join(out_dir, f"{w}_profile.json"), "w"), indent=1)
     summary[w] = doc
@@ -93,12 +93,31 @@ for w in ("config2", "config2_blend", "config1", "config3"):
             print("   %-30s x%-5s avg %9.1f us  %6.1f MB  %s" % (k, v["launches_per_step"], v["avg_us"], v.get("hbm_bytes", 0) / 1e6,
                                                              ("VALU %.1f M, lanes %.1f" % (v["sq"]["SQ_INSTS_VALU"] / 1e6, v["sq"]["derived"]["active_lanes_per_valu_instruction"])) if "sq" in v else ""))
 if "config2" in summary:
-    cur = {"source": f"profiles/{rnd}/config2_profile.json (rocprofv3 passes of `python bench.py --no-cpu-baseline --no-capi`)",
+    bid_path = os.path.join(src, "build_id.txt")
+    build_id = open(bid_path).read().strip() if os.path.exists(bid_path) else None
+    cur = {"source": f"profiles/{rnd}/config2_profile.json (rocprofv3 passes of `python bench.py --no-cpu-baseline --no-capi --no-routes`)",
+           # hash of the device sources of the profiled library (o2v_hip_build_id): bench.py labels these counters stale if
+           # the running library was built from other sources
+           "build_id": build_id,
            "kernels": summary["config2"]["kernels"]}
     # device statistics of the profiled workload (bench.py uses `jobs` to scale the instruction count to other workloads)
     stats = (summary["config2"].get("result_line") or {}).get("stats")
     if stats:
         cur["workload_stats"] = stats
+    # the other routes (tools/run_workload.py NAME): only what bench.py reads, per kernel
+    keep = ("launches_per_step", "avg_us", "hbm_bytes", "fetch_size_raw_bytes", "write_size_bytes")
+    cur["workloads"] = {}
+    for w, doc in summary.items():
+        if w == "config2":
+            continue
+        ks = {}
+        for k, v in doc["kernels"].items():
+            e = {f: v[f] for f in keep if f in v}
+            if "sq" in v:
+                e["sq"] = {c: v["sq"][c] for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY") if c in v["sq"]}
+            ks[k] = e
+        cur["workloads"][w] = {"source": f"profiles/{rnd}/{w}_profile.json", "kernels": ks,
+                               "workload_stats": (doc.get("result_line") or {}).get("stats")}
     json.dump(cur, open("profiles/current.json", "w"), indent=1)
 for extra in ("predict_scaling_8_weak.jsonl", "predict_scaling_8_config4.jsonl"):
     if os.path.exists(os.path.join(src, extra)):

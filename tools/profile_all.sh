@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage: tools/profile_all.sh [workload ...]   (default: every profiled workload)
 # Runs on the GPU box: every rocprofv3 pass the committed summaries under profiles/<round>/ are made from
 # (tools/collect_profiles.py turns gpurun_out/prof/ into profiles/).  Counter passes use --kernel-trace only, one counter
 # family per pass.  Workloads: the bench command itself (BASELINE configs[2], direct MAX route) and the general route
@@ -10,8 +11,9 @@ OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 SQ1="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"
 SQ2="SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"
-for W in config2 config2_blend config1 config3; do
-  if [ $W = config2 ]; then CMD="python bench.py --no-cpu-baseline --no-capi"; S1="--steps 20 --warmup 3"; S2="--steps 3 --warmup 1"
+WL="${@:-config2 config2_colored_max config2_blend config2_textured_max config1 config3}"
+for W in $WL; do
+  if [ $W = config2 ]; then CMD="python bench.py --no-cpu-baseline --no-capi --no-routes"; S1="--steps 20 --warmup 3"; S2="--steps 3 --warmup 1"
   else CMD="python tools/run_workload.py $W"; S1="--steps 10 --warmup 2"; S2="--steps 3 --warmup 1"; fi
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_stats -o s -- $CMD $S1 > $OUT/${W}_stats.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -22,7 +24,8 @@ for W in config2 config2_blend config1 config3; do
   grep "^{" $OUT/${W}_stats.log | tail -1 > $OUT/${W}_line.json
 done
 # the bench line itself (with the CPU baseline and the C API wall time), unprofiled
-timeout -k 5 600 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+python -c "from obj2voxel_amd import hip; print(hip.build_id())" > $OUT/build_id.txt
+timeout -k 5 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 # predicted multi-GPU balance (one GPU runs the planned slabs of the N = 8 jobs one after the other)
 timeout -k 5 200 python tools/predict_scaling.py 8 weak > $OUT/predict_scaling_8_weak.jsonl 2>&1
 timeout -k 5 400 python tools/predict_scaling.py 8 config4 > $OUT/predict_scaling_8_config4.jsonl 2>&1

@@ -144,6 +144,10 @@ struct Params {
     float bounds[6];
     int32_t unit[9];
     uint32_t has_uv;
+    // Occupancy-only mode: every triangle is MATERIALLESS, so every voxel's colour is white whatever the weights are (MAX
+    // picks one white, BLEND computes (w1 * 1 + w2 * 1) / (w1 + w2) = s / s = 1 exactly) and only the set of voxels with a
+    // non-zero weight matters: a voxel job ends at its first surviving piece and every hit takes the direct path.
+    uint32_t occupancy_only;
     uint32_t exact_clip;   // O2V_HIP_FLAG_EXACT_CLIP: no work-removal shortcuts in k_voxelize (every leaf is treated as not `small`)
     // Direct MAX path (MAX strategy, no textured triangle; section 4 of DESIGN.md): one 64-bit cell per output voxel that
     // holds max over {weight bits << 32 | ~(sub-voxel << 29 | triangle)}, and its own dirty-brick map.
@@ -174,7 +178,7 @@ __device__ __forceinline__ bool expand_overflowed(const Counters *c, const Param
 // identically by every kernel of the pass (and by the host afterwards).
 __device__ __forceinline__ bool direct_active(const Counters *c, const Params &p)
 {
-    return p.direct_max && c->n_nodes[0] <= c->n_root_leaves;
+    return p.direct_max && (p.occupancy_only || c->n_nodes[0] <= c->n_root_leaves);
 }
 __device__ __forceinline__ bool pass_overflowed(const Counters *c, const Params &p)
 {

@@ -465,11 +465,15 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
     // voxel (the long ones) are filed from the front, the others from the back, and the queue is served front to back:
     // longest jobs first keeps the end of a sub-batch, when lanes run out of work, short.
     uint2 *jobq = jobq_all + (size_t) blockIdx.x * kQueueCap;
+    __shared__ uint32_t s_next_x[kVoxBlock], s_next_y[kVoxBlock];  // every lane's prefetched next job record (take_job)
     __shared__ uint8_t s_cls[64];    // classify_flags
     __shared__ uint8_t s_kept[128];  // classify_kept: index | keep_lo << 6
 
     if (expand_overflowed(c, p)) return;
     const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
+    // occupancy-only mode (Params::occupancy_only): a job is decided by its first surviving piece - splitTriangle only
+    // ever adds the leaf's area per surviving piece (voxelization.cpp:414-420), so the weight is non-zero from then on
+    const bool occ_only = !UV && p.occupancy_only != 0u;
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
     // Batch size: about kBatchesPerBlock batches per workgroup (VoxShape), between one tile per wavefront and what the LDS staging holds.  Few
     // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
@@ -736,29 +740,28 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             float margin = 0.f;                  // out_margin of the job's leaf
             uint32_t pos_xy = 0, pos_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
             // Every lane holds its next job one ahead: the record is requested from the queue (an LDS ticket, then a load
-            // that L2 answers) when the lane starts a job and is only looked at when that job is done.
-            // The load is issued by hand (global_load into the registers that carry the record around the loop) and waited
-            // for by hand where the record is consumed: written as plain C++, the compiler loads into a temporary and
-            // copies it into the loop-carried registers at once, i.e. waits for L2 in every iteration that fetches a job
-            // (measured: a quarter of the wavefronts' time in s_waitcnt).  Between the two asm statements nothing reads
-            // next_rec, and the compiler's own vmcnt waits only get stricter by one more load in flight.
-            unsigned long long next_rec = 0ull;
+            // that L2 answers) when the lane starts a job and is only looked at when that job is done.  The load goes
+            // straight into the lane's LDS slot (global_load_lds: no destination register, so nothing the register
+            // allocator does can touch data in flight).  The wait before the slot is read is explicit: hipcc (ROCm 7.2) does
+            // track LDS-DMA for its own s_waitcnt placement, but across the loop's back edge it put the wait in front of
+            // the wrong LDS reads (seen in the compiled code: the slot was read first).  A stricter-than-needed vmcnt(0)
+            // costs nothing here: the lane's only other loads in flight are those of a rare stack overflow.
             bool next_valid = false;
             auto take_job = [&]() {
                 const uint32_t q = atomicAdd(&s_next, 1u);
                 next_valid = q < n_surv;
                 if (next_valid) {
                     const uint2 *src = jobq + (q < n_heavy ? q : kQueueCap - 1u - (q - n_heavy));
-                    asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(next_rec) : "v"(src) : "memory");
+                    // (LDS address = the wave-uniform base + 4 x lane)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) &src->x,
+                                                     (__attribute__((address_space(3))) void *) &s_next_x[threadIdx.x & ~63u], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) &src->y,
+                                                     (__attribute__((address_space(3))) void *) &s_next_y[threadIdx.x & ~63u], 4, 0, 0);
                 }
             };
             auto job_record = [&]() {
-                uint2 r;
-                asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3"
-                             : "=&v"(r.x), "=&v"(r.y)
-                             : "v"((uint32_t) next_rec), "v"((uint32_t) (next_rec >> 32))
-                             : "memory");
-                return r;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                return make_uint2(s_next_x[threadIdx.x], s_next_y[threadIdx.x]);
             };
             take_job();
             // parked result of this lane's last finished hit
@@ -771,7 +774,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 // Direct MAX path: a hit of an unsplit triangle (order key 0: its only leaf) is the triangle's whole weight in
                 // this (sub-)voxel, so it competes at once - one 64-bit atomic max on the cell, no hit record.  Hits of
                 // subdivided triangles still go through the pool (their leaves' weights must be added up in order first).
-                const bool direct = d_valid && use_direct && s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u;
+                // (occupancy-only mode: any hit marks the voxel, also those of subdivided triangles)
+                const bool direct = d_valid && use_direct && (occ_only || s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u);
                 // with textures a direct hit still leaves a record behind: {cell, key, colour} for k_pick
                 const bool pooled = d_valid && (UV || !direct);
                 const unsigned long long mask = __ballot(pooled);
@@ -907,6 +911,10 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         O2V_EV(2, true);
                         accumulate_piece<UV>(cur, area, w, u, v);  // inside all remaining planes
                         active = false;
+                        if (occ_only) {
+                            sp = 0;
+                            pmask = 0;
+                        }
                     }
                     else {
                         const uint32_t level = (uint32_t) __ffs((int) cf) - 1u;
@@ -988,6 +996,12 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             cur = sel_piece<UV>(s_takes_over, sec, cur);
                             cf = s_takes_over ? s_fail : c_fail;
                             active = s_takes_over || !c_over;
+                            if (!UV && occ_only && (c_kept | s_kept_n) != 0u) {
+                                // a piece survived: the voxel is hit, the rest of the job cannot change that
+                                active = false;
+                                sp = 0;
+                                pmask = 0;
+                            }
                         }
                     }
                 }

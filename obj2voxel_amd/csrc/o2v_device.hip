@@ -315,9 +315,10 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     if (p.direct_max) {
         O2V_CHECK(hipStreamSynchronize(ctx->aux[0]));
         const Counters &h = *ctx->h_ctr;
-        run_emit = h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
+        run_emit = p.occupancy_only || h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
         // hits are pooled only for leaves of subdivided triangles: without any, every hit goes straight into the 64-bit grid
-        run_general = !run_emit || h.n_nodes[0] != 0;
+        // (occupancy-only mode: those too)
+        run_general = !run_emit || (h.n_nodes[0] != 0 && !p.occupancy_only);
         if (run_emit) {
             const uint32_t groups = (p.n_bricks + 15u) / 16u;
             O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
@@ -851,7 +852,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
     {
         const char *off = std::getenv("O2V_NO_DIRECT_MAX");
-        p.direct_max = (params->strategy == 0u && !(off && off[0] == '1')) ? 1u : 0u;
+        // occupancy-only mode (Params::occupancy_only): no triangle has a material, so the result is the set of hit voxels,
+        // all white, with either strategy.  Not in exact mode: the fast-vs-exact comparison covers this shortcut too.
+        const char *no_occ = std::getenv("O2V_NO_OCCUPANCY_ONLY");
+        p.occupancy_only = (!ctx->d_types && !use_uv && !p.exact_clip && !(off && off[0] == '1') && !(no_occ && no_occ[0] == '1')) ? 1u : 0u;
+        p.direct_max = ((params->strategy == 0u || p.occupancy_only) && !(off && off[0] == '1')) ? 1u : 0u;
         p.pick_max = (p.direct_max && use_uv) ? 1u : 0u;  // textured: the winner's colour is picked afterwards (k_pick)
         p.mat = Materials{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
     }
@@ -870,6 +875,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
                 ctx->d_maxgrid = nullptr;
                 p.direct_max = 0;
                 p.pick_max = 0;
+                p.occupancy_only = 0;
             }
             else {
                 // all three buffers exist before the capacity is published: a context (cached process-wide by the C API)
@@ -886,6 +892,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
                     ctx->d_dirty_list_max = nullptr;
                     p.direct_max = 0;
                     p.pick_max = 0;
+                    p.occupancy_only = 0;
                 }
                 else {
                     ctx->maxgrid_cells = cells;
@@ -1042,7 +1049,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         if (!again) {
             ctx->grid_dirty = false;
             ctx->maxgrid_dirty = false;
-            const bool direct = p.direct_max && h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
+            const bool direct = p.direct_max && (p.occupancy_only || h.n_nodes[0] <= h.n_root_leaves);  // direct_active() on the device
             const uint64_t n_final = direct ? h.n_out : h.n_vox;
             ctx->last_direct = direct;
             ctx->n_vox = n_final;

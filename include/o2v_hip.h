@@ -183,8 +183,7 @@ int o2v_hip_get_transform(const o2v_hip_ctx *ctx, float out12[12]);
 int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t *out, uint32_t max_records,
                             uint32_t *out_count);
 
-/* Debugging aid: log2 histogram of pooled hits per brick (4 x 4 x 4 cells) of the last run (32 buckets; bucket b:
- * 2^(b-1) < hits <= 2^b). */
+/* Debugging aid: log2 histogram of hits per occupied cell of the last run (32 buckets; bucket b: 2^(b-1) < hits <= 2^b). */
 int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32);
 
 /* ---- multi-GPU: the grid sharded by z-slab over the GPUs of one node --------------------------

@@ -48,7 +48,7 @@ struct BigLeaf {
 
 struct __attribute__((aligned(16))) HitRec {  // 32 B: one (leaf, voxel) hit as emitted by k_voxelize
     uint32_t brick;       // brick of the cell; kHoleBrick marks a pool slot that holds no hit
-    uint32_t local_rank;  // cell inside the brick << 24 | rank of this hit among the hits of its brick
+    uint32_t local_rank;  // cell inside the brick << 24 | rank of this hit among the hits of its cell
     uint32_t keyhi;       // sub-voxel << 29 | triangle index
     uint32_t keylo;       // leaf order key
     float w, u, v;        // WeightedUv of this (leaf, voxel) pair (voxelization.cpp:414-423)
@@ -62,13 +62,13 @@ constexpr uint32_t kPickRecord = 1u;  // HitRec::pad of a direct hit's {cell, ke
 constexpr unsigned long long kPickTag = 1ull << 63;  // a max-grid cell that already holds its final argb (low word)
 constexpr uint32_t kMaxRank = 1u << 24;
 
-struct __attribute__((aligned(8))) SortedRec {  // 24 B: the same hit, placed contiguously with its brick's other hits
+struct __attribute__((aligned(8))) SortedRec {  // 24 B: the same hit, placed contiguously with its cell's other hits
     uint32_t keyhi, keylo;
     float w, u, v;
-    uint32_t pad;  // cell inside the brick
+    uint32_t pad;
 };
 
-// The sorted array is read through a view: 6 dwords per record in general, 4 (keyhi, keylo, w, cell: one 16-byte access)
+// The sorted array is read through a view: 6 dwords per record in general, 4 (keyhi, keylo, w, pad: one 16-byte access)
 // when the mesh has no textured triangle, because then u and v are never used and the scatter's cost scales with the
 // bytes it writes.
 struct SortedView {
@@ -78,10 +78,16 @@ struct SortedView {
     {
         if (stride == 4u) {
             const uint4 q = reinterpret_cast<const uint4 *>(base)[i];
-            return SortedRec{q.x, q.y, __uint_as_float(q.z), 0.f, 0.f, q.w};
+            return SortedRec{q.x, q.y, __uint_as_float(q.z), 0.f, 0.f, 0u};
         }
         return reinterpret_cast<const SortedRec *>(base)[i];
     }
+};
+
+struct __attribute__((aligned(16))) Occ {  // 16 B: one occupied cell
+    uint32_t cell_lo, cell_hi;  // brick * kBrickCells + cell in brick
+    uint32_t offset;            // first SortedRec of the cell
+    uint32_t count;             // number of hits
 };
 
 struct DevTexture {
@@ -99,13 +105,12 @@ struct Materials {
 
 struct Counters {
     uint32_t n_leaves, n_tiles, n_big, n_hits_reserved;
-    uint32_t n_vox, batch_cursor, err_flags, n_bocc;
+    uint32_t n_vox, batch_cursor, err_flags, n_lane16;
     uint32_t n_mid, n_long, n_huge, scratch_used;
     uint32_t n_dirty, n_sorted, n_bigl, cursor_big;
-    uint32_t cursor_mid, cursor_long, cursor_huge, cursor_w64;
+    uint32_t cursor_mid, cursor_long, cursor_huge, n_lane;
     uint32_t n_nodes[kMaxRounds + 1];
     uint32_t n_w64, n_dirty_max, n_out;
-    uint32_t n_w128, n_long2, cursor_long2, pad3;
     unsigned long long n_candidates, n_hits;
     uint32_t bounds_enc[6];
     uint32_t n_root_leaves, pad2;  // root triangles that became leaves as they are (the others are in n_nodes[0]);
@@ -133,7 +138,6 @@ struct Params {
     uint32_t zo0;          // slab begin in output space
     uint32_t blend;
     uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
-    uint32_t cap_bocc;     // entries of the list of bricks with pooled hits (and of each resolve tier's list)
     uint32_t n_bricks;     // bricks of this slab
     uint32_t cap_dirty;    // entries of each dirty-brick list
     uint32_t bounds_known;
@@ -152,8 +156,6 @@ struct Params {
     // {cell, key, argb} record; k_pick later gives every cell whose winner it was that colour.
     uint32_t pick_max;
     Materials mat;
-    uint32_t *bcount;      // one counter per brick: k_voxelize hands out a pooled hit's rank among the hits of its brick
-    unsigned long long *bmask;  // one bit per cell of the brick that received a pooled hit: the resolve kernels' output slots
     uint32_t *pick_extra;  // the same records for the winners of cells resolved by replay: 6 words each, cap_vox of them
     unsigned long long *maxgrid;
     uint8_t *dirty_max;
@@ -180,7 +182,7 @@ __device__ __forceinline__ bool direct_active(const Counters *c, const Params &p
 }
 __device__ __forceinline__ bool pass_overflowed(const Counters *c, const Params &p)
 {
-    return c->n_hits_reserved > p.cap_hits || c->n_sorted > p.cap_hits || c->n_bocc > p.cap_bocc;
+    return c->n_hits_reserved > p.cap_hits || c->n_sorted > p.cap_hits || c->n_vox > p.cap_vox;
 }
 
 __device__ __forceinline__ uint32_t f2ord(float f)
@@ -257,31 +259,7 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wave /*
     return base + inc - v;
 }
 
-// texture get, triangle.hpp:161-166 (getPixel semantics: see DESIGN.md): the colour of texture `id` at (u, v)
-__device__ __forceinline__ void texel_color(const Materials &m, uint32_t id, float u, float v, float &r, float &g, float &b)
-{
-    if (id >= m.n_textures) id = 0;
-    const DevTexture tx = m.textures[id];
-    float tu = u, tv = 1 - v;
-    if (tx.wrap) {
-        tu = tu - floor_f(tu);
-        tv = tv - floor_f(tv);
-    }
-    else {
-        tu = tu < 0.f ? 0.f : (tu > 1.f ? 1.f : tu);
-        tv = tv < 0.f ? 0.f : (tv > 1.f ? 1.f : tv);
-    }
-    uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
-    if (px >= tx.width) px = tx.width - 1;
-    if (py >= tx.height) py = tx.height - 1;
-    const uint8_t *q = tx.pixels + ((size_t) py * tx.width + px) * tx.channels;
-    const uint32_t o = tx.channels == 4 ? 1u : 0u;
-    r = (float) q[o] / 255.f;
-    g = (float) q[o + 1] / 255.f;
-    b = (float) q[o + 2] / 255.f;
-}
-
-// colorAt_f, triangle.hpp:181-194
+// colorAt_f, triangle.hpp:181-194 (+ texture get, triangle.hpp:161-166; getPixel semantics: see DESIGN.md)
 __device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float u, float v, float &r, float &g, float &b)
 {
     const uint32_t type = m.types ? m.types[tri] : (uint32_t) kTriMaterialless;
@@ -294,7 +272,26 @@ __device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float
         b = m.colors ? m.colors[(size_t) tri * 3 + 2] : 0.f;
     }
     else if (type == kTriTextured && m.n_textures) {
-        texel_color(m, m.texids ? (uint32_t) m.texids[tri] : 0u, u, v, r, g, b);
+        uint32_t id = m.texids ? (uint32_t) m.texids[tri] : 0u;
+        if (id >= m.n_textures) id = 0;
+        const DevTexture tx = m.textures[id];
+        float tu = u, tv = 1 - v;
+        if (tx.wrap) {
+            tu = tu - floor_f(tu);
+            tv = tv - floor_f(tv);
+        }
+        else {
+            tu = tu < 0.f ? 0.f : (tu > 1.f ? 1.f : tu);
+            tv = tv < 0.f ? 0.f : (tv > 1.f ? 1.f : tv);
+        }
+        uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
+        if (px >= tx.width) px = tx.width - 1;
+        if (py >= tx.height) py = tx.height - 1;
+        const uint8_t *q = tx.pixels + ((size_t) py * tx.width + px) * tx.channels;
+        const uint32_t o = tx.channels == 4 ? 1u : 0u;
+        r = (float) q[o] / 255.f;
+        g = (float) q[o + 1] / 255.f;
+        b = (float) q[o + 2] / 255.f;
     }
     else {
         r = 1.f;
@@ -302,3 +299,4 @@ __device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float
         b = 1.f;
     }
 }
+

@@ -441,7 +441,7 @@ __device__ __forceinline__ uint32_t vox_exscan(uint32_t v, uint32_t *s_wave /*[k
 
 template <bool UV>
 __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
-                                                     Counters *c, uint8_t *brick_dirty, HitRec *pool,
+                                                     Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
                                                      uint2 *jobq_all, Params p)
 {
     constexpr uint32_t kVoxBlock = VoxShape<UV>::block, kVoxTiles = VoxShape<UV>::tiles, kQueueCap = VoxShape<UV>::queue;
@@ -795,48 +795,14 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 }
                 const uint32_t mine = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
                 chunk_used += cnt;
-                // A pooled hit gets its rank among the hits of its brick (4 x 4 x 4 cells): the counting sort behind this
-                // kernel is by brick (k_scan_bcount / k_scatter), the order inside a brick is made by the resolve kernels.
-                // One atomic per distinct brick of the wavefront's parked hits, all issued at once: the lanes are grouped by
-                // brick first (ballots only), the first lane of a group reserves the group's ranks.
-                uint32_t brick = 0, cell_local = 0, keyhi = 0;
-                uint64_t cell = 0;
-                const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
                 if (d_valid) {
                     const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
+                    const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
                     const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
-                    cell = cell_index(ox, oy, oz - p.zo0, p, brick);
-                    cell_local = (uint32_t) cell & (kBrickCells - 1u);
+                    uint32_t brick;
+                    const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
                     const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
-                    keyhi = (sub << 29) | lf[18];
-                }
-                const bool ranked = d_valid && !direct && mine < p.cap_hits;
-                uint32_t rank = 0;
-                {
-                    unsigned long long todo = __ballot(ranked);
-                    uint32_t my_leader = lane, my_idx = 0, my_cnt = 0;
-                    while (todo) {
-                        const int leader = __builtin_ctzll(todo);
-                        const uint32_t b = (uint32_t) __builtin_amdgcn_readlane((int) brick, leader);
-                        const bool same = ranked && brick == b;
-                        const unsigned long long grp = __ballot(same);
-                        if (same) {
-                            my_leader = (uint32_t) leader;
-                            my_idx = __builtin_amdgcn_mbcnt_hi((uint32_t) (grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) grp, 0u));
-                            my_cnt = (uint32_t) __popcll(grp);
-                        }
-                        todo &= ~grp;
-                    }
-                    uint32_t base = 0;
-                    if (ranked && my_leader == lane) {
-                        base = atomicAdd(&p.bcount[brick], my_cnt);
-                        if (base + my_cnt >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
-                        brick_dirty[brick] = 1;  // benign race: every writer stores the same value
-                        if (use_direct) p.dirty_max[brick] = 1;  // the resolve kernels will add this brick's cells
-                    }
-                    rank = __shfl(base, (int) my_leader, 64) + my_idx;
-                }
-                if (d_valid) {
+                    const uint32_t keyhi = (sub << 29) | lf[18];
                     if (direct) {
                         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
                         p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
@@ -845,15 +811,17 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             // triangle is unsplit, so (d_u, d_v) already is its whole uv mean in this voxel
                             float cr, cg, cb;
                             color_at(p.mat, lf[18], d_u, d_v, cr, cg, cb);
-                            pool[mine] = HitRec{brick, cell_local << 24, keyhi, pack_argb(cr, cg, cb), d_w, 0.f, 0.f, kPickRecord};
+                            pool[mine] = HitRec{brick, ((uint32_t) cell & (kBrickCells - 1u)) << 24, keyhi, pack_argb(cr, cg, cb), d_w, 0.f, 0.f, kPickRecord};
                         }
                     }
-                    else if (ranked) {
-                        // the brick's occupied cells, one bit each (fire and forget): the resolve kernels' output slots
-#ifndef O2V_EXP_NO_BMASK
-                        atomicOr(&p.bmask[brick], 1ull << cell_local);
-#endif
-                        pool[mine] = HitRec{brick, (cell_local << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w, d_u, d_v, 0u};
+                    else if (mine < p.cap_hits) {
+                        // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
+                        const uint32_t rank = atomicAdd(&grid[cell], 1u);
+                        if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
+                        brick_dirty[brick] = 1;  // benign race: every writer stores the same value
+                        if (use_direct) p.dirty_max[brick] = 1;  // the resolve kernels will add this cell's result
+                        pool[mine] = HitRec{brick, (((uint32_t) cell & (kBrickCells - 1u)) << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w,
+                                            d_u, d_v, 0u};
                     }
                 }
                 if (lane == 0) atomicAdd(&s_hits, (uint32_t) __popcll(all));

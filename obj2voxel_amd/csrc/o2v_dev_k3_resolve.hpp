@@ -52,69 +52,177 @@ struct CellFold {
     }
 };
 
+__device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const Params &p)
+{
+    const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+    uint32_t x, y, z;
+    cell_position((uint32_t) (cell >> kBrickShift), (uint32_t) cell & (kBrickCells - 1u), p, x, y, z);
+    return make_uint4(x, y, z + p.zo0, argb);
+}
+
 // Where a resolved cell goes.  Normally its (x, y, z, argb) record is final.  On the direct MAX path (Params::direct_max)
 // the cell may also have received hits of unsplit triangles straight from k_voxelize, so the winner of the hits resolved
 // here - weight `w`, group `keyhi` = sub-voxel << 29 | triangle - competes in the same 64-bit cell and k_emit_max
-// writes the record.  Returns true if the caller has to write the record `rec` to the output list itself.
-__device__ __forceinline__ bool emit_cell(uint32_t brick, uint32_t local, uint32_t argb, float w, uint32_t keyhi, uint4 &rec,
+// writes the record.
+__device__ __forceinline__ void emit_cell(const Occ &o, uint32_t argb, float w, uint32_t keyhi, uint4 *out, uint32_t i,
                                           const Counters *c, const Params &p)
 {
     if (direct_active(c, p)) {
-        const uint64_t cell = (uint64_t) brick * kBrickCells + local;
+        const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(w) << 32) | (0xffffffffu - keyhi));
         if (p.pick_max) {
             // textured mesh: the colour is known here, the winner of the cell only later (k_pick)
             const uint32_t slot = atomicAdd(const_cast<uint32_t *>(&c->pad2), 1u);
             if (slot < p.cap_vox) {
                 uint32_t *q = p.pick_extra + (size_t) slot * 6u;
-                q[0] = (uint32_t) cell;
-                q[1] = (uint32_t) (cell >> 32);
+                q[0] = o.cell_lo;
+                q[1] = o.cell_hi;
                 q[2] = keyhi;
                 q[3] = __float_as_uint(w);
                 q[4] = argb;
                 q[5] = 0u;
             }
         }
-        return false;
     }
-    uint32_t x, y, z;
-    cell_position(brick, local, p, x, y, z);
-    rec = make_uint4(x, y, z + p.zo0, argb);
-    return true;
+    else {
+        out[i] = cell_record(o, argb, p);
+    }
 }
 
-// The fold over one cell's (sub-voxel, triangle) groups, each already reduced to {weight, colour}: CellFold's close_tri /
-// close_sub sequence (moveUvBufferIntoVoxels, voxelization.cpp:513-526; downscale, voxelization.hpp:82-85) without the
-// per-hit part.  Groups must be added in ascending key order.
-struct GroupFold {
-    bool have_sub = false, have_cell = false;
-    uint32_t cur = 0, sub_key = 0, cell_key = 0;
-    WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
-    __device__ __forceinline__ void close_sub(uint32_t blend)
-    {
-        if (!have_cell || (!blend && sub_acc.w > cell_acc.w)) cell_key = sub_key;
-        cell_acc = have_cell ? wcombine(blend, sub_acc, cell_acc) : sub_acc;
-        have_cell = true;
-        have_sub = false;
-    }
-    __device__ __forceinline__ void add(uint32_t blend, uint32_t keyhi, const WCol &fresh)
-    {
-        if (have_sub && (keyhi >> 29) != (cur >> 29)) close_sub(blend);
-        if (!have_sub || (!blend && fresh.w > sub_acc.w)) sub_key = keyhi;  // wmax keeps the existing value on a tie
-        sub_acc = have_sub ? wcombine(blend, fresh, sub_acc) : fresh;
-        have_sub = true;
-        cur = keyhi;
-    }
-    __device__ __forceinline__ uint32_t finish(uint32_t blend)
-    {
-        if (have_sub) close_sub(blend);
-        return pack_argb(cell_acc.r, cell_acc.g, cell_acc.b);
-    }
-};
 
-// Bitonic sort of (cell, key, idx) triples held in two arrays: `ci` = cell << 16 | idx (idx < 2^16), order by (cell, key).
-template <typename KeyPtr, typename CiPtr>
-__device__ __forceinline__ void bitonic_sort_ck(KeyPtr key, CiPtr ci, uint32_t n_pow2, uint32_t tid, uint32_t nthreads)
+// Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
+// from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
+template <uint32_t STRIDE>
+__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn,
+                                                    const Counters *c, Materials m, uint4 *out, Params p)
+{
+    constexpr bool kUv = STRIDE == 6;  // 16-byte records carry no uv: the columns shrink to 24 KiB, 6 workgroups per CU
+    __shared__ uint64_t s_key[kShortList][kBlock];
+    __shared__ float s_w[kShortList][kBlock], s_u[kUv ? kShortList : 1][kBlock], s_v[kUv ? kShortList : 1][kBlock];
+    const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads below stay branch-free
+    if (pass_overflowed(c, p)) return;
+    const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const Occ o = occ[i];
+        if (o.count > kShortList) continue;  // filed for a cooperative tier by k_scan_bricks
+        // all loads are issued before anything is consumed (independent round trips overlap), then the records are
+        // insertion-sorted into this lane's private LDS column and folded by a rolled loop
+        SortedRec r[kShortList];
+#pragma unroll
+        for (uint32_t k = 0; k < kShortList; ++k) r[k] = sorted.load(o.offset + (k < o.count ? k : 0u));
+#pragma unroll
+        for (uint32_t k = 0; k < kShortList; ++k) {
+            if (k < o.count) {
+                const uint64_t key = ((uint64_t) r[k].keyhi << 32) | r[k].keylo;
+                uint32_t j = k;
+                while (j > 0 && s_key[j - 1][threadIdx.x] > key) {
+                    s_key[j][threadIdx.x] = s_key[j - 1][threadIdx.x];
+                    s_w[j][threadIdx.x] = s_w[j - 1][threadIdx.x];
+                    if (kUv) {
+                        s_u[j][threadIdx.x] = s_u[j - 1][threadIdx.x];
+                        s_v[j][threadIdx.x] = s_v[j - 1][threadIdx.x];
+                    }
+                    --j;
+                }
+                s_key[j][threadIdx.x] = key;
+                s_w[j][threadIdx.x] = r[k].w;
+                if (kUv) {
+                    s_u[j][threadIdx.x] = r[k].u;
+                    s_v[j][threadIdx.x] = r[k].v;
+                }
+            }
+        }
+        CellFold f;
+        for (uint32_t t = 0; t < o.count; ++t)
+            f.add(m, p.blend, (uint32_t) (s_key[t][threadIdx.x] >> 32), s_w[t][threadIdx.x],
+                  kUv ? s_u[t][threadIdx.x] : 0.f, kUv ? s_v[t][threadIdx.x] : 0.f);
+        const uint32_t argb = f.finish(m, p.blend);
+        emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
+    }
+}
+
+// Tier 2: cells with 9..64 hits, W = 16, 32 or 64 lanes per cell (64 / W cells per wavefront).  Every lane loads one
+// record; the (key, position) pairs are bitonic-sorted across the W lanes with cross-lane moves only (no LDS, no
+// barrier); the payload is gathered to its sorted lane and the cell is folded in order, every lane of the group
+// running the same fold on broadcast values.
+template <uint32_t W>
+__global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                         const Counters *c, const Occ *__restrict__ occ,
+                                                         SortedView sorted, Materials m, uint4 *out, uint32_t list_cap,
+                                                         Params p)
+{
+    constexpr uint32_t kPerWave = 64u / W;
+    if (pass_overflowed(c, p)) return;
+    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane / W, sl = lane % W, base_lane = sub * W;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64u);
+    for (uint32_t item0 = wave * kPerWave; item0 < total; item0 += n_waves * kPerWave) {  // wave-uniform
+        const uint32_t item = item0 + sub;
+        const bool valid = item < total;
+        uint32_t i = 0;
+        Occ o{};
+        if (valid) {
+            i = list[item];
+            o = occ[i];
+        }
+        const uint32_t n = valid ? (o.count < W ? o.count : W) : 0u;
+        uint64_t key = ~0ull;
+        uint32_t hi = 0, idx = sl;
+        float w = 0.f, u = 0.f, v = 0.f;
+        if (sl < n) {
+            const SortedRec r = sorted.load(o.offset + sl);
+            key = ((uint64_t) r.keyhi << 32) | r.keylo;
+            hi = r.keyhi;
+            w = r.w;
+            u = r.u;
+            v = r.v;
+        }
+#pragma unroll
+        for (uint32_t k = 2; k <= W; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint64_t okey = __shfl_xor(key, (int) j, 64);
+                const uint32_t oidx = __shfl_xor(idx, (int) j, 64);
+                const bool keep_min = ((sl & k) == 0) == ((sl & j) == 0);
+                if (keep_min ? okey < key : okey > key) {
+                    key = okey;
+                    idx = oidx;
+                }
+            }
+        }
+        const int src = (int) (base_lane + idx);
+        hi = __shfl(hi, src, 64);
+        w = __shfl(w, src, 64);
+        u = __shfl(u, src, 64);
+        v = __shfl(v, src, 64);
+        CellFold f;
+        for (uint32_t t = 0; t < W; ++t) {
+            if (!__any(t < n)) break;
+            uint32_t hh;
+            float ww, uu, vv;
+            if (W == 64) {
+                // one cell per wavefront: the source lane is uniform, the values come straight out of its registers
+                hh = (uint32_t) __builtin_amdgcn_readlane((int) hi, (int) t);
+                ww = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(w), (int) t));
+                uu = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(u), (int) t));
+                vv = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), (int) t));
+            }
+            else {
+                const int from = (int) (base_lane + t);
+                hh = __shfl(hi, from, 64);
+                ww = __shfl(w, from, 64);
+                uu = __shfl(u, from, 64);
+                vv = __shfl(v, from, 64);
+            }
+            if (t < n) f.add(m, p.blend, hh, ww, uu, vv);
+        }
+        const uint32_t argb = f.finish(m, p.blend);
+        if (n != 0 && sl == 0) emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
+    }
+}
+
+template <typename KeyPtr, typename IdxPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_pow2, uint32_t tid, uint32_t nthreads)
 {
     for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -123,13 +231,12 @@ __device__ __forceinline__ void bitonic_sort_ck(KeyPtr key, CiPtr ci, uint32_t n
                 if (partner > t) {
                     const bool up = (t & k) == 0;
                     const uint64_t a = key[t], b = key[partner];
-                    const uint32_t ca = ci[t], cb = ci[partner];
-                    const bool a_gt_b = (ca >> 16) != (cb >> 16) ? (ca >> 16) > (cb >> 16) : a > b;
-                    if (a_gt_b == up) {
+                    if ((a > b) == up) {
                         key[t] = b;
                         key[partner] = a;
-                        ci[t] = cb;
-                        ci[partner] = ca;
+                        const uint32_t ia = idx[t];
+                        idx[t] = idx[partner];
+                        idx[partner] = ia;
                     }
                 }
             }
@@ -137,368 +244,23 @@ __device__ __forceinline__ void bitonic_sort_ck(KeyPtr key, CiPtr ci, uint32_t n
         }
     }
 }
-constexpr uint32_t kPadCell = 0xffffu;  // `cell` of the padding entries of a sort: after every real cell (< 64)
 
-// ---- brick resolve: the bulk tiers, one wavefront per brick, out of registers ------------------------------------------
-// Bricks with up to 64 * R pooled hits (R = 1, 2, 4 records per lane; nine bricks in ten have at most 64).  Per brick:
-//   load     the brick's records are one contiguous block (k_scatter): one coalesced load per lane and record; right behind it
-//            the lane asks for the material of its record's triangle (type, colour, texture index: independent loads that
-//            arrive while the sort runs, so the colour lookup later has no chain of dependent loads left);
-//   sort     by rank: every lane counts the records that precede its own in (cell, sub-voxel, triangle, leaf) order, the
-//            other records' keys coming out of the lanes' registers one by one (v_readlane, the index is wavefront-uniform):
-//            64 * R steps of a few instructions, no LDS, no barrier; the records are then written to LDS at their rank;
-//   A        the lane at the first record of a (cell, sub-voxel, triangle) group folds the group - the leaves of one
-//            triangle in one (sub-)voxel, insertWeighted<BLEND> (voxelization.cpp:466-468) in leaf order - and looks its
-//            colour up (colorAt_f, triangle.hpp:181-194);
-//   B        the lane at the first record of a cell folds the cell's groups in order (GroupFold) and writes the record to
-//            its place in the output (BrickOcc::out_base + the number of occupied cells before it).
-// The next brick's list entry is requested before the current one is processed.  Workgroup b takes the bricks b, b + grid,
-// ... of its tier's list (an atomic per brick on one address would serialise at ~88 per us).
-template <uint32_t R>
-__global__ __launch_bounds__(64) void k_resolve_brick_wave(const BrickOcc *__restrict__ list, const uint32_t *n_list, Counters *c,
-                                                           SortedView sorted, Materials m, uint4 *out, uint32_t list_cap, Params p)
-{
-    constexpr uint32_t N = 64u * R;
-    if (pass_overflowed(c, p)) return;
-    __shared__ uint32_t s_cell[N];  // cell | 0x100 at a group's first record
-    __shared__ uint32_t s_hi[N], s_lo[N], s_mat[N];
-    __shared__ float s_w[N], s_u[N], s_v[N], s_r[N], s_g[N], s_b[N];
-    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
-    const uint32_t lane = threadIdx.x;
-    uint32_t item = blockIdx.x;
-    if (item >= total) return;
-    BrickOcc o = list[item];
-#ifdef O2V_INSTRUMENT
-    unsigned long long tmr[5] = {0, 0, 0, 0, 0}, t_mark = __builtin_readcyclecounter();
-    auto lap = [&](int which) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        tmr[which] += now - t_mark;
-        t_mark = now;
-    };
-#define O2V_RLAP(i) lap(i)
-#else
-#define O2V_RLAP(i) do { } while (0)
-#endif
-    for (;;) {
-        const uint32_t item_next = item + gridDim.x;
-        const bool more = item_next < total;
-        BrickOcc o_next{};
-        if (more) o_next = list[item_next];
-        const uint32_t n = o.count < N ? o.count : N;
-        // ---- load ----
-        uint32_t a_hi[R], a_lo[R], kb[R], mat[R], rank[R];
-        float w[R], u[R], v[R], cr[R], cg[R], cb[R];
-#pragma unroll
-        for (uint32_t k = 0; k < R; ++k) {
-            const uint32_t t = lane + 64u * k;
-            a_hi[k] = 0xffffffffu;  // (not a record: after every real one)
-            a_lo[k] = kb[k] = mat[k] = rank[k] = 0;
-            w[k] = u[k] = v[k] = cr[k] = cg[k] = cb[k] = 0.f;
-            if (t < n) {
-                const SortedRec r = sorted.load(o.offset + t);
-                a_hi[k] = r.pad;
-                a_lo[k] = r.keyhi;
-                kb[k] = r.keylo;
-                w[k] = r.w;
-                u[k] = r.u;
-                v[k] = r.v;
-                const uint32_t tri = r.keyhi & 0x1fffffffu;
-                const uint32_t type = m.types ? m.types[tri] : (uint32_t) kTriMaterialless;
-                const uint32_t texid = m.texids ? (uint32_t) m.texids[tri] : 0u;
-                if (m.colors) {
-                    cr[k] = m.colors[(size_t) tri * 3 + 0];
-                    cg[k] = m.colors[(size_t) tri * 3 + 1];
-                    cb[k] = m.colors[(size_t) tri * 3 + 2];
-                }
-                mat[k] = (type & 0xffu) | (texid << 8);
-            }
-        }
-        O2V_RLAP(0);
-        // ---- sort by rank ----
-        // by (cell, sub-voxel, triangle) and, among equal ones, by position: one unique 64-bit key per record (6 + 32 + 8
-        // bits), so a step is two v_readlane, one 64-bit compare and one add per own record.  The leaves of one triangle in one
-        // (sub-)voxel - equal keys, few and rare - are put into leaf order by the group's fold (A).
-        uint64_t key[R];
-#pragma unroll
-        for (uint32_t k = 0; k < R; ++k) key[k] = ((((uint64_t) a_hi[k] << 32) | a_lo[k]) << 8) | (lane + 64u * k);
-#pragma unroll
-        for (uint32_t kk = 0; kk < R; ++kk) {
-            const uint32_t here = n > 64u * kk ? (n - 64u * kk < 64u ? n - 64u * kk : 64u) : 0u;  // records in register set kk
-            const uint32_t klo = (uint32_t) key[kk], khi = (uint32_t) (key[kk] >> 32);
-            for (uint32_t j = 0; j < here; ++j) {
-                const uint64_t other = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) khi, (int) j) << 32) |
-                                       (uint32_t) __builtin_amdgcn_readlane((int) klo, (int) j);
-#pragma unroll
-                for (uint32_t k = 0; k < R; ++k) rank[k] += other < key[k] ? 1u : 0u;
-            }
-        }
-        O2V_RLAP(1);
-        __syncthreads();  // (one wavefront: orders the LDS accesses of the previous brick before these writes)
-#pragma unroll
-        for (uint32_t k = 0; k < R; ++k) {
-            if (lane + 64u * k < n) {
-                const uint32_t at = rank[k];
-                s_cell[at] = a_hi[k];
-                s_hi[at] = a_lo[k];
-                s_lo[at] = kb[k];
-                s_mat[at] = mat[k];
-                s_w[at] = w[k];
-                s_u[at] = u[k];
-                s_v[at] = v[k];
-                s_r[at] = cr[k];
-                s_g[at] = cg[k];
-                s_b[at] = cb[k];
-            }
-        }
-        __syncthreads();
-        O2V_RLAP(2);
-        // ---- A: groups -> {weight, colour} at the group's first record ----
-        bool start[R];
-        float gw[R], gr[R], gg[R], gb[R];
-#pragma unroll
-        for (uint32_t k = 0; k < R; ++k) {
-            const uint32_t t = lane + 64u * k;
-            start[k] = false;
-            gw[k] = gr[k] = gg[k] = gb[k] = 0.f;
-            if (t < n) {
-                const uint32_t cell = s_cell[t], hi = s_hi[t];
-                start[k] = t == 0 || s_hi[t - 1] != hi || s_cell[t - 1] != cell;
-                if (start[k]) {
-                    WUv acc{s_w[t], s_u[t], s_v[t]};
-                    uint32_t end = t + 1;
-                    while (end < n && s_hi[end] == hi && s_cell[end] == cell) ++end;
-                    if (end > t + 1) {
-                        // several leaves of the triangle in this (sub-)voxel: fold them in leaf order (selection by the leaf key;
-                        // a handful at most: a leaf spans several voxels)
-                        uint32_t last = 0;
-                        bool first = true;
-                        for (uint32_t done = t; done < end; ++done) {
-                            uint32_t best = 0xffffffffu, at = t;
-                            for (uint32_t j = t; j < end; ++j) {
-                                const uint32_t kl = s_lo[j];
-                                if ((first || kl > last) && kl <= best) {
-                                    best = kl;
-                                    at = j;
-                                }
-                            }
-                            const WUv hit{s_w[at], s_u[at], s_v[at]};
-                            acc = first ? hit : wmix(hit, acc);
-                            last = best;
-                            first = false;
-                        }
-                    }
-                    const uint32_t mt = s_mat[t], type = mt & 0xffu;
-                    gw[k] = acc.w;
-                    if (type == kTriMaterialless) {
-                        gr[k] = gg[k] = gb[k] = 1.f;
-                    }
-                    else if (type == kTriUntextured) {
-                        gr[k] = s_r[t];
-                        gg[k] = s_g[t];
-                        gb[k] = s_b[t];
-                    }
-                    else if (type == kTriTextured && m.n_textures) {
-                        texel_color(m, mt >> 8, acc.u, acc.v, gr[k], gg[k], gb[k]);
-                    }
-                    else {
-                        gr[k] = 1.f;
-                        gg[k] = 0.f;
-                        gb[k] = 1.f;
-                    }
-                }
-            }
-        }
-        __syncthreads();  // (every group has read its members before the first records are overwritten)
-#pragma unroll
-        for (uint32_t k = 0; k < R; ++k) {
-            const uint32_t t = lane + 64u * k;
-            if (start[k]) {
-                s_w[t] = gw[k];
-                s_r[t] = gr[k];
-                s_g[t] = gg[k];
-                s_b[t] = gb[k];
-                s_cell[t] |= 0x100u;
-            }
-        }
-        __syncthreads();
-        O2V_RLAP(3);
-        // ---- B: cells ----
-#pragma unroll
-        for (uint32_t k = 0; k < R; ++k) {
-            const uint32_t t = lane + 64u * k;
-            if (t < n) {
-                const uint32_t cell = s_cell[t] & 0xffu;
-                if (t == 0 || (s_cell[t - 1] & 0xffu) != cell) {
-                    GroupFold f;
-                    for (uint32_t j = t; j < n; ++j) {
-                        const uint32_t cj = s_cell[j];
-                        if ((cj & 0xffu) != cell) break;
-                        if (cj & 0x100u) f.add(p.blend, s_hi[j], WCol{s_w[j], s_r[j], s_g[j], s_b[j]});
-                    }
-                    const uint32_t argb = f.finish(p.blend);
-                    uint4 rec;
-                    if (emit_cell(o.brick, cell, argb, f.cell_acc.w, f.cell_key, rec, c, p)) {
-                        const uint32_t slot = o.out_base + (uint32_t) __popcll(o.cells & ((1ull << cell) - 1ull));
-                        if (slot < p.cap_vox) out[slot] = rec;
-                    }
-                }
-            }
-        }
-        O2V_RLAP(4);
-        if (!more) break;
-        item = item_next;
-        o = o_next;
-    }
-#ifdef O2V_INSTRUMENT
-    if (R == 1 && lane == 0)
-        for (uint32_t k = 0; k < 5; ++k) atomicAdd(&c->dbg[k], tmr[k]);  // (k_voxelize's counts are overwritten: run a BLEND workload)
-#endif
-}
-
-// ---- brick resolve: tiers up to kTierLong hits -------------------------------------------------------------------------
-// THREADS lanes (a wavefront or a workgroup) take one brick at a time from their tier's list: the brick's records are one
-// contiguous block (k_scatter), loaded coalesced; (cell, key, position) is bitonic-sorted in LDS; the payload is gathered in
-// sorted order; then, all in parallel,
-//   A  the lane at the first record of a (cell, sub-voxel, triangle) group folds the group - the leaves of one triangle in one
-//      (sub-)voxel, insertWeighted<BLEND> (voxelization.cpp:466-468) in leaf order - and looks its colour up (colorAt_f),
-//   B  the lane at the first record of a cell folds the cell's groups in order (GroupFold) and makes the record;
-// every record goes straight to its place in the output (BrickOcc::out_base + the number of occupied cells before it).
-// DYNAMIC: bricks are taken from a global cursor (few, uneven items); otherwise workgroup b takes the items b, b + grid, ...
-// (an atomic per brick on one address serialises at ~88 per us: 23 ms for the two million bricks of configs[3]).
-// PARK: the payload (w, u, v) is parked in LDS at its unsorted position when the records are read; otherwise it is read again
-// from global memory in sorted order (the tier of up to 4096 hits: 128 KiB of LDS without the parking area).
-template <uint32_t THREADS, uint32_t CAP, bool DYNAMIC, bool PARK>
-__global__ __launch_bounds__(THREADS) void k_resolve_brick(const BrickOcc *__restrict__ list, const uint32_t *n_list, uint32_t *cursor,
-                                                           Counters *c, SortedView sorted, Materials m, uint4 *out, uint32_t list_cap,
-                                                           Params p)
+// Tiers 2 and 3: THREADS lanes cooperate on one cell (a wavefront for up to 256 hits, a workgroup for up to 2048).
+// The cell's records are contiguous: keys are loaded coalesced, (key, idx) pairs are bitonic-sorted in LDS, the
+// payload is gathered in sorted order, and lane 0 replays the fold (which is inherently sequential: the float
+// combine is not associative).
+template <uint32_t THREADS, uint32_t CAP>
+__global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                            uint32_t *cursor, const Counters *c,
+                                                            const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                            uint4 *out, uint32_t list_cap, Params p)
 {
     if (pass_overflowed(c, p)) return;
     __shared__ uint64_t s_key[CAP];
-    __shared__ uint32_t s_ci[CAP];
+    __shared__ uint32_t s_idx[CAP];
     __shared__ uint32_t s_hi[CAP];
-    __shared__ float s_w[CAP], s_u[CAP], s_v[CAP], s_b[CAP];
-    __shared__ float s_w0[PARK ? CAP : 1], s_u0[PARK ? CAP : 1], s_v0[PARK ? CAP : 1];
+    __shared__ float s_w[CAP], s_u[CAP], s_v[CAP];
     __shared__ uint32_t s_item;
-    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
-    for (uint32_t round = 0;; ++round) {
-        __syncthreads();
-        if (DYNAMIC) {
-            if (threadIdx.x == 0) s_item = atomicAdd(cursor, 1u);
-            __syncthreads();
-        }
-        const uint32_t item = DYNAMIC ? s_item : blockIdx.x + round * gridDim.x;
-        if (item >= total) break;
-        const BrickOcc o = list[item];
-        const uint32_t n = o.count < CAP ? o.count : CAP;
-        uint32_t n_pow2 = 1;
-        while (n_pow2 < n) n_pow2 <<= 1;
-        // the records are read once: keys for the sort, the payload parked in LDS at its unsorted position
-        for (uint32_t t = threadIdx.x; t < n_pow2; t += THREADS) {
-            if (t < n) {
-                const SortedRec r = sorted.load(o.offset + t);
-                s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
-                s_ci[t] = (r.pad << 16) | t;
-                if (PARK) {
-                    s_w0[t] = r.w;
-                    s_u0[t] = r.u;
-                    s_v0[t] = r.v;
-                }
-            }
-            else {
-                s_key[t] = ~0ull;
-                s_ci[t] = kPadCell << 16;
-            }
-        }
-        __syncthreads();
-        bitonic_sort_ck(s_key, s_ci, n_pow2, threadIdx.x, THREADS);
-        for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
-            const uint32_t from = s_ci[t] & 0xffffu;
-            s_hi[t] = (uint32_t) (s_key[t] >> 32);
-            if (PARK) {
-                s_w[t] = s_w0[from];
-                s_u[t] = s_u0[from];
-                s_v[t] = s_v0[from];
-            }
-            else {
-                const SortedRec r = sorted.load(o.offset + from);
-                s_w[t] = r.w;
-                s_u[t] = r.u;
-                s_v[t] = r.v;
-            }
-        }
-        __syncthreads();
-        // A: groups -> {weight, r, g, b} at the group's first record (s_w, s_u, s_v, s_b)
-        bool starts[(CAP + THREADS - 1) / THREADS];
-#pragma unroll
-        for (uint32_t k = 0; k < (CAP + THREADS - 1) / THREADS; ++k) {
-            const uint32_t t = threadIdx.x + k * THREADS;
-            starts[k] = t < n && (t == 0 || s_hi[t] != s_hi[t - 1] || (s_ci[t] >> 16) != (s_ci[t - 1] >> 16));
-        }
-        float gw[(CAP + THREADS - 1) / THREADS], gr[(CAP + THREADS - 1) / THREADS], gg[(CAP + THREADS - 1) / THREADS],
-            gb[(CAP + THREADS - 1) / THREADS];
-#pragma unroll
-        for (uint32_t k = 0; k < (CAP + THREADS - 1) / THREADS; ++k) {
-            const uint32_t t = threadIdx.x + k * THREADS;
-            gw[k] = gr[k] = gg[k] = gb[k] = 0.f;
-            if (starts[k]) {
-                const uint32_t cell = s_ci[t] >> 16;
-                WUv acc{s_w[t], s_u[t], s_v[t]};
-                for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t] && (s_ci[j] >> 16) == cell; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
-                color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, gr[k], gg[k], gb[k]);
-                gw[k] = acc.w;
-            }
-        }
-        __syncthreads();  // (every group has read its members' w, u, v before the first records are overwritten)
-#pragma unroll
-        for (uint32_t k = 0; k < (CAP + THREADS - 1) / THREADS; ++k) {
-            const uint32_t t = threadIdx.x + k * THREADS;
-            if (starts[k]) {
-                s_w[t] = gw[k];
-                s_u[t] = gr[k];
-                s_v[t] = gg[k];
-                s_b[t] = gb[k];
-                s_ci[t] |= 0x8000u;  // marks a group's first record (idx is no longer needed; CAP <= 2^15)
-            }
-        }
-        __syncthreads();
-        // B: cells
-#pragma unroll
-        for (uint32_t k = 0; k < (CAP + THREADS - 1) / THREADS; ++k) {
-            const uint32_t t = threadIdx.x + k * THREADS;
-            if (t < n && (t == 0 || (s_ci[t] >> 16) != (s_ci[t - 1] >> 16))) {
-                const uint32_t cell = s_ci[t] >> 16;
-                GroupFold f;
-                for (uint32_t j = t; j < n && (s_ci[j] >> 16) == cell; ++j)
-                    if (s_ci[j] & 0x8000u) f.add(p.blend, s_hi[j], WCol{s_w[j], s_u[j], s_v[j], s_b[j]});
-                const uint32_t argb = f.finish(p.blend);
-                uint4 rec;
-                if (emit_cell(o.brick, cell, argb, f.cell_acc.w, f.cell_key, rec, c, p)) {
-                    // the brick's records follow each other in ascending order of the cell (k_scan_bcount made room for them)
-                    const uint32_t slot = o.out_base + (uint32_t) __popcll(o.cells & ((1ull << cell) - 1ull));
-                    if (slot < p.cap_vox) out[slot] = rec;
-                }
-            }
-        }
-    }
-}
-
-// ---- brick resolve: the long tail ----------------------------------------------------------------------------------------
-// Bricks with more than kTierLong hits (the poles of a finely tessellated sphere; a whole mesh inside a few voxels): one
-// workgroup per brick sorts (cell, key, position) - up to kTierBig in 96 KiB of dynamic LDS (key 8 B + cell / position 4 B),
-// beyond that in a global scratch area - and its first thread replays the records in order (CellFold per cell; sequential
-// by nature for BLEND, and rare enough for MAX), the payload staged through LDS a thousand records at a time.
-constexpr uint32_t kBigStage = 1024, kBigThreads = 1024;
-template <bool GLOBAL_SCRATCH>
-__global__ __launch_bounds__(kBigThreads) void k_resolve_brick_big(const BrickOcc *__restrict__ list, const uint32_t *n_list, uint32_t *cursor,
-                                                                   Counters *c, SortedView sorted, Materials m, uint4 *out,
-                                                                   uint64_t *scratch_key, uint32_t *scratch_idx, uint32_t scratch_cap,
-                                                                   uint32_t list_cap, Params p)
-{
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ uint32_t s_hi[kBigStage], s_cell[kBigStage];
-    __shared__ float s_w[kBigStage], s_u[kBigStage], s_v[kBigStage];
-    __shared__ uint32_t s_item, s_base, s_ok;
-    if (pass_overflowed(c, p)) return;
     const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
     for (;;) {
         __syncthreads();
@@ -506,111 +268,327 @@ __global__ __launch_bounds__(kBigThreads) void k_resolve_brick_big(const BrickOc
         __syncthreads();
         const uint32_t item = s_item;
         if (item >= total) break;
-        const BrickOcc o = list[item];
-        const uint32_t n = GLOBAL_SCRATCH ? o.count : (o.count < kTierBig ? o.count : kTierBig);
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count < CAP ? o.count : CAP;
         uint32_t n_pow2 = 1;
         while (n_pow2 < n) n_pow2 <<= 1;
-        uint64_t *key = reinterpret_cast<uint64_t *>(s_dyn);
-        uint32_t *idx = reinterpret_cast<uint32_t *>(s_dyn + (size_t) kTierBig * 8);
-        uint32_t *cellv = nullptr;  // GLOBAL_SCRATCH: the position does not fit beside the cell in 32 bits
-        if (GLOBAL_SCRATCH) {
-            if (threadIdx.x == 0) {
-                s_base = atomicAdd(&c->scratch_used, 2u * n_pow2);
-                // scratch too small: the host sees scratch_used > capacity, grows it and re-runs
-                s_ok = (uint64_t) s_base + 2ull * n_pow2 <= scratch_cap ? 1u : 0u;
-            }
-            __syncthreads();
-            if (!s_ok) continue;
-            key = scratch_key + s_base;
-            idx = scratch_idx + s_base;
-            cellv = scratch_idx + s_base + n_pow2;
-        }
-        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBigThreads) {
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += THREADS) {
             if (t < n) {
                 const SortedRec r = sorted.load(o.offset + t);
-                key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
-                if (GLOBAL_SCRATCH) {
-                    idx[t] = t;
-                    cellv[t] = r.pad;
-                }
-                else {
-                    idx[t] = (r.pad << 16) | t;
-                }
+                s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                s_idx[t] = t;
             }
             else {
-                key[t] = ~0ull;
-                if (GLOBAL_SCRATCH) {
-                    idx[t] = 0;
-                    cellv[t] = kPadCell;
-                }
-                else {
-                    idx[t] = kPadCell << 16;
-                }
+                s_key[t] = ~0ull;
+                s_idx[t] = 0;
             }
         }
         __syncthreads();
-        if (GLOBAL_SCRATCH) {
-            for (uint32_t k = 2; k <= n_pow2; k <<= 1) {
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t t = threadIdx.x; t < n_pow2; t += kBigThreads) {
-                        const uint32_t partner = t ^ j;
-                        if (partner > t) {
-                            const bool up = (t & k) == 0;
-                            const uint64_t a = key[t], b = key[partner];
-                            const uint32_t ca = cellv[t], cb = cellv[partner];
-                            const bool a_gt_b = ca != cb ? ca > cb : a > b;
-                            if (a_gt_b == up) {
-                                key[t] = b;
-                                key[partner] = a;
-                                cellv[t] = cb;
-                                cellv[partner] = ca;
-                                const uint32_t ia = idx[t];
-                                idx[t] = idx[partner];
-                                idx[partner] = ia;
-                            }
-                        }
-                    }
-                    __syncthreads();
+        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, THREADS);
+        for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+            const SortedRec r = sorted.load(o.offset + s_idx[t]);
+            s_hi[t] = r.keyhi;
+            s_w[t] = r.w;
+            s_u[t] = r.u;
+            s_v[t] = r.v;
+        }
+        __syncthreads();
+        if (p.blend) {
+            // BLEND: the weighted mean is folded in the reference's order (float mix is not associative), but only the
+            // chain over the triangles is sequential: every triangle's own hits (its leaves in this cell) and its colour
+            // lookup are independent of the other triangles, so the lane at a group's first record folds the group and
+            // leaves {weight, r, g, b} there; lane 0 then combines the groups in order (CellFold's close_tri /
+            // close_sub sequence without the loads).
+            for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+                if (t == 0 || s_hi[t] != s_hi[t - 1]) {
+                    WUv acc{s_w[t], s_u[t], s_v[t]};
+                    for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                    float cr, cg, cb;
+                    color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                    s_w[t] = acc.w;
+                    s_u[t] = cr;
+                    s_v[t] = cg;
+                    s_idx[t] = __float_as_uint(cb);  // the sort indices are no longer needed
                 }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64u) {
+                // The chain over the groups is sequential, but nothing in it has to wait for memory: the first wavefront
+                // loads 64 entries at a time, one per lane, and walks the group starts among them in order, every value
+                // of the step coming out of a lane's register (v_readlane: the lane index is wavefront-uniform).  All
+                // lanes run the same recurrence; lane 0 writes the result.
+                const uint32_t lane = threadIdx.x;
+                bool have_sub = false, have_cell = false;
+                WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
+                uint32_t cur_sub = 0;
+                for (uint32_t base = 0; base < n; base += 64u) {
+                    const uint32_t t = base + lane;
+                    const bool in = t < n;
+                    const uint32_t hi_t = in ? s_hi[t] : 0u;
+                    const bool start = in && (t == 0 || hi_t != s_hi[t - 1]);
+                    const float w_t = in ? s_w[t] : 0.f, r_t = in ? s_u[t] : 0.f, g_t = in ? s_v[t] : 0.f;
+                    const uint32_t b_t = in ? s_idx[t] : 0u;
+                    unsigned long long starts = __ballot(start);
+                    while (starts) {
+                        const int j = __builtin_ctzll(starts);
+                        starts &= starts - 1ull;
+                        const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) hi_t, j);
+                        const WCol fresh{__uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(w_t), j)),
+                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(r_t), j)),
+                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(g_t), j)),
+                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) b_t, j))};
+                        if (have_sub && (hi >> 29) != cur_sub) {
+                            cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                            have_cell = true;
+                            have_sub = false;
+                        }
+                        sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
+                        have_sub = true;
+                        cur_sub = hi >> 29;
+                    }
+                }
+                if (have_sub) cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
+                if (lane == 0) out[i] = cell_record(o, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b), p);
             }
         }
         else {
-            bitonic_sort_ck(key, idx, n_pow2, threadIdx.x, kBigThreads);
-        }
-        CellFold f;  // only thread 0's copy is used
-        uint32_t cur_cell = kPadCell, n_emitted = 0;
-        auto emit = [&]() {
-            const uint32_t argb = f.finish(m, p.blend);
-            uint4 rec;
-            if (emit_cell(o.brick, cur_cell, argb, f.cell_acc.w, f.cell_key, rec, c, p) && o.out_base + n_emitted < p.cap_vox)
-                out[o.out_base + n_emitted] = rec;
-            n_emitted += 1;
-        };
-        for (uint32_t base = 0; base < n; base += kBigStage) {
-            const uint32_t m_here = n - base < kBigStage ? n - base : kBigStage;
-            __syncthreads();
-            for (uint32_t t = threadIdx.x; t < m_here; t += kBigThreads) {
-                const uint32_t at = GLOBAL_SCRATCH ? idx[base + t] : (idx[base + t] & 0xffffu);
-                const SortedRec r = sorted.load(o.offset + at);
-                s_hi[t] = r.keyhi;
-                s_cell[t] = r.pad;
-                s_w[t] = r.w;
-                s_u[t] = r.u;
-                s_v[t] = r.v;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                for (uint32_t t = 0; t < m_here; ++t) {
-                    if (s_cell[t] != cur_cell) {
-                        if (cur_cell != kPadCell) emit();
-                        f = CellFold{};
-                        cur_cell = s_cell[t];
-                    }
-                    f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
+            // MAX: `new.w > existing.w ? new : existing` over ascending (sub-voxel, triangle) groups keeps the first
+            // group with the greatest weight, which is a true reduction: every group is folded by the lane at its
+            // first record (leaves of one triangle, in order), then the groups are max-reduced with ties to the
+            // lower position.
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
+                if (t == 0 || s_hi[t] != s_hi[t - 1]) {
+                    WUv acc{s_w[t], s_u[t], s_v[t]};
+                    uint32_t j = t + 1;
+                    for (; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                    // weights are non-negative, so their bit patterns order like the values
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
                 }
             }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            if (THREADS > 64) {
+                __syncthreads();
+                if ((threadIdx.x & 63u) == 0) s_key[threadIdx.x >> 6] = best;  // s_key is free after the sort
+                __syncthreads();
+                best = s_key[0];
+                for (uint32_t wv = 1; wv < THREADS / 64; ++wv) best = s_key[wv] > best ? s_key[wv] : best;
+            }
+            if (threadIdx.x == 0) {
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                // rebuild the winning group's uv (needed for a textured winner) and emit
+                WUv acc{s_w[t], s_u[t], s_v[t]};
+                for (uint32_t j = t + 1; j < n && s_hi[j] == s_hi[t]; ++j) acc = wmix(WUv{s_w[j], s_u[j], s_v[j]}, acc);
+                float cr, cg, cb;
+                color_at(m, s_hi[t] & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                emit_cell(o, pack_argb(cr, cg, cb), acc.w, s_hi[t], out, i, c, p);
+            }
         }
-        if (threadIdx.x == 0 && cur_cell != kPadCell) emit();
+    }
+}
+
+// Tier 3b: cells with 2049..8192 hits (the poles of a finely tessellated sphere at high resolution).  One workgroup
+// per cell; (key, idx) pairs are bitonic-sorted in dynamic LDS (96 KiB), the payload stays in global memory: MAX
+// folds the groups in parallel straight from it, BLEND stages it in sorted order, 1024 records at a time, for the
+// sequential replay.
+constexpr uint32_t kBigStage = 1024, kBigThreads = 1024;
+__global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__restrict__ list, Counters *c,
+                                                        const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                        uint4 *out, uint32_t list_cap, Params p)
+{
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    uint64_t *s_key = reinterpret_cast<uint64_t *>(s_dyn);                                  // [kBigList]
+    uint32_t *s_idx = reinterpret_cast<uint32_t *>(s_dyn + (size_t) kBigList * 8);           // [kBigList]
+    __shared__ uint32_t s_hi[kBigStage];
+    __shared__ float s_w[kBigStage], s_u[kBigStage], s_v[kBigStage];
+    __shared__ unsigned long long s_best[kBigThreads / 64];
+    __shared__ uint32_t s_item;
+    if (pass_overflowed(c, p)) return;
+    const uint32_t total = c->n_bigl < list_cap ? c->n_bigl : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(&c->cursor_big, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count < kBigList ? o.count : kBigList;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBigThreads) {
+            if (t < n) {
+                const SortedRec r = sorted.load(o.offset + t);
+                s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                s_idx[t] = t;
+            }
+            else {
+                s_key[t] = ~0ull;
+                s_idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, kBigThreads);
+        if (p.blend) {
+            CellFold f;  // only thread 0's copy is used
+            for (uint32_t base = 0; base < n; base += kBigStage) {
+                const uint32_t m_here = n - base < kBigStage ? n - base : kBigStage;
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < m_here; t += kBigThreads) {
+                    const SortedRec r = sorted.load(o.offset + s_idx[base + t]);
+                    s_hi[t] = r.keyhi;
+                    s_w[t] = r.w;
+                    s_u[t] = r.u;
+                    s_v[t] = r.v;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    for (uint32_t t = 0; t < m_here; ++t) f.add(m, p.blend, s_hi[t], s_w[t], s_u[t], s_v[t]);
+            }
+            if (threadIdx.x == 0) out[i] = cell_record(o, f.finish(m, p.blend), p);
+        }
+        else {
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += kBigThreads) {
+                const uint32_t hi = (uint32_t) (s_key[t] >> 32);
+                if (t == 0 || (uint32_t) (s_key[t - 1] >> 32) != hi) {
+                    SortedRec r = sorted.load(o.offset + s_idx[t]);
+                    WUv acc{r.w, r.u, r.v};
+                    for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
+                        r = sorted.load(o.offset + s_idx[j]);
+                        acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                    }
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBigThreads / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                const uint32_t hi = (uint32_t) (s_key[t] >> 32);
+                SortedRec r = sorted.load(o.offset + s_idx[t]);
+                WUv acc{r.w, r.u, r.v};
+                for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
+                    r = sorted.load(o.offset + s_idx[j]);
+                    acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                }
+                float cr, cg, cb;
+                color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                emit_cell(o, pack_argb(cr, cg, cb), acc.w, hi, out, i, c, p);
+            }
+        }
+    }
+}
+
+// Tier 4: cells with more than 8192 hits (a whole mesh inside a few voxels).  Same algorithm with the (key, idx)
+// pairs in a global scratch area; each cell bump-allocates a power-of-two range (scratch holds 2 * cap_hits pairs).
+__global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restrict__ list, Counters *c,
+                                                         const Occ *__restrict__ occ, SortedView sorted,
+                                                         Materials m, uint4 *out, uint64_t *scratch_key,
+                                                         uint32_t *scratch_idx, uint32_t scratch_cap, uint32_t list_cap,
+                                                         Params p)
+{
+    __shared__ uint32_t s_item, s_base, s_ok;
+    __shared__ unsigned long long s_best[kBlock / 64];
+    if (pass_overflowed(c, p)) return;
+    const uint32_t total = c->n_huge < list_cap ? c->n_huge : list_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(&c->cursor_huge, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        if (item >= total) break;
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const uint32_t n = o.count;
+        uint32_t n_pow2 = 1;
+        while (n_pow2 < n) n_pow2 <<= 1;
+        if (threadIdx.x == 0) {
+            s_base = atomicAdd(&c->scratch_used, n_pow2);
+            // scratch too small: the host sees scratch_used > capacity, grows it and re-runs
+            s_ok = (uint64_t) s_base + n_pow2 <= scratch_cap ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_ok) continue;
+        uint64_t *key = scratch_key + s_base;
+        uint32_t *idx = scratch_idx + s_base;
+        for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
+            if (t < n) {
+                const SortedRec r = sorted.load(o.offset + t);
+                key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
+                idx[t] = t;
+            }
+            else {
+                key[t] = ~0ull;
+                idx[t] = 0;
+            }
+        }
+        __syncthreads();
+        bitonic_sort(key, idx, n_pow2, threadIdx.x, kBlock);
+        if (p.blend) {
+            // BLEND: sequential by nature (see k_resolve_sorted)
+            if (threadIdx.x == 0) {
+                CellFold f;
+                for (uint32_t t = 0; t < n; ++t) {
+                    const SortedRec r = sorted.load(o.offset + idx[t]);
+                    f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
+                }
+                out[i] = cell_record(o, f.finish(m, p.blend), p);
+            }
+        }
+        else {
+            // MAX: fold every (sub-voxel, triangle) group at its first record, max-reduce with ties to the earlier group
+            unsigned long long best = 0;
+            for (uint32_t t = threadIdx.x; t < n; t += kBlock) {
+                const uint32_t hi = (uint32_t) (key[t] >> 32);
+                if (t == 0 || (uint32_t) (key[t - 1] >> 32) != hi) {
+                    SortedRec r = sorted.load(o.offset + idx[t]);
+                    WUv acc{r.w, r.u, r.v};
+                    for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
+                        r = sorted.load(o.offset + idx[j]);
+                        acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                    }
+                    const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
+                    best = cand > best ? cand : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(best, d, 64);
+                best = other > best ? other : best;
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63u) == 0) s_best[threadIdx.x >> 6] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (uint32_t wv = 1; wv < kBlock / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
+                const uint32_t t = 0xffffffffu - (uint32_t) best;
+                const uint32_t hi = (uint32_t) (key[t] >> 32);
+                SortedRec r = sorted.load(o.offset + idx[t]);
+                WUv acc{r.w, r.u, r.v};
+                for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
+                    r = sorted.load(o.offset + idx[j]);
+                    acc = wmix(WUv{r.w, r.u, r.v}, acc);
+                }
+                float cr, cg, cb;
+                color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+                emit_cell(o, pack_argb(cr, cg, cb), acc.w, hi, out, i, c, p);
+            }
+        }
     }
 }
 

@@ -1,19 +1,13 @@
-// o2v_dev_k5_scan_scatter.hpp -- K5: dirty-brick scan and the counting sort of the pooled hits BY BRICK
-// (k_scan_flags, k_scan_bcount, k_scatter, k_reset_bcount).
+// o2v_dev_k5_scan_scatter.hpp -- K5: dirty-brick scan, counting sort of the hits (k_scan_flags / _bricks, k_scatter, k_reset_bricks).
 //
 // Part of the device code of o2v_device.hip, which includes this file inside its anonymous namespace (one
 // translation unit: the stages share records and launch parameters).  Not a stand-alone header.
-//
-// The unit of the sort is the brick (4 x 4 x 4 output cells), not the cell: k_voxelize ranks a pooled hit among the hits of
-// its brick with one atomic per (wavefront flush, brick), so the hits a wavefront emits for a brick keep consecutive ranks
-// and the scatter writes them as one run.  The order inside a brick - by cell, then the reference's (sub-voxel, triangle,
-// leaf) order - is made by the resolve kernels, which read a brick's hits as one contiguous block.  (Round 2 sorted by cell:
-// one atomic on a 4-byte counter per hit, a 4-byte random read and a 16/24-byte random write per hit in the scatter, and
-// gathers of short per-cell runs in the replay: the three latency-bound kernels of that design.)
 
-// ---- K5a: dirty bricks ---------------------------------------------------------------------------------------
-// k_scan_flags streams the one-byte-per-brick dirty map (n_bricks bytes, 16 MiB at 1024^3), lists the dirty bricks and
-// clears their flags.
+// ---- K5a: scan + compact + reset ---------------------------------------------------------------------------
+// Two steps.  k_scan_flags streams the one-byte-per-brick dirty map (n_bricks bytes, 16 MiB at 1024^3), lists the
+// dirty bricks and clears their flags.  k_scan_bricks then reads only those bricks (four cells = one 16-byte load
+// per lane), compacts the occupied cells into `occ` through an LDS staging buffer (one global atomic per flush,
+// not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.
 
 constexpr uint32_t kFlagLoads = 2;  // 16-byte loads of the flag map per thread and round
 __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uint32_t *n_dirty, uint32_t *dirty_list, Counters *c, Params p)
@@ -66,95 +60,156 @@ __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uin
     if (n) flush(n);
 }
 
-// ---- K5b: brick counts -> offsets --------------------------------------------------------------------------------
-// Resolve tiers by the number of pooled hits of a brick (a brick's records are sorted and folded by one wavefront or
-// workgroup): up to kTierWave / kTierWave2 / kTierMid by a single wavefront out of its registers (one, two, four records per
-// lane), up to kTierLong / kTierLong2 by a workgroup in LDS (every cell of the brick folded by its own lane: the long chains
-// of a sphere's pole cells run side by side), up to kTierBig with the sort keys in 96 KiB of dynamic LDS and a sequential
-// replay, beyond that in global memory.
-constexpr uint32_t kTierWave = 64, kTierWave2 = 128, kTierMid = 256, kTierLong = 1024, kTierLong2 = 4096, kTierBig = 8192;
-constexpr uint32_t kResolveClasses = 7;
+constexpr uint32_t kScanBricksPerWave = 4;                                   // independent 1 KiB loads (four bricks each) in flight per wave
+constexpr uint32_t kScanBricksPerRound = (kBlock / 64) * kScanBricksPerWave * kBricksPerLoad;  // 4096 cells per block round
+constexpr uint32_t kScanFlushAt = 2048;
+constexpr uint32_t kScanCap = kScanFlushAt + kScanBricksPerRound * kBrickCells;
 
-struct __attribute__((aligned(16))) BrickOcc {  // 32 B: one brick with pooled hits
-    uint32_t brick;
-    uint32_t offset;    // first SortedRec of the brick
-    uint32_t count;     // number of hits
-    uint32_t out_base;  // first output record of the brick: its occupied cells follow in ascending order of the cell
-    unsigned long long cells;  // one bit per occupied cell
-    unsigned long long pad;
-};
+constexpr uint32_t kShortList = 8;     // cells with up to this many hits are sorted in registers by k_resolve
+constexpr uint32_t kLane16List = 16;   // up to this: 16 lanes per cell, bitonic sort in registers (k_resolve_wave<16>)
+constexpr uint32_t kLaneList = 32;     // up to this: 32 lanes per cell (k_resolve_wave<32>)
+constexpr uint32_t kWaveList = 64;     // up to this: one wavefront per cell (k_resolve_wave<64>)
+constexpr uint32_t kMidList = 256;     // up to this: one wavefront per cell, LDS bitonic sort
+constexpr uint32_t kLongList = 2048;   // up to this: one workgroup per cell, LDS bitonic sort
+constexpr uint32_t kBigList = 8192;    // up to this: one workgroup per cell, keys + indices in 96 KiB of dynamic LDS;
+                                       // beyond: global-memory sort
 
-struct ResolveLists {  // the bricks with pooled hits, by hit count class (each list: cap entries)
-    BrickOcc *tier[kResolveClasses];
+struct ResolveLists {  // cells k_resolve defers, by hit count class (indices into occ[])
+    uint32_t *lane16, *lane, *w64, *mid, *lng, *big, *huge;
     uint32_t cap;
 };
 
+// Cells with more than kShortList hits are resolved by the cooperative tiers; k_scan_bricks files them by hit count
+// while it builds occ[] (one global atomic per class and flush), so that every resolve tier can start at once.
+constexpr uint32_t kResolveClasses = 7;
 __device__ __forceinline__ uint32_t resolve_class(uint32_t cnt)
 {
-    return cnt <= kTierWave ? 0u : cnt <= kTierWave2 ? 1u : cnt <= kTierMid ? 2u : cnt <= kTierLong ? 3u : cnt <= kTierLong2 ? 4u : cnt <= kTierBig ? 5u : 6u;
+    return cnt <= kLane16List ? 0u
+           : cnt <= kLaneList ? 1u
+           : cnt <= kWaveList ? 2u
+           : cnt <= kMidList  ? 3u
+           : cnt <= kLongList ? 4u
+           : cnt <= kBigList  ? 5u
+                              : 6u;
+}
+__device__ __forceinline__ uint32_t *class_list(const ResolveLists &l, uint32_t k)
+{
+    return k == 0 ? l.lane16 : k == 1 ? l.lane : k == 2 ? l.w64 : k == 3 ? l.mid : k == 4 ? l.lng : k == 5 ? l.big : l.huge;
 }
 __device__ __forceinline__ uint32_t *class_counter(Counters *c, uint32_t k)
 {
-    return k == 0 ? &c->n_w64 : k == 1 ? &c->n_w128 : k == 2 ? &c->n_mid : k == 3 ? &c->n_long : k == 4 ? &c->n_long2 : k == 5 ? &c->n_bigl : &c->n_huge;
+    return k == 0 ? &c->n_lane16 : k == 1 ? &c->n_lane : k == 2 ? &c->n_w64 : k == 3 ? &c->n_mid : k == 4 ? &c->n_long
+           : k == 5 ? &c->n_bigl : &c->n_huge;
 }
 
-// One thread per dirty brick: its hit count becomes its offset in the sorted record array and the number of its occupied cells
-// its place in the output (block-level prefix sums, one reservation of (bricks, hits, cells) per workgroup round: no kernel
-// behind this one needs an atomic to place a record); the offset is written back into the counter, where k_scatter reads
-// it, the cell mask is taken over into the list entry and cleared, and the brick is filed into the list of its resolve tier.
-__global__ __launch_bounds__(kBlock) void k_scan_bcount(uint32_t *bcount, unsigned long long *bmask, const uint32_t *__restrict__ dirty_list,
-                                                        Counters *c, ResolveLists lists, Params p)
+// Writes the staged occupied cells of one workgroup to `occ`, giving every cell the offset of its hits in the sorted
+// record array: one reservation of (cells, hits) per flush, offsets by a block-level prefix sum over the counts.
+// The offset is also stored in the cell itself, where k_scatter reads it.
+__device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi, uint32_t *s_cnt,
+                                           uint32_t *s_wave, uint32_t *s_base, uint32_t *s_cls /*[7], zero*/,
+                                           uint32_t *s_cls_base /*[7]*/, uint32_t *grid, Counters *c, Occ *occ,
+                                           const ResolveLists &lists, const Params &p)
 {
-    __shared__ uint32_t s_wave[kBlock / 64], s_base[3], s_cls[kResolveClasses], s_cls_base[kResolveClasses];
-    const uint32_t n_dirty = c->n_dirty < p.cap_dirty ? c->n_dirty : p.cap_dirty;
-    if (threadIdx.x < kResolveClasses) s_cls[threadIdx.x] = 0;
-    for (uint32_t base = blockIdx.x * kBlock; base < n_dirty; base += gridDim.x * kBlock) {  // (uniform per workgroup)
-        __syncthreads();
-        const uint32_t item = base + threadIdx.x;
-        const bool valid = item < n_dirty;
-        const uint32_t brick = valid ? dirty_list[item] : 0u;
-        const uint32_t cnt = valid ? bcount[brick] : 0u;
-        const unsigned long long cells = valid ? bmask[brick] : 0ull;
-        if (valid) bmask[brick] = 0ull;
-        uint32_t total, total_cells;
-        uint32_t run = block_exscan(cnt, s_wave, total);
-        __syncthreads();
-        uint32_t run_cells = block_exscan((uint32_t) __popcll(cells), s_wave, total_cells);
-        const uint32_t n_here = n_dirty - base < kBlock ? n_dirty - base : kBlock;
-        uint32_t cls = 0, cls_rank = 0;
-        if (valid && cnt) {
-            cls = resolve_class(cnt);
-            cls_rank = atomicAdd(&s_cls[cls], 1u);
+    // thread t owns the entries [t * per, (t + 1) * per)
+    const uint32_t per = (n + kBlock - 1) / kBlock;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += s_cnt[i];
+    uint32_t total;
+    uint32_t run = block_exscan(sum, s_wave, total);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base[0] = atomicAdd(&c->n_vox, n);
+        s_base[1] = atomicAdd(&c->n_sorted, total);
+    }
+    __syncthreads();
+    const uint32_t base_vox = s_base[0];
+    run += s_base[1];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t cnt = s_cnt[i];
+        const bool listed = base_vox + i < p.cap_vox;
+        if (listed) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], run, cnt};
+        grid[((uint64_t) s_hi[i] << 32) | s_lo[i]] = run;
+        if (cnt > kShortList && listed) {
+            // rank within its class among this flush's cells; the count is not needed again, the slot keeps the tag
+            const uint32_t cls = resolve_class(cnt);
+            s_cnt[i] = 0x80000000u | (cls << 24) | atomicAdd(&s_cls[cls], 1u);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(&c->n_bocc, n_here);  // (an upper bound of every tier's list: the host sizes the lists by it)
-            s_base[1] = atomicAdd(&c->n_sorted, total);
-            s_base[2] = atomicAdd(&c->n_vox, total_cells);
-        }
-        if (threadIdx.x < kResolveClasses) {
-            const uint32_t n_cls = s_cls[threadIdx.x];
-            s_cls[threadIdx.x] = 0;
-            if (n_cls) s_cls_base[threadIdx.x] = atomicAdd(class_counter(c, threadIdx.x), n_cls);
-        }
-        __syncthreads();
-        if (valid) {
-            run += s_base[1];
-            bcount[brick] = run;
-            if (cnt) {
-                const uint32_t at = s_cls_base[cls] + cls_rank;
-                if (at < lists.cap) lists.tier[cls][at] = BrickOcc{brick, run, cnt, s_base[2] + run_cells, cells, 0ull};
-            }
+        run += cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < kResolveClasses) {
+        const uint32_t n_cls = s_cls[threadIdx.x];
+        s_cls[threadIdx.x] = 0;
+        if (n_cls) s_cls_base[threadIdx.x] = atomicAdd(class_counter(c, threadIdx.x), n_cls);
+    }
+    __syncthreads();
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t tag = s_cnt[i];
+        if (tag & 0x80000000u) {
+            const uint32_t cls = (tag >> 24) & 7u, slot = s_cls_base[cls] + (tag & 0xffffffu);
+            if (slot < lists.cap) class_list(lists, cls)[slot] = base_vox + i;
         }
     }
 }
 
-// ---- K5c: scatter --------------------------------------------------------------------------------------------
-// Streams the hit pool once (coalesced 32-byte records, holes skipped) and places every hit at offset(brick) + rank, so
-// that each brick's hits are contiguous for the resolve kernels.  The hits one wavefront of k_voxelize emitted for a brick
-// have consecutive ranks and sit in one 256-slot chunk of the pool, so a wavefront here writes a few runs, not 64 pieces.
-// The record keeps its cell inside the brick in its last word.
-__global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ pool, const uint32_t *__restrict__ bcount,
+__global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const uint32_t *__restrict__ dirty_list,
+                                                        Counters *c, Occ *occ, ResolveLists lists, Params p)
+{
+    __shared__ uint32_t s_lo[kScanCap], s_hi[kScanCap], s_cnt[kScanCap];
+    __shared__ uint32_t s_n, s_base[2], s_wave[kBlock / 64], s_cls[kResolveClasses], s_cls_base[kResolveClasses];
+    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x < kResolveClasses) s_cls[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n_dirty = c->n_dirty < p.cap_dirty ? c->n_dirty : p.cap_dirty;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_rounds = (n_dirty + kScanBricksPerRound - 1) / kScanBricksPerRound;
+    for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
+        uint32_t brick[kScanBricksPerWave];
+        uint4 h[kScanBricksPerWave];
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
+            // (a load covers kBricksPerLoad bricks: kLanesPerBrick lanes each)
+            const uint32_t item = r * kScanBricksPerRound + (wave * kScanBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
+            brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBricksPerWave; ++k)
+            h[k] = brick[k] != 0xffffffffu ? reinterpret_cast<const uint4 *>(grid + (uint64_t) brick[k] * kBrickCells)[lane % kLanesPerBrick]
+                                           : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
+            if (h[k].x | h[k].y | h[k].z | h[k].w) {
+                const uint32_t hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
+#pragma unroll
+                for (uint32_t e = 0; e < 4; ++e) {
+                    if (hv[e]) {
+                        const uint64_t cell = (uint64_t) brick[k] * kBrickCells + (lane % kLanesPerBrick) * 4u + e;
+                        const uint32_t slot = atomicAdd(&s_n, 1u);
+                        s_lo[slot] = (uint32_t) cell;
+                        s_hi[slot] = (uint32_t) (cell >> 32);
+                        s_cnt[slot] = hv[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n >= kScanFlushAt) {
+            scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+        }
+        __syncthreads();
+    }
+    const uint32_t n = s_n;
+    if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
+}
+
+// ---- K5b: scatter --------------------------------------------------------------------------------------------
+// Streams the hit pool once (coalesced 32-byte records, holes skipped) and places every hit at
+// offset(cell) + rank, so that each cell's hits are contiguous for the resolve kernels.
+__global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ pool, const uint32_t *__restrict__ grid,
                                                     const Counters *c, uint32_t *sorted, uint32_t stride, Params p)
 {
     const uint32_t n = c->n_hits_reserved < p.cap_hits ? c->n_hits_reserved : p.cap_hits;
@@ -168,19 +223,23 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ p
     for (uint32_t i = lo + local_block * kBlock + threadIdx.x; i < hi; i += blocks_per_xcd * kBlock) {
         const HitRec r = pool[i];
         if (r.brick == kHoleBrick || r.pad == kPickRecord) continue;
-        const uint32_t pos = bcount[r.brick] + (r.local_rank & (kMaxRank - 1u));
+        const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
+        const uint32_t pos = grid[cell] + (r.local_rank & (kMaxRank - 1u));
         if (pos < p.cap_hits) {
-            const uint32_t local = r.local_rank >> 24;
-            if (stride == 4u) reinterpret_cast<uint4 *>(sorted)[pos] = make_uint4(r.keyhi, r.keylo, __float_as_uint(r.w), local);
-            else reinterpret_cast<SortedRec *>(sorted)[pos] = SortedRec{r.keyhi, r.keylo, r.w, r.u, r.v, local};
+            if (stride == 4u) reinterpret_cast<uint4 *>(sorted)[pos] = make_uint4(r.keyhi, r.keylo, __float_as_uint(r.w), 0u);
+            else reinterpret_cast<SortedRec *>(sorted)[pos] = SortedRec{r.keyhi, r.keylo, r.w, r.u, r.v, 0u};
         }
     }
 }
 
-// Zeroes the counters of the dirty bricks: leaves them clean for the next voxelization.  Runs after k_scatter has read
-// the offsets.
-__global__ __launch_bounds__(kBlock) void k_reset_bcount(uint32_t *bcount, const uint32_t *__restrict__ dirty_list, const Counters *c, Params p)
+// Zeroes the dirty bricks (whole bricks, one 16-byte store per lane): leaves the dense grid clean for the next
+// voxelization.  Runs after k_scatter has read the per-cell offsets.
+__global__ __launch_bounds__(kBlock) void k_reset_bricks(uint32_t *grid, const uint32_t *__restrict__ dirty_list,
+                                                         const Counters *c, Params p)
 {
     const uint32_t n_dirty = c->n_dirty < p.cap_dirty ? c->n_dirty : p.cap_dirty;
-    for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < n_dirty; item += gridDim.x * kBlock) bcount[dirty_list[item]] = 0u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t item = (blockIdx.x * (kBlock / 64) + wave) * kBricksPerLoad + lane / kLanesPerBrick; item < n_dirty;
+         item += gridDim.x * (kBlock / 64) * kBricksPerLoad)
+        reinterpret_cast<uint4 *>(grid + (uint64_t) dirty_list[item] * kBrickCells)[lane % kLanesPerBrick] = make_uint4(0, 0, 0, 0);
 }

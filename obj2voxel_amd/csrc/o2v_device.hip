@@ -111,18 +111,18 @@ struct o2v_hip_ctx {
     HitRec *d_pool = nullptr;
     SortedRec *d_sorted = nullptr;  // cap_hits records (read through SortedView: 24 or 16 bytes per record)
     uint32_t sorted_stride = 6;
+    Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
-    BrickOcc *d_tier[kResolveClasses] = {};  // the bricks with pooled hits, one list per resolve tier: cap_bocc entries each
-    uint32_t cap_bocc = 0;
+    uint32_t *d_list_lane16 = nullptr, *d_list_w64 = nullptr, *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_big = nullptr,
+             *d_list_huge = nullptr;  // cap_vox each
     uint64_t *d_scratch_key = nullptr;  // tier-4 resolve scratch, allocated on first need
     uint32_t *d_scratch_idx = nullptr;
     uint32_t cap_scratch = 0;
     uint32_t cap_leaves = 0, cap_tiles = 0, cap_big = 0, cap_nodes = 0, cap_hits = 0, cap_vox = 0;
 
-    // one hit counter per brick of this context's slab (the counting sort of the pooled hits is by brick)
-    uint32_t *d_bcount = nullptr;
-    unsigned long long *d_bmask = nullptr;  // ... and one bit per cell that received a pooled hit
-    uint64_t bcount_bricks = 0;   // allocated
+    // dense grid of list heads for this context's slab
+    uint32_t *d_grid = nullptr;
+    uint64_t grid_cells = 0;      // allocated
     uint8_t *d_brick_dirty = nullptr;   // one flag per brick (padded to 16 bytes)
     uint32_t *d_dirty_list = nullptr;   // dirty brick ids of the current run
     uint32_t cap_pick_extra = 0;
@@ -138,7 +138,6 @@ struct o2v_hip_ctx {
 
     // results of the last run
     uint64_t n_vox = 0;
-    uint32_t last_tier[kResolveClasses] = {}, last_nbx = 0, last_nby = 0, last_zo0 = 0;  // of the last run (debug calls)
     bool last_direct = false;  // the last run used the 64-bit max grid: occ[] / sorted[] do not describe every voxel
     o2v_hip_timings timings = {};
     o2v_hip_stats stats = {};
@@ -298,12 +297,12 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         if (use_uv) {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES_UV * (kBlock / VoxShape<true>::block);
             O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         else {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
             O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
@@ -331,14 +330,13 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
         O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
                            dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, ctx->d_ctr, p);
-        ResolveLists lists{};
-        for (uint32_t k = 0; k < kResolveClasses; ++k) lists.tier[k] = ctx->d_tier[k];
-        lists.cap = p.cap_bocc;
-        O2V_LAUNCH("k_scan_bcount", s, k_scan_bcount, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_bcount, ctx->d_bmask,
-                           ctx->d_dirty_list, ctx->d_ctr, lists, p);
-        O2V_LAUNCH("k_scatter", s, k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_bcount, ctx->d_ctr,
+        const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
+                                 ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
+        O2V_LAUNCH("k_scan_bricks", s, k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
+                           ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, lists, p);
+        O2V_LAUNCH("k_scatter", s, k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
-        O2V_LAUNCH("k_reset_bcount", s, k_reset_bcount, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_bcount,
+        O2V_LAUNCH("k_reset_bricks", s, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr, p);
     }
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
@@ -346,35 +344,41 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
     if (run_general) {
         const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
-        // The tiers work on disjoint bricks and were filed by k_scan_bcount, so they run side by side: the bulk tier on the
-        // main stream, the others (few bricks, long chains) on three auxiliary streams.
+        // The tiers work on disjoint cells and were filed by k_scan_bricks, so they run side by side: tier 1 on the
+        // main stream, the cooperative tiers (short, latency-bound launches) on three auxiliary streams.
         const bool fork = debug_sync_level() != 1;
-        hipStream_t sm = s, sl = s, sb = s;
+        hipStream_t sw = s, sm = s, sl = s;
         if (fork) {
-            sm = ctx->aux[0];
-            sl = ctx->aux[1];
-            sb = ctx->aux[2];
+            sw = ctx->aux[0];
+            sm = ctx->aux[1];
+            sl = ctx->aux[2];
             O2V_CHECK(hipEventRecord(ctx->ev_fork, s));
             for (hipStream_t a : ctx->aux) O2V_CHECK(hipStreamWaitEvent(a, ctx->ev_fork, 0));
         }
-        Counters *ctr = ctx->d_ctr;
-        O2V_LAUNCH("k_resolve_brick_wave<1>", s, k_resolve_brick_wave<1>, dim3((uint32_t) ctx->num_cus * 32u), dim3(64), 0, s,
-                           ctx->d_tier[0], &ctr->n_w64, ctr, sorted_view, m, ctx->d_out, p.cap_bocc, p);
-        O2V_LAUNCH("k_resolve_brick_wave<2>", sm, k_resolve_brick_wave<2>, dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, sm,
-                           ctx->d_tier[1], &ctr->n_w128, ctr, sorted_view, m, ctx->d_out, p.cap_bocc, p);
-        O2V_LAUNCH("k_resolve_brick_wave<4>", sm, k_resolve_brick_wave<4>, dim3((uint32_t) ctx->num_cus * 16u), dim3(64), 0, sm,
-                           ctx->d_tier[2], &ctr->n_mid, ctr, sorted_view, m, ctx->d_out, p.cap_bocc, p);
-        O2V_LAUNCH("k_resolve_brick<256,1024>", sl, (k_resolve_brick<kBlock, kTierLong, true, true>), dim3((uint32_t) ctx->num_cus * 3u), dim3(kBlock), 0, sl,
-                           ctx->d_tier[3], &ctr->n_long, &ctr->cursor_long, ctr, sorted_view, m, ctx->d_out, p.cap_bocc, p);
-        O2V_LAUNCH("k_resolve_brick<1024,4096>", sb, (k_resolve_brick<1024, kTierLong2, true, false>), dim3((uint32_t) ctx->num_cus), dim3(1024), 0, sb,
-                           ctx->d_tier[4], &ctr->n_long2, &ctr->cursor_long2, ctr, sorted_view, m, ctx->d_out, p.cap_bocc, p);
-        O2V_LAUNCH("k_resolve_brick_big<false>", sb, k_resolve_brick_big<false>, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBigThreads), kTierBig * 12u, sb,
-                           ctx->d_tier[5], &ctr->n_bigl, &ctr->cursor_big, ctr, sorted_view, m, ctx->d_out,
-                           (uint64_t *) nullptr, (uint32_t *) nullptr, 0u, p.cap_bocc, p);
+        if (use_uv)
+            O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+                               ctx->d_out, p);
+        else
+            O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+                               ctx->d_out, p);
+        O2V_LAUNCH("k_resolve_wave<16>", sw, k_resolve_wave<16>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
+                           &ctx->d_ctr->n_lane16, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_LAUNCH("k_resolve_wave<32>", sw, k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane,
+                           &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_LAUNCH("k_resolve_wave<64>", sm, k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_w64,
+                           &ctx->d_ctr->n_w64, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_LAUNCH("k_resolve_sorted<64,256>", sm, (k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 8u), dim3(64), 0, sm,
+                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_ctr, ctx->d_occ, sorted_view, m,
+                           ctx->d_out, p.cap_vox, p);
+        O2V_LAUNCH("k_resolve_sorted<256,2048>", sl, (k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sl,
+                           ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_ctr, ctx->d_occ, sorted_view, m,
+                           ctx->d_out, p.cap_vox, p);
+        O2V_LAUNCH("k_resolve_big", sl, k_resolve_big, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBigThreads), kBigList * 12u, sl, ctx->d_list_big,
+                           ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         if (ctx->d_scratch_key) {
-            O2V_LAUNCH("k_resolve_brick_big<true>", sb, k_resolve_brick_big<true>, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBigThreads), 0, sb,
-                               ctx->d_tier[6], &ctr->n_huge, &ctr->cursor_huge, ctr, sorted_view, m, ctx->d_out,
-                               ctx->d_scratch_key, ctx->d_scratch_idx, ctx->cap_scratch, p.cap_bocc, p);
+            O2V_LAUNCH("k_resolve_huge", sl, k_resolve_huge, dim3((uint32_t) ctx->num_cus / 2u), dim3(kBlock), 0, sl, ctx->d_list_huge,
+                               ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, ctx->d_scratch_key,
+                               ctx->d_scratch_idx, ctx->cap_scratch, p.cap_vox, p);
         }
         if (fork)
             for (int j = 0; j < 3; ++j) {
@@ -420,20 +424,6 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 namespace o2v {
 
 hipStream_t ctx_stream(o2v_hip_ctx *ctx) { return ctx->stream; }
-
-// the bricks with pooled hits of the last run, all tiers (debug calls)
-int ctx_last_bricks(o2v_hip_ctx *ctx, std::vector<BrickOcc> &out)
-{
-    O2V_CHECK(hipSetDevice(ctx->device));
-    out.clear();
-    for (uint32_t k = 0; k < kResolveClasses; ++k) {
-        const size_t at = out.size();
-        out.resize(at + ctx->last_tier[k]);
-        if (ctx->last_tier[k])
-            O2V_CHECK(hipMemcpy(out.data() + at, ctx->d_tier[k], ctx->last_tier[k] * sizeof(BrickOcc), hipMemcpyDeviceToHost));
-    }
-    return O2V_HIP_OK;
-}
 int ctx_device(const o2v_hip_ctx *ctx) { return ctx->device; }
 
 int ctx_alloc_triangles(o2v_hip_ctx *ctx, uint64_t count, bool uvs, bool types, bool colors, bool texids)
@@ -547,9 +537,9 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
-    // k_resolve_brick_big<false> sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_brick_big<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int) (kTierBig * 12u));
+    // k_resolve_big sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int) (kBigList * 12u));
     *out_ctx = ctx;
     return O2V_HIP_OK;
 }
@@ -561,8 +551,8 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
-                    ctx->d_pool,  ctx->d_sorted, ctx->d_out,      ctx->d_bcount, ctx->d_bmask, ctx->d_jobq,
-                    ctx->d_tier[0], ctx->d_tier[1], ctx->d_tier[2], ctx->d_tier[3], ctx->d_tier[4], ctx->d_tier[5], ctx->d_tier[6], ctx->d_scratch_key, ctx->d_scratch_idx,
+                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq,
+                    ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
@@ -835,35 +825,30 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     const bool use_uv = ctx->d_uvs && ctx->any_textured;
     ctx->sorted_stride = use_uv ? 6u : 4u;
 
-    // one hit counter and one dirty flag per brick of the slab (bricks of 4 x 4 x 4 cells, see cell_index); allocated zeroed,
-    // kept clean by k_scan_flags / k_reset_bcount
+    // dense grid for the slab (bricked, see cell_index) + one dirty flag per brick; allocated zeroed, kept clean
+    // by k_scan_flags / k_scan_bricks
     const uint64_t cells = n_bricks * kBrickCells;
     ctx->stats.grid_cells = cells;
-    ctx->stats.grid_bytes = n_bricks * (sizeof(uint32_t) + sizeof(unsigned long long)) + n_bricks;
-    if (n_bricks > ctx->bcount_bricks || !ctx->d_bcount) {
-        for (void *q : {(void *) ctx->d_bcount, (void *) ctx->d_bmask, (void *) ctx->d_brick_dirty, (void *) ctx->d_dirty_list})
+    ctx->stats.grid_bytes = cells * sizeof(uint32_t) + n_bricks;
+    if (cells > ctx->grid_cells || !ctx->d_grid) {
+        for (void *q : {(void *) ctx->d_grid, (void *) ctx->d_brick_dirty, (void *) ctx->d_dirty_list})
             if (q) O2V_CHECK(hipFree(q));
-        ctx->d_bcount = nullptr;
-        ctx->d_bmask = nullptr;
+        ctx->d_grid = nullptr;
         ctx->d_brick_dirty = nullptr;
         ctx->d_dirty_list = nullptr;
-        ctx->bcount_bricks = 0;
+        ctx->grid_cells = 0;
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_grid), cells * sizeof(uint32_t)));
+        ctx->grid_cells = cells;
         ctx->brick_cap = (n_bricks + 15u) & ~15ull;
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_bcount), ctx->brick_cap * sizeof(uint32_t)));
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_bmask), ctx->brick_cap * sizeof(unsigned long long)));
-        ctx->bcount_bricks = n_bricks;
         O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_brick_dirty), ctx->brick_cap));
         O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list), std::min<uint64_t>(ctx->brick_cap, kDirtyListMax) * sizeof(uint32_t)));
         ctx->grid_dirty = true;
     }
     if (ctx->grid_dirty) {
-        O2V_CHECK(hipMemsetAsync(ctx->d_bcount, 0, ctx->brick_cap * sizeof(uint32_t), ctx->stream));
-        O2V_CHECK(hipMemsetAsync(ctx->d_bmask, 0, ctx->brick_cap * sizeof(unsigned long long), ctx->stream));
+        O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
         O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
         ctx->grid_dirty = false;
     }
-    p.bcount = ctx->d_bcount;
-    p.bmask = ctx->d_bmask;
     // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
     {
         const char *off = std::getenv("O2V_NO_DIRECT_MAX");
@@ -947,13 +932,9 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         want_hits = std::max<uint64_t>(ctx->cap_hits, 512);
     }
     uint64_t want_scratch = ctx->cap_scratch;
-    // bricks with pooled hits (a surface meets about a sixteenth as many 4 x 4 x 4 bricks as cells)
-    uint64_t want_bocc = std::max<uint64_t>(ctx->cap_bocc, std::min<uint64_t>(n_bricks, ctx->n_tris + (1u << 20)));
     uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
     if (const char *tiny = std::getenv("O2V_TEST_TINY_BUFFERS"); tiny && tiny[0] == '1')
         want_vox = std::max<uint64_t>(ctx->cap_vox, 256);
-    if (const char *tiny = std::getenv("O2V_TEST_TINY_BUFFERS"); tiny && tiny[0] == '1')
-        want_bocc = std::max<uint64_t>(ctx->cap_bocc, 16);
 
     // Subdivision rounds to launch: every round halves a node's extents and a node becomes a leaf once its voxel
     // AABB volume is below 512, so ceil(log2(S)) rounds cover the usual case; if a node is still waiting after the
@@ -981,8 +962,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         int rc;
         if (pass > 1) {
             // a pass that overflowed a buffer may have left counters / offsets in cells it could not list
-            O2V_CHECK(hipMemsetAsync(ctx->d_bcount, 0, ctx->brick_cap * sizeof(uint32_t), ctx->stream));
-            O2V_CHECK(hipMemsetAsync(ctx->d_bmask, 0, ctx->brick_cap * sizeof(unsigned long long), ctx->stream));
+            O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
             O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
             if (p.direct_max) {
                 O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
@@ -1002,7 +982,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             if ((rc = grow(ctx, ctx->d_sorted, cap_s, want_hits))) return rc;
             ctx->cap_hits = cap_p;
         }
-        uint32_t cap_v1 = ctx->cap_vox;
+        uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
+        if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
         if (p.pick_max) {
             uint32_t cap_px = ctx->cap_pick_extra;
@@ -1010,15 +991,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->cap_pick_extra = cap_px;
             p.pick_extra = reinterpret_cast<uint32_t *>(ctx->d_pick_extra);
         }
-        ctx->cap_vox = cap_v1;
-        {
-            uint32_t cap_b = ctx->cap_bocc;
-            for (uint32_t k = 0; k < kResolveClasses; ++k) {
-                cap_b = ctx->cap_bocc;
-                if ((rc = grow(ctx, ctx->d_tier[k], cap_b, want_bocc))) return rc;
-            }
-            ctx->cap_bocc = cap_b;
+        for (uint32_t **lp : {&ctx->d_list_lane16, &ctx->d_list_w64, &ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
+            uint32_t cap_l = ctx->cap_vox;
+            if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;
         }
+        ctx->cap_vox = cap_v0;
         if (want_scratch) {
             uint32_t cap_s0 = ctx->cap_scratch, cap_s1 = ctx->cap_scratch;
             if ((rc = grow(ctx, ctx->d_scratch_key, cap_s0, want_scratch))) return rc;
@@ -1031,7 +1008,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         p.cap_nodes = ctx->cap_nodes;
         p.cap_hits = ctx->cap_hits;
         p.cap_vox = ctx->cap_vox;
-        p.cap_bocc = ctx->cap_bocc;
 
         if ((rc = run_pass(ctx, p, use_uv, n_rounds))) return rc;
         const Counters &h = *ctx->h_ctr;
@@ -1060,7 +1036,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(max_nodes, ctx->cap_nodes, want_nodes);
         need(h.n_hits_reserved, ctx->cap_hits, want_hits);
         need(h.n_vox, ctx->cap_vox, want_vox);
-        need(h.n_bocc, ctx->cap_bocc, want_bocc);
         if (p.direct_max) need(h.n_out, ctx->cap_vox, want_vox);
         if (n_rounds < kMaxRounds && h.n_nodes[n_rounds] != 0) {
             n_rounds = kMaxRounds;  // unusually deep subdivision
@@ -1068,7 +1043,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         }
         if (!again && h.n_huge && (!ctx->d_scratch_key || h.scratch_used > ctx->cap_scratch)) {
             // some cell holds more than kLongList hits: the global-memory sort tier needs its scratch area
-            want_scratch = (uint64_t) h.scratch_used + 1024;  // (the counter keeps counting past the capacity)
+            want_scratch = std::max<uint64_t>(2ull * ctx->cap_hits, (uint64_t) h.scratch_used + 1024);
             again = true;
         }
         if (!again) {
@@ -1077,13 +1052,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             const bool direct = p.direct_max && (p.occupancy_only || h.n_nodes[0] <= h.n_root_leaves);  // direct_active() on the device
             const uint64_t n_final = direct ? h.n_out : h.n_vox;
             ctx->last_direct = direct;
-            {
-                const uint32_t per_tier[kResolveClasses] = {h.n_w64, h.n_w128, h.n_mid, h.n_long, h.n_long2, h.n_bigl, h.n_huge};
-                for (uint32_t k = 0; k < kResolveClasses; ++k) ctx->last_tier[k] = std::min<uint32_t>(per_tier[k], ctx->cap_bocc);
-            }
-            ctx->last_nbx = p.NBx;
-            ctx->last_nby = p.NBy;
-            ctx->last_zo0 = p.zo0;
             ctx->n_vox = n_final;
             ctx->stats.leaves = h.n_leaves;
             ctx->stats.tiles = h.n_tiles;
@@ -1426,8 +1394,8 @@ int o2v_hip_voxels_device_ptr(o2v_hip_ctx *ctx, const uint32_t **out_ptr, uint64
     return O2V_HIP_OK;
 }
 
-// Debugging aid: the hit records of one output cell of the last run (the list of bricks with pooled hits and the sorted
-// records stay valid after a run).  Each record is 6 words: keyhi, keylo, w, u, v (as float bits) and its position.
+// Debugging aid: the hit records of one output cell of the last run (the occupied-cell list and the hit pool
+// stay valid after a run).  Each record is 6 words: keyhi, keylo, w, u, v (as float bits) and the pool index.
 int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t *out, uint32_t max_records,
                             uint32_t *out_count)
 {
@@ -1438,33 +1406,27 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
         return O2V_HIP_ERR_BAD_ARGUMENT;
     }
     O2V_CHECK(hipSetDevice(ctx->device));
-    std::vector<BrickOcc> bocc;
-    {
-        const int rc_list = o2v::ctx_last_bricks(ctx, bocc);
-        if (rc_list) return rc_list;
-    }
-    if (bocc.empty() || z < ctx->last_zo0) return O2V_HIP_OK;
-    const uint32_t zr = z - ctx->last_zo0;
-    const uint32_t brick = ((zr >> kBrickZs) * ctx->last_nby + (y >> kBrickYs)) * ctx->last_nbx + (x >> kBrickXs);
-    const uint32_t local = ((((zr & (kBrickZ - 1u)) << kBrickYs) + (y & (kBrickY - 1u))) << kBrickXs) + (x & (kBrickX - 1u));
-    for (const BrickOcc &o : bocc) {
-        if (o.brick != brick) continue;
-        std::vector<uint32_t> raw((size_t) o.count * ctx->sorted_stride);
-        if (o.count)
-            O2V_CHECK(hipMemcpy(raw.data(), reinterpret_cast<const uint32_t *>(ctx->d_sorted) + (size_t) o.offset * ctx->sorted_stride,
+    std::vector<Occ> occ(ctx->n_vox);
+    std::vector<uint4> vox(ctx->n_vox);
+    if (!ctx->n_vox) return O2V_HIP_OK;
+    O2V_CHECK(hipMemcpy(occ.data(), ctx->d_occ, occ.size() * sizeof(Occ), hipMemcpyDeviceToHost));
+    O2V_CHECK(hipMemcpy(vox.data(), ctx->d_out, vox.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < ctx->n_vox; ++i) {
+        if (vox[i].x != x || vox[i].y != y || vox[i].z != z) continue;
+        const uint32_t n = occ[i].count < max_records ? occ[i].count : max_records;
+        std::vector<uint32_t> raw((size_t) n * ctx->sorted_stride);
+        if (n)
+            O2V_CHECK(hipMemcpy(raw.data(), reinterpret_cast<const uint32_t *>(ctx->d_sorted) + (size_t) occ[i].offset * ctx->sorted_stride,
                                 raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        uint32_t n = 0;
-        for (uint32_t k = 0; k < o.count && n < max_records; ++k) {
+        for (uint32_t k = 0; k < n; ++k) {
             const uint32_t *r = &raw[(size_t) k * ctx->sorted_stride];
-            if (r[ctx->sorted_stride - 1] != local) continue;
-            uint32_t *q = out + n * 6;
-            q[0] = r[0];
-            q[1] = r[1];
-            q[2] = r[2];
-            q[3] = ctx->sorted_stride == 6 ? r[3] : 0u;
-            q[4] = ctx->sorted_stride == 6 ? r[4] : 0u;
-            q[5] = o.offset + k;
-            ++n;
+            uint32_t *o = out + k * 6;
+            o[0] = r[0];
+            o[1] = r[1];
+            o[2] = r[2];
+            o[3] = ctx->sorted_stride == 6 ? r[3] : 0u;
+            o[4] = ctx->sorted_stride == 6 ? r[4] : 0u;
+            o[5] = occ[i].offset + k;
         }
         *out_count = n;
         break;
@@ -1472,22 +1434,21 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
     return O2V_HIP_OK;
 }
 
-// Debugging aid: histogram of pooled hits per brick of the last run; bucket b counts bricks with 2^(b-1) < hits <= 2^b
+// Debugging aid: histogram of hits per occupied cell of the last run; bucket b counts cells with 2^(b-1) < hits <= 2^b
 // (bucket 0: exactly one hit), 32 buckets.
 int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32)
 {
     if (!ctx || !out32) return O2V_HIP_ERR_BAD_ARGUMENT;
     for (int i = 0; i < 32; ++i) out32[i] = 0;
+    if (!ctx->n_vox) return O2V_HIP_OK;
     if (ctx->last_direct) {
         ctx->err = "hit lists are not kept on the direct MAX path: run with O2V_NO_DIRECT_MAX=1 to inspect them";
         return O2V_HIP_ERR_BAD_ARGUMENT;
     }
-    std::vector<BrickOcc> bocc;
-    {
-        const int rc_list = o2v::ctx_last_bricks(ctx, bocc);
-        if (rc_list) return rc_list;
-    }
-    for (const BrickOcc &o : bocc) {
+    O2V_CHECK(hipSetDevice(ctx->device));
+    std::vector<Occ> occ(ctx->n_vox);
+    O2V_CHECK(hipMemcpy(occ.data(), ctx->d_occ, occ.size() * sizeof(Occ), hipMemcpyDeviceToHost));
+    for (const Occ &o : occ) {
         uint32_t b = 0;
         while ((1u << b) < o.count && b < 31) ++b;
         out32[b]++;

@@ -467,17 +467,23 @@ def cpu_baseline(verts, res, expect_voxels, supersampling=1):
         oracle.set_threads(threads)
         t0 = time.perf_counter()
         vox = oracle.voxelize(verts, res, supersampling=supersampling)   # (occupancy does not depend on materials)
-        return len(vox), time.perf_counter() - t0
+        return len(vox), time.perf_counter() - t0, oracle.phase_seconds()
 
     once(cores)  # warm-up: page in the library, spawn the thread pool
     runs = [once(cores) for _ in range(3)]
     n_vox = runs[0][0]
-    med = statistics.median(t for _, t in runs)
-    n1, t1 = once(1)
+    med = statistics.median(t for _, t, _ in runs)
+    phases = sorted(runs, key=lambda r: r[1])[1][2]   # of the median run: prelude, chunk loop (the algorithm), output join
+    n1, t1, phases1 = once(1)
     oracle.set_threads(1)
     return {"value": round(n_vox / med / 1e6, 3), "unit": "Mvoxels/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "value_1_thread": round(n1 / t1 / 1e6, 3),
-            "runs_s": [round(t, 3) for _, t in runs], "run_1_thread_s": round(t1, 2),
+            "runs_s": [round(t, 3) for _, t, _ in runs], "run_1_thread_s": round(t1, 2),
+            # the harness around the algorithm is parallel too (copy, bounds, transform, chunk binning, output join); what is
+            # left of it and the Python call are the serial part
+            "phases_s": {"prelude": round(phases[0], 4), "chunk_loop": round(phases[1], 4), "join": round(phases[2], 4)},
+            "chunk_loop_mvoxels_per_s": round(n_vox / phases[1] / 1e6, 2) if phases[1] > 0 else None,
+            "phases_1_thread_s": {"prelude": round(phases1[0], 4), "chunk_loop": round(phases1[1], 4), "join": round(phases1[2], 4)},
             "sample": f"the full workload ({len(verts)} tris at {res}^3 -> {n_vox} voxels): median of 3 runs with {cores} threads "
                       f"over 64^3 chunks after one warm-up run, and one run with 1 thread",
             "matches_gpu_voxel_count": n_vox == expect_voxels}

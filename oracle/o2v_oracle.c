@@ -27,6 +27,7 @@
  * All arithmetic is IEEE binary32 evaluated in source order; build with -ffp-contract=off (no FMA).
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,6 +57,7 @@ typedef struct {
 static o2v_oracle_stats g_stats;              /* totals of the last run */
 static _Thread_local o2v_oracle_stats t_stats;  /* per worker thread, merged at the end of a run */
 static int g_threads = 1;
+static double g_phase_seconds[3] = {0, 0, 0};
 /* Chunk-parallel execution like the reference's worker pool (one VOXELIZE_CHUNK command per chunk,
  * obj2voxel.cpp:415-424,979): results do not depend on the thread count because chunks are independent. */
 void o2v_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
@@ -710,8 +712,12 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
     const uint32_t sample_res = resolution * supersampling; /* obj2voxel.cpp:684-698 */
     const uint32_t chunks_per_axis = (sample_res + O2V_CHUNK - 1) / O2V_CHUNK; /* :580-581 */
 
+    const double t_begin = omp_get_wtime();
     cached_tri *tris = (cached_tri *) calloc(T, sizeof(cached_tri));
-    for (uint64_t i = 0; i < T; ++i) {
+    /* (the harness around the reference's algorithm is parallel too - copy, bounds, transform, binning, merge - so that the
+     * multi-threaded baseline measures the algorithm, not a serial prelude; results do not depend on the thread count) */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t) T; ++i) {
         const float *p = verts + i * 9;
         for (unsigned k = 0; k < 3; ++k) {
             tris[i].geo.v[k].x = p[k * 3 + 0];
@@ -742,7 +748,11 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
         mesh_max.z = bounds[5];
     }
     else {
-        for (uint64_t b = 0; b < T; b += O2V_BATCH) {
+        /* batches are merged under a mutex in the reference (boundsMutex); min / max are exact and order-free */
+        const int64_t n_batches = (int64_t) ((T + O2V_BATCH - 1) / O2V_BATCH);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (int64_t bi = 0; bi < n_batches; ++bi) {
+            const uint64_t b = (uint64_t) bi * O2V_BATCH;
             uint64_t end = b + O2V_BATCH < T ? b + O2V_BATCH : T;
             v3 mn = {INFINITY, INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY, -INFINITY};
             for (uint64_t i = b; i < end; ++i) {
@@ -754,19 +764,23 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                 mx.y = fmax2(tmx.y, mx.y);
                 mx.z = fmax2(tmx.z, mx.z);
             }
-            mesh_min.x = fmin2(mesh_min.x, mn.x);
-            mesh_min.y = fmin2(mesh_min.y, mn.y);
-            mesh_min.z = fmin2(mesh_min.z, mn.z);
-            mesh_max.x = fmax2(mesh_max.x, mx.x);
-            mesh_max.y = fmax2(mesh_max.y, mx.y);
-            mesh_max.z = fmax2(mesh_max.z, mx.z);
+#pragma omp critical(o2v_bounds)
+            {
+                mesh_min.x = fmin2(mesh_min.x, mn.x);
+                mesh_min.y = fmin2(mesh_min.y, mn.y);
+                mesh_min.z = fmin2(mesh_min.z, mn.z);
+                mesh_max.x = fmax2(mesh_max.x, mx.x);
+                mesh_max.y = fmax2(mesh_max.y, mx.y);
+                mesh_max.z = fmax2(mesh_max.z, mx.z);
+            }
         }
     }
 
     affine xf = compute_mesh_transform(mesh_min, mesh_max, sample_res, unit ? unit : ident);
 
     /* applyMeshTransform, obj2voxel.cpp:202-224 */
-    for (uint64_t i = 0; i < T; ++i) {
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t) T; ++i) {
         for (unsigned k = 0; k < 3; ++k) tris[i].geo.v[k] = affine_apply(&xf, tris[i].geo.v[k]);
         uint32_t lo[3], hi[3];
         tri_voxel_bounds(&tris[i].geo, lo, hi);
@@ -776,35 +790,52 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
         }
     }
 
-    /* sortTriangleIntoChunks, obj2voxel.cpp:226-243: ascending triangle order inside each chunk (CSR here) */
+    /* sortTriangleIntoChunks, obj2voxel.cpp:226-243: ascending triangle order inside each chunk (CSR here).  The triangle
+     * list is cut into contiguous ranges, one per thread: every range counts its entries per chunk, a prefix over (chunk,
+     * range) gives each range its place in each chunk's list, and the ranges fill their places - ascending triangle order
+     * inside a chunk follows from the order of the ranges, as in the reference's serial loop (obj2voxel.cpp:489-491). */
     const size_t nchunks = (size_t) chunks_per_axis * chunks_per_axis * chunks_per_axis;
     uint64_t *chunk_start = (uint64_t *) calloc(nchunks + 1, sizeof(uint64_t));
-    for (int pass = 0; pass < 2; ++pass) {
+    {
+        int n_ranges = g_threads;
+        while (n_ranges > 1 && (size_t) n_ranges * nchunks > ((size_t) 1 << 26)) n_ranges /= 2;
+        uint32_t *cnt = (uint32_t *) calloc((size_t) n_ranges * nchunks, sizeof(uint32_t));
         uint32_t *chunk_items = NULL;
-        uint64_t *fill = NULL;
-        if (pass == 1) {
-            uint64_t acc = 0;
-            for (size_t c = 0; c < nchunks; ++c) {
-                uint64_t n = chunk_start[c];
-                chunk_start[c] = acc;
-                acc += n;
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma omp parallel for num_threads(g_threads) schedule(static, 1)
+            for (int r = 0; r < n_ranges; ++r) {
+                const uint64_t i0 = T * (uint64_t) r / (uint64_t) n_ranges, i1 = T * (uint64_t) (r + 1) / (uint64_t) n_ranges;
+                uint32_t *row = cnt + (size_t) r * nchunks;
+                for (uint64_t i = i0; i < i1; ++i) {
+                    const cached_tri *t = &tris[i];
+                    for (uint32_t z = t->chunk_min[2]; z <= t->chunk_max[2] && z < chunks_per_axis; ++z)
+                        for (uint32_t y = t->chunk_min[1]; y <= t->chunk_max[1] && y < chunks_per_axis; ++y)
+                            for (uint32_t x = t->chunk_min[0]; x <= t->chunk_max[0] && x < chunks_per_axis; ++x) {
+                                size_t c = ((size_t) z * chunks_per_axis + y) * chunks_per_axis + x;
+                                if (pass == 0) row[c]++;
+                                else chunk_items[row[c]++] = (uint32_t) i;
+                            }
+                }
             }
-            chunk_start[nchunks] = acc;
-            chunk_items = (uint32_t *) malloc(sizeof(uint32_t) * (acc ? acc : 1));
-            fill = (uint64_t *) malloc(sizeof(uint64_t) * nchunks);
-            memcpy(fill, chunk_start, sizeof(uint64_t) * nchunks);
-        }
-        for (uint64_t i = 0; i < T; ++i) {
-            const cached_tri *t = &tris[i];
-            for (uint32_t z = t->chunk_min[2]; z <= t->chunk_max[2] && z < chunks_per_axis; ++z)
-                for (uint32_t y = t->chunk_min[1]; y <= t->chunk_max[1] && y < chunks_per_axis; ++y)
-                    for (uint32_t x = t->chunk_min[0]; x <= t->chunk_max[0] && x < chunks_per_axis; ++x) {
-                        size_t c = ((size_t) z * chunks_per_axis + y) * chunks_per_axis + x;
-                        if (pass == 0) chunk_start[c]++;
-                        else chunk_items[fill[c]++] = (uint32_t) i;
+            if (pass == 0) {
+                /* counts -> places: chunk by chunk, range by range (the 32-bit places bound a chunk list at 2^32 entries) */
+                uint64_t acc = 0;
+                for (size_t c = 0; c < nchunks; ++c) {
+                    chunk_start[c] = acc;
+                    for (int r = 0; r < n_ranges; ++r) {
+                        const uint32_t n = cnt[(size_t) r * nchunks + c];
+                        cnt[(size_t) r * nchunks + c] = (uint32_t) acc;
+                        acc += n;
                     }
+                }
+                chunk_start[nchunks] = acc;
+                chunk_items = (uint32_t *) malloc(sizeof(uint32_t) * (acc ? acc : 1));
+            }
         }
-        if (pass == 1) {
+        free(cnt);
+        {
+            g_phase_seconds[0] = omp_get_wtime() - t_begin;
+            const double t_vox = omp_get_wtime();
             /* voxelizeChunk for every chunk, obj2voxel.cpp:254-314,503-505 */
             size_t n_work = 0;
             size_t *work = (size_t *) malloc(sizeof(size_t) * (nchunks ? nchunks : 1));
@@ -819,6 +850,8 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                 }
                 work[n_work++] = c;
             }
+            outvec *per_thread = (outvec *) calloc((size_t) g_threads, sizeof(outvec));
+            double t_merge = 0.0;
 #pragma omp parallel num_threads(g_threads)
             {
                 voxelizer *vz = voxelizer_new();
@@ -832,20 +865,37 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                     voxelize_chunk(vz, &lov, tris, chunk_items, chunk_start[c], chunk_start[c + 1], cx, cy, cz, strategy,
                                    supersampling, textures, zlo, zhi);
                 }
+                /* every thread keeps its own output; the lists are joined below by parallel copies (the sink of the
+                 * reference takes each chunk's voxels under a mutex, obj2voxel.cpp:298-303: the order is unspecified) */
+                per_thread[omp_get_thread_num()] = lov;
 #pragma omp critical
                 {
-                    for (size_t k = 0; k < lov.n; ++k)
-                        out_push(&ov, lov.d[k * 4], lov.d[k * 4 + 1], lov.d[k * 4 + 2], lov.d[k * 4 + 3]);
                     uint64_t *dst = (uint64_t *) &g_stats;
                     const uint64_t *src = (const uint64_t *) &t_stats;
                     for (size_t k = 0; k < sizeof(g_stats) / sizeof(uint64_t); ++k) dst[k] += src[k];
                 }
-                free(lov.d);
                 voxelizer_free(vz);
+#pragma omp barrier
+#pragma omp single
+                {
+                    t_merge = omp_get_wtime();
+                    size_t total = 0;
+                    for (int k = 0; k < g_threads; ++k) total += per_thread[k].n;
+                    ov.d = (uint32_t *) malloc(sizeof(uint32_t) * 4 * (total ? total : 1));
+                    ov.n = ov.cap = total;
+                }
+                {
+                    size_t before = 0;
+                    for (int k = 0; k < omp_get_thread_num(); ++k) before += per_thread[k].n;
+                    if (lov.n) memcpy(ov.d + before * 4, lov.d, sizeof(uint32_t) * 4 * lov.n);
+                }
+                free(lov.d);
             }
+            g_phase_seconds[1] = t_merge - t_vox;
+            g_phase_seconds[2] = omp_get_wtime() - t_merge;
+            free(per_thread);
             free(work);
             free(chunk_items);
-            free(fill);
         }
     }
     free(chunk_start);
@@ -855,5 +905,12 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
 }
 
 void o2v_oracle_free(uint32_t *p) { free(p); }
+
+/* wall seconds of the last o2v_oracle_voxelize call: [0] copy + bounds + transform + chunk binning, [1] the chunk loop
+ * (the reference's algorithm), [2] joining the threads' output lists */
+void o2v_oracle_get_phase_seconds(double out[3])
+{
+    for (int k = 0; k < 3; ++k) out[k] = g_phase_seconds[k];
+}
 
 void o2v_oracle_get_stats(o2v_oracle_stats *out) { *out = g_stats; }

@@ -49,6 +49,7 @@ def lib():
         _lib.o2v_oracle_mesh_transform.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.o2v_oracle_get_stats.argtypes = [C.POINTER(_Stats)]
         _lib.o2v_oracle_set_threads.argtypes = [C.c_int]
+        _lib.o2v_oracle_get_phase_seconds.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -91,6 +92,14 @@ def voxelize(verts, resolution, *, uvs=None, types=None, colors=None, texids=Non
 def set_threads(n):
     """Chunk-parallel worker threads (default 1). Results are independent of the thread count."""
     lib().o2v_oracle_set_threads(int(n))
+
+
+def phase_seconds():
+    """Wall seconds of the last voxelize(): (prelude: copy + bounds + transform + chunk binning, the chunk loop = the
+    reference's algorithm, joining the threads' output lists)."""
+    out = (C.c_double * 3)()
+    lib().o2v_oracle_get_phase_seconds(out)
+    return tuple(float(x) for x in out)
 
 
 def stats():

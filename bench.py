@@ -178,6 +178,7 @@ def main():
             step()
         names = ("bounds_ms", "expand_ms", "voxelize_ms", "scan_ms", "resolve_ms", "total_ms", "plan_ms", "collective_ms")
         acc = {k: 0.0 for k in names}
+        parts = [0.0] * 5
         barrier()
         t0 = time.perf_counter()
         count = 0
@@ -186,11 +187,13 @@ def main():
             tm = dv.timings()
             for k in names:
                 acc[k] += tm[k]
+            parts = [a + b for a, b in zip(parts, tm["collective_parts_ms"])]
         barrier()
         elapsed = time.perf_counter() - t0
         total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed,
                                                       device="cuda" if (dist is not None and args.backend == "nccl") else None)
         run = {"name": name, "res": res, "nv": nv, "T": len(verts), "verts": verts, "voxels": total_voxels, "text": text, "kw": kw,
+               "collective_parts_ms": [x / steps for x in parts],
                "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / steps for k in names}, "stats": dv.stats()}
         if n == 1:
             # per-kernel times: two further steps with an event pair around every launch (outside the timed region: the
@@ -228,6 +231,9 @@ def main():
                 routes.append(route_entry(workloads.run(r, steps=args.route_steps, warmup=2, dv=dv, kernel_steps=2), prof))
             except Exception as e:   # noqa: BLE001 - a route that cannot run must not take the headline down
                 routes.append({"workload": r, "error": f"{type(e).__name__}: {e}"})
+    upload = None
+    if n > 1 and main_run["verts"] is not None:
+        upload = upload_comparison(main_run["verts"], dv, dist, args.backend, rank, barrier)
     companion = None
     if n > 1 and name == "config4" and args.workload == "auto":
         main_run["verts"] = None   # 1.8 GB of host memory
@@ -239,6 +245,8 @@ def main():
         out = report(args, n, main_run, dv, comm)
         if routes is not None:
             out["routes"] = routes
+        if upload is not None:
+            out["config"]["upload"] = upload
         if companion:
             sec = companion["seconds_per_step"]
             out["weak_scaling_companion"] = {
@@ -253,6 +261,47 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def upload_comparison(verts, dv, dist, backend, rank, barrier):
+    """SURVEY.md section 8e asks to measure, on a multi-GPU node, how the triangle list reaches the GPUs: every rank copying it
+    over its own PCIe link (what the sharded run does: o2v_hip_set_triangles per rank) against one host-to-device copy on rank
+    0 followed by an RCCL broadcast over xGMI (here: torch.distributed's broadcast of the same bytes, backend nccl = RCCL).
+    Wall times, max over ranks, best of 3."""
+    import time as _t
+    import torch
+    out = {"bytes": int(verts.nbytes), "what": "triangle list to every GPU: per-rank H2D (o2v_hip_set_triangles) vs H2D on rank 0 + RCCL broadcast"}
+    best = None
+    for _ in range(3):
+        barrier()
+        t0 = _t.perf_counter()
+        dv.set_triangles(verts)
+        torch.cuda.synchronize()
+        barrier()
+        dt = _t.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["h2d_per_rank_ms"] = round(best * 1e3, 3)
+    if backend == "nccl":
+        try:
+            host = torch.from_numpy(verts)
+            dev = torch.empty_like(host, device="cuda")
+            best = None
+            for _ in range(3):
+                barrier()
+                t0 = _t.perf_counter()
+                if rank == 0:
+                    dev.copy_(host, non_blocking=False)
+                dist.broadcast(dev, src=0)
+                torch.cuda.synchronize()
+                barrier()
+                dt = _t.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            out["h2d_rank0_plus_rccl_broadcast_ms"] = round(best * 1e3, 3)
+            del dev
+        except Exception as e:  # noqa: BLE001
+            out["h2d_rank0_plus_rccl_broadcast_ms"] = None
+            out["broadcast_error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def kernel_view(name, ms, launches, alg_bytes, prof_kernels, stale):
@@ -408,9 +457,13 @@ def report(args, n, run, dv, comm):
         "mtris_per_s": round(T / sec / 1e6, 2),
         "config": {"workload": run.get("text") or WORKLOAD_TEXT[run["name"]].format(nv=nv, T=T, res=res, n=n), "resolution": res, "triangles": T,
                    "voxels": V, "parallelism": f"zslab{n}",
-                   "collectives": None if comm is None else {"backend": comm.kind, "world": comm.world,
-                                                             "plan_ms_rank0": round(stages_ms["plan_ms"], 4),
-                                                             "collective_ms_rank0": round(stages_ms["collective_ms"], 4)}},
+                   "collectives": None if comm is None else {
+                       "backend": comm.kind, "world": comm.world, "plan_ms_rank0": round(stages_ms["plan_ms"], 4),
+                       "collective_ms_rank0": round(stages_ms["collective_ms"], 4),
+                       # device time of each collective on rank 0 (it includes waiting for the slowest rank to arrive)
+                       "per_collective_ms_rank0": dict(zip(("ready_allreduce_4B", "bounds_allreduce_24B", "histogram_allreduce_16KiB",
+                                                            "block_extents_allgather", "slab_counts_allgather"),
+                                                           [round(x, 4) for x in run.get("collective_parts_ms", [0.0] * 5)]))}},
         "roofline": roofline, "roofline_hbm_view": hbm_view if roofline is not hbm_view else None, "stages": stages, "pipeline": pipeline,
         "stats": {k: int(st[k]) for k in ("triangles", "leaves", "tiles", "candidates", "jobs", "hits", "voxels", "bricks", "dirty_bricks")
                   if k in st},

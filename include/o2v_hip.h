@@ -80,6 +80,10 @@ typedef struct {
                             (host wall time; not part of total_ms) */
     float collective_ms; /* ... of which inside the collectives (all-reduce of bounds and histogram, all-gather of the
                             block extents and of the slab counts) */
+    float collective_parts_ms[5]; /* the same by collective, device time on the context's stream: [0] readiness word
+                            (all-reduce max of 4 bytes), [1] mesh bounds (all-reduce min + max of 3 x u32), [2] z histogram of
+                            predicted work (all-reduce sum of 2048 x u64), [3] block z extents (all-gather, 8 bytes per 256
+                            triangles), [4] slab voxel counts (all-gather, 8 bytes per rank) */
 } o2v_hip_timings;
 
 /* Work counters of the last o2v_hip_voxelize call. */

@@ -357,7 +357,7 @@ std::mutex g_session_mutex;
 Session *g_cached_session = nullptr;  // intentionally never destroyed at exit (HIP may already be torn down)
 bool g_cached_busy = false;
 
-Session *acquire_session(const std::vector<int> &devices, bool &from_cache)
+Session *acquire_session(const std::vector<int> &devices, bool &from_cache, std::string &why)
 {
     {
         std::lock_guard<std::mutex> lock{g_session_mutex};
@@ -373,6 +373,15 @@ Session *acquire_session(const std::vector<int> &devices, bool &from_cache)
     const int rc = devices.size() > 1 ? o2v_hip_group_create(devices.data(), (uint32_t) devices.size(), &s->group)
                                       : o2v_hip_create(devices[0], &s->ctx);
     if (rc != O2V_HIP_OK) {
+        // the reason, before the session that knows it is gone
+        std::string list;
+        for (int d : devices) list += (list.empty() ? "" : ",") + std::to_string(d);
+        const int n_dev = o2v_hip_device_count();
+        why = "device(s) " + list + " of " + std::to_string(n_dev) + " visible: code " + std::to_string(rc);
+        for (int d : devices)
+            if (d < 0 || d >= n_dev) why += "; device index " + std::to_string(d) + " does not exist (O2V_DEVICE / O2V_DEVICES)";
+        if (s->group) why += std::string("; ") + o2v_hip_group_last_error(s->group);
+        if (rc == O2V_HIP_ERR_OUT_OF_MEMORY) why += "; out of device memory";
         delete s;
         return nullptr;
     }
@@ -546,9 +555,10 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
     // staging memory.
     const std::vector<int> devices = requested_devices();
     bool from_cache = false;
-    Session *session = acquire_session(devices, from_cache);
+    std::string why;
+    Session *session = acquire_session(devices, from_cache, why);
     if (!session) {
-        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device: the GPU voxelization path cannot run "
+        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device (" + why + "): the GPU voxelization path cannot run "
                                                "and this library has no CPU fallback");
         if (inst.output_kind != IoKind::MEMORY) inst.sink.reset();
         inst.done = true;

@@ -143,12 +143,47 @@ __device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, 
     return off;
 }
 
+// The blocks of 256 triangles whose z extent (from the slab plan, k_zhist) meets this GPU's slab, compacted into a list:
+// the reference's sortTriangleIntoChunks (obj2voxel.cpp:226-243) at the granularity of a block and with one "chunk" per GPU.
+// On an N-GPU run every rank holds the whole triangle list but only ~1/N of its blocks matter to it; k_expand_roots then
+// walks the list instead of testing every block.  count = ~0: the extents were made with another transform, no list.
+__global__ __launch_bounds__(kBlock) void k_list_blocks(const float2 *__restrict__ zrange, const float *__restrict__ zrange_xform,
+                                                        const Counters *c, uint32_t *list, uint32_t *count, Params p)
+{
+    bool valid = true;
+    for (int i = 0; i < 12; ++i) valid &= __float_as_uint(zrange_xform[i]) == __float_as_uint(c->xform[i]);
+    if (!valid) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0xffffffffu;
+        return;
+    }
+    const uint32_t n_blocks = (uint32_t) ((p.n_tris + kBlock - 1) / kBlock);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t b0 = blockIdx.x * kBlock; b0 < n_blocks; b0 += gridDim.x * kBlock) {  // (uniform per wavefront)
+        const uint32_t b = b0 + threadIdx.x;
+        bool keep = false;
+        if (b < n_blocks) {
+            const float2 r = zrange[b];
+            // (a block whose extent is not finite is kept: its triangles decide for themselves)
+            keep = !(r.y < 1e9f && (floor_u32(r.y) + 1u <= p.zs0 || floor_u32(r.x) >= p.zs1));
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(count, (uint32_t) __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (keep) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u))] = b;
+        }
+    }
+}
+
 // Roots: one lane per input triangle.  applyMeshTransform (obj2voxel.cpp:202-224) then the head of
-// voxelizeTriangleToUvBuffer (voxelization.cpp:488-511).
+// voxelizeTriangleToUvBuffer (voxelization.cpp:488-511).  With a block list (k_list_blocks) only the listed blocks of 256
+// triangles are visited.
 __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict__ verts, const float *__restrict__ uvs,
                                                          Counters *c, Leaf *leaves, Tile *tiles, BigLeaf *big,
                                                          Node *nodes_out, const float2 *__restrict__ zrange,
-                                                         const float *__restrict__ zrange_xform, Params p)
+                                                         const float *__restrict__ zrange_xform,
+                                                         const uint32_t *__restrict__ block_list, const uint32_t *block_count, Params p)
 {
     __shared__ __align__(8) uint32_t s_wave[2 * (kBlock / 64)];
     __shared__ uint32_t s_base[4];
@@ -174,8 +209,13 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
 #define O2V_ROOT_BATCH 3
 #endif
     constexpr uint32_t kRootBatch = O2V_ROOT_BATCH;
+    // the sequence of blocks this launch visits: the listed ones (their extents were already tested), or all
+    const bool listed = block_list != nullptr && *block_count != 0xffffffffu;
+    if (listed) use_zrange = false;
+    const uint64_t n_seq = listed ? (uint64_t) *block_count : (p.n_tris + kBlock - 1) / kBlock;
+    const uint64_t n_super = (n_seq + kRootBatch - 1) / kRootBatch;
+    auto block_at = [&](uint64_t i) -> uint64_t { return i >= n_seq ? ~0ull : (listed ? (uint64_t) block_list[i] : i); };
     const uint64_t n_blocks = (p.n_tris + kBlock - 1) / kBlock;
-    const uint64_t n_super = (n_blocks + kRootBatch - 1) / kRootBatch;
 
     // Vertex (and uv) staging is software-pipelined: while one sub-batch is classified from LDS, the loads of the next
     // one in the sequence are already in flight (15 registers per lane).
@@ -268,9 +308,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         bool as_leaf = false, as_node = false;
         // pass 1: what this lane's (up to) four triangles emit
         for (uint32_t k = 0; k < kRootBatch; ++k) {
-            const uint64_t blk = sblk * kRootBatch + k;
+            const uint64_t at = sblk * kRootBatch + k, blk = block_at(at);
             // after the last sub-batch of this pass comes the first one again (pass 2)
-            classify(blk, k + 1 < kRootBatch ? blk + 1 : sblk * kRootBatch, s, e, pl, area, as_leaf, as_node);
+            classify(blk, block_at(k + 1 < kRootBatch ? at + 1 : sblk * kRootBatch), s, e, pl, area, as_leaf, as_node);
             sum.n_leaf += e.n_leaf;
             sum.n_tile += e.n_tile;
             sum.n_big += e.n_big;
@@ -283,9 +323,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         if (threadIdx.x == 0) s_cand = 0;
         // pass 2: the same triangles again, now written to their slots
         for (uint32_t k = 0; k < kRootBatch; ++k) {
-            const uint64_t blk = sblk * kRootBatch + k;
+            const uint64_t at = sblk * kRootBatch + k, blk = block_at(at);
             // ... and after the last one of pass 2 the first sub-batch of this workgroup's next super-block
-            const uint64_t next = k + 1 < kRootBatch ? blk + 1 : (sblk + gridDim.x) * kRootBatch;
+            const uint64_t next = block_at(k + 1 < kRootBatch ? at + 1 : (sblk + gridDim.x) * kRootBatch);
             if (!classify(blk, next, s, e, pl, area, as_leaf, as_node)) continue;
             const uint32_t tri = (uint32_t) (blk * kBlock + threadIdx.x);
             if (as_leaf) {

@@ -70,6 +70,7 @@ struct o2v_hip_ctx {
     hipEvent_t ev[6] = {};
     hipEvent_t ev_coll[2] = {};                 // sharded planning: around the collectives
     unsigned long long *d_counts = nullptr, *h_counts = nullptr;  // per-rank voxel counts (all-gathered), world entries
+    uint32_t *d_status = nullptr, *h_status = nullptr;            // sharded runs: "this rank is ready" word, max-reduced over the ranks
     uint32_t cap_counts = 0;
     std::string err;
 
@@ -100,6 +101,8 @@ struct o2v_hip_ctx {
     float2 *d_zrange = nullptr;      // z extent per 256 triangles, written by the slab plan
     float *d_zrange_xform = nullptr;  // the transform they were computed with (12 floats)
     uint32_t cap_zrange = 0;
+    uint32_t *d_block_list = nullptr, *d_block_count = nullptr;  // the blocks of 256 triangles that meet the slab (k_list_blocks)
+    uint32_t cap_block_list = 0;
     float mesh_bounds_hint[6] = {0, 0, 0, 0, 0, 0};  // bounds and largest triangle extent of the uploaded mesh: only used to
     float max_tri_extent = -1.f;                     // bound the number of subdivision rounds (-1: unknown)
     uint64_t tri_generation = 0, zrange_generation = ~0ull;  // the extents belong to the triangles of that upload
@@ -138,6 +141,8 @@ struct o2v_hip_ctx {
 
     // results of the last run
     uint64_t n_vox = 0;
+    bool last_ran_general = true;  // the last pass enqueued the counting sort + replay stages
+    bool force_general = false;    // ... must do so whatever K1's counters say (set if the shortcut's premise did not hold)
     bool last_direct = false;  // the last run used the 64-bit max grid: occ[] / sorted[] do not describe every voxel
     o2v_hip_timings timings = {};
     o2v_hip_stats stats = {};
@@ -274,10 +279,23 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     O2V_LAUNCH("k_setup", s, k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
     O2V_CHECK(hipEventRecord(ctx->ev[1], s));
 
+    // After a slab plan the z extent of every block of 256 triangles is known: a slab that is not the whole grid visits only
+    // the blocks that meet it (on N GPUs ~1/N of the list, compacted by k_list_blocks).
+    const bool have_zrange = ctx->zrange_generation == ctx->tri_generation;
+    const uint64_t n_tri_blocks = (p.n_tris + kBlock - 1) / kBlock;
+    uint32_t *block_list = nullptr;
+    const char *list_hook = std::getenv("O2V_TEST_BLOCK_LIST");  // test hook: 1 = use the list for any mesh
+    const uint64_t list_above = list_hook && list_hook[0] == '1' ? 0ull : 256ull;
+    if (have_zrange && (p.zs0 != 0 || p.zs1 < p.S) && n_tri_blocks > list_above && ctx->d_block_list && ctx->cap_block_list >= n_tri_blocks) {
+        block_list = ctx->d_block_list;
+        O2V_CHECK(hipMemsetAsync(ctx->d_block_count, 0, sizeof(uint32_t), s));
+        O2V_LAUNCH("k_list_blocks", s, k_list_blocks, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (n_tri_blocks + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, s, ctx->d_zrange, ctx->d_zrange_xform, ctx->d_ctr, ctx->d_block_list, ctx->d_block_count, p);
+    }
     O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, (p.n_tris + kBlock - 1) / kBlock)),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
-                       ctx->d_big, ctx->d_nodes[0], ctx->zrange_generation == ctx->tri_generation ? ctx->d_zrange : nullptr,
-                       ctx->d_zrange_xform, p);
+                       ctx->d_big, ctx->d_nodes[0], have_zrange ? ctx->d_zrange : nullptr,
+                       ctx->d_zrange_xform, block_list, ctx->d_block_count, p);
     for (uint32_t round = 0; round < n_rounds; ++round) {
         // most rounds are empty or small: a narrow grid keeps an empty launch short (the kernel strides over its input)
         O2V_LAUNCH("k_expand_nodes", s, k_expand_nodes, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
@@ -318,7 +336,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         run_emit = p.occupancy_only || h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
         // hits are pooled only for leaves of subdivided triangles: without any, every hit goes straight into the 64-bit grid
         // (occupancy-only mode: those too)
-        run_general = !run_emit || (h.n_nodes[0] != 0 && !p.occupancy_only);
+        run_general = !run_emit || (h.n_nodes[0] != 0 && !p.occupancy_only) || ctx->force_general;
         if (run_emit) {
             const uint32_t groups = (p.n_bricks + 15u) / 16u;
             O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
@@ -339,6 +357,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         O2V_LAUNCH("k_reset_bricks", s, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr, p);
     }
+    ctx->last_ran_general = run_general;
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
 
     Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
@@ -561,6 +580,8 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->h_ctr) (void) hipHostFree(ctx->h_ctr);
     if (ctx->d_zhist) (void) hipFree(ctx->d_zhist);
     if (ctx->d_zrange) (void) hipFree(ctx->d_zrange);
+    if (ctx->d_block_list) (void) hipFree(ctx->d_block_list);
+    if (ctx->d_block_count) (void) hipFree(ctx->d_block_count);
     if (ctx->d_zrange_xform) (void) hipFree(ctx->d_zrange_xform);
     if (ctx->h_zhist) (void) hipHostFree(ctx->h_zhist);
     for (o2v_hip_staging &b : ctx->stage)
@@ -571,6 +592,8 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     for (void *q : ctx->retired) (void) hipFree(q);
     if (ctx->d_counts) (void) hipFree(ctx->d_counts);
     if (ctx->h_counts) (void) hipHostFree(ctx->h_counts);
+    if (ctx->d_status) (void) hipFree(ctx->d_status);
+    if (ctx->h_status) (void) hipHostFree(ctx->h_status);
     for (auto &e : ctx->ev_coll)
         if (e) (void) hipEventDestroy(e);
     for (auto &e : ctx->ev)
@@ -956,6 +979,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             n_rounds = std::min<uint32_t>(n_rounds, depth + 1u);
         }
     }
+    ctx->force_general = false;
     ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
     if (p.direct_max) ctx->maxgrid_dirty = true;
     for (uint32_t pass = 1; pass <= 12; ++pass) {
@@ -1041,6 +1065,13 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             n_rounds = kMaxRounds;  // unusually deep subdivision
             again = true;
         }
+        if (!again && !ctx->last_ran_general && h.n_hits != h.n_direct) {
+            // The stages behind k_voxelize were chosen from K1's counters alone, on the premise that only leaves of subdivided
+            // triangles are pooled (order key 0 <=> unsplit triangle, a convention of k_expand_*).  Pooled hits exist although
+            // the sort + replay stages were skipped: run the pass again with them.
+            ctx->force_general = true;
+            again = true;
+        }
         if (!again && h.n_huge && (!ctx->d_scratch_key || h.scratch_used > ctx->cap_scratch)) {
             // some cell holds more than kLongList hits: the global-memory sort tier needs its scratch area
             want_scratch = std::max<uint64_t>(2ull * ctx->cap_hits, (uint64_t) h.scratch_used + 1024);
@@ -1091,7 +1122,7 @@ namespace {
 // are combined over the ranks: min / max of the bounds, sum of the histogram, all-gather of the block extents
 // (`blocks_per_rank` blocks each).  Afterwards the histogram is in ctx->h_zhist and the counters in ctx->h_ctr.
 int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_begin, uint64_t tri_end, o2v_hip_comm *comm,
-                uint64_t blocks_per_rank, uint32_t &n_bins, uint32_t &bin_out, float *collective_ms)
+                uint64_t blocks_per_rank, uint32_t &n_bins, uint32_t &bin_out, float *collective_ms, float *parts_ms = nullptr)
 {
     const uint32_t ss = params->supersampling ? params->supersampling : 1u;
     const uint32_t G = params->resolution;
@@ -1115,7 +1146,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
 
     hipStream_t s = ctx->stream;
     float coll_ms = 0.f;
-    auto timed = [&](auto &&collectives) -> int {
+    auto timed = [&](int part, auto &&collectives) -> int {
         O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s));
         const int rc = collectives();
         if (rc) return rc;
@@ -1124,6 +1155,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
         float ms = 0.f;
         O2V_CHECK(hipEventElapsedTime(&ms, ctx->ev_coll[0], ctx->ev_coll[1]));
         coll_ms += ms;
+        if (parts_ms) parts_ms[part] += ms;
         return O2V_HIP_OK;
     };
     auto comm_failed = [&](int rc) {
@@ -1137,7 +1169,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
                                dim3(kBlock), 0, s, ctx->d_verts + tri_begin * 9, n_range * 9, ctx->d_ctr);
         O2V_STAGE("k_bounds");
         if (comm) {
-            int rc = timed([&]() -> int {
+            int rc = timed(1, [&]() -> int {
                 int r = comm->allreduce_min_u32(ctx->d_ctr->bounds_enc, 3, s);
                 if (!r) r = comm->allreduce_max_u32(ctx->d_ctr->bounds_enc + 3, 3, s);
                 return r;
@@ -1153,6 +1185,8 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
         if ((rc = grow(ctx, ctx->d_zrange, ctx->cap_zrange, std::max<uint64_t>(comm ? blocks_per_rank * (uint64_t) comm->world : n_blocks, 1))))
             return rc;
         if (!ctx->d_zrange_xform) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zrange_xform), 12 * sizeof(float)));
+        if ((rc = grow(ctx, ctx->d_block_list, ctx->cap_block_list, std::max<uint64_t>(n_blocks, 1)))) return rc;
+        if (!ctx->d_block_count) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_block_count), sizeof(uint32_t)));
     }
     ctx->zrange_generation = ~0ull;
     hipLaunchKernelGGL(k_zhist, dim3((uint32_t) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) ctx->num_cus * 6u, (n_range + kBlock - 1) / kBlock))),
@@ -1160,11 +1194,9 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
                        bin_out * ss, tri_begin, tri_end);
     O2V_STAGE("k_zhist");
     if (comm) {
-        int rc = timed([&]() -> int {
-            int r = comm->allreduce_sum_u64(ctx->d_zhist, kPlanBins, s);
-            if (!r) r = comm->allgather(ctx->d_zrange, blocks_per_rank * sizeof(float2), s);
-            return r;
-        });
+        int rc = timed(2, [&]() -> int { return comm->allreduce_sum_u64(ctx->d_zhist, kPlanBins, s); });
+        if (rc) return comm_failed(rc);
+        rc = timed(3, [&]() -> int { return comm->allgather(ctx->d_zrange, blocks_per_rank * sizeof(float2), s); });
         if (rc) return comm_failed(rc);
     }
     O2V_CHECK(hipMemcpyAsync(ctx->h_zhist, ctx->d_zhist, n_bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1269,27 +1301,83 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
         return O2V_HIP_OK;
     }
     if (!plan_params_ok(ctx, params, world)) return O2V_HIP_ERR_BAD_ARGUMENT;
-    O2V_CHECK(hipSetDevice(ctx->device));
-    if (!ctx->ev_coll[0])
-        for (auto &e : ctx->ev_coll) O2V_CHECK(hipEventCreate(&e));
-    if (ctx->cap_counts < world) {
-        if (ctx->d_counts) O2V_CHECK(hipFree(ctx->d_counts));
-        if (ctx->h_counts) O2V_CHECK(hipHostFree(ctx->h_counts));
-        ctx->d_counts = ctx->h_counts = nullptr;
-        ctx->cap_counts = 0;
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), world * sizeof(unsigned long long)));
-        O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts), world * sizeof(unsigned long long), hipHostMallocDefault));
-        ctx->cap_counts = world;
+    // Everything that can fail on one rank alone - the device, the allocations of the planning passes - happens before the
+    // first collective, and the ranks then agree on going ahead (one 4-byte max-reduce): a rank that returned early would
+    // leave the others waiting for it in RCCL.  The only word that has to exist for that is allocated first.
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        ctx->err = "hipSetDevice failed";
+        return O2V_HIP_ERR_HIP;  // (nothing can be communicated from a rank without its device)
+    }
+    if (!ctx->d_status) {
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_status), sizeof(uint32_t)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            ctx->err = "allocating the status word failed";
+            return O2V_HIP_ERR_OUT_OF_MEMORY;
+        }
+    }
+    const uint64_t T = ctx->n_tris, n_blocks = (T + kBlock - 1) / kBlock;
+    const uint64_t bpr = std::max<uint64_t>(1, (n_blocks + world - 1) / world);
+    float parts_ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int rc_prepare = O2V_HIP_OK;
+    {
+        auto prepare = [&]() -> int {
+            if (!ctx->ev_coll[0])
+                for (auto &e : ctx->ev_coll) O2V_CHECK(hipEventCreate(&e));
+            if (ctx->cap_counts < world) {
+                if (ctx->d_counts) O2V_CHECK(hipFree(ctx->d_counts));
+                if (ctx->h_counts) O2V_CHECK(hipHostFree(ctx->h_counts));
+                ctx->d_counts = ctx->h_counts = nullptr;
+                ctx->cap_counts = 0;
+                O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), world * sizeof(unsigned long long)));
+                O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_counts), world * sizeof(unsigned long long), hipHostMallocDefault));
+                ctx->cap_counts = world;
+            }
+            if (!ctx->d_zhist) {
+                O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zhist), kPlanBins * sizeof(unsigned long long)));
+                O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_zhist), kPlanBins * sizeof(unsigned long long), hipHostMallocDefault));
+            }
+            int rc_grow;
+            if ((rc_grow = grow(ctx, ctx->d_zrange, ctx->cap_zrange, std::max<uint64_t>(bpr * (uint64_t) world, 1)))) return rc_grow;
+            if (!ctx->d_zrange_xform) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zrange_xform), 12 * sizeof(float)));
+            if ((rc_grow = grow(ctx, ctx->d_block_list, ctx->cap_block_list, std::max<uint64_t>(n_blocks, 1)))) return rc_grow;
+            if (!ctx->d_block_count) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_block_count), sizeof(uint32_t)));
+            return O2V_HIP_OK;
+        };
+        rc_prepare = prepare();
+        if (const char *fail = std::getenv("O2V_TEST_FAIL_RANK"); fail && std::atoi(fail) == (int) rank && rc_prepare == O2V_HIP_OK) {
+            ctx->err = "O2V_TEST_FAIL_RANK: simulated failure of this rank before the collectives";  // test hook
+            rc_prepare = O2V_HIP_ERR_OUT_OF_MEMORY;
+        }
+        const std::string prepare_err = ctx->err;
+        hipStream_t s0 = ctx->stream;
+        *ctx->h_status = rc_prepare ? 1u : 0u;
+        O2V_CHECK(hipMemcpyAsync(ctx->d_status, ctx->h_status, sizeof(uint32_t), hipMemcpyHostToDevice, s0));
+        const bool time_it = ctx->ev_coll[0] && ctx->ev_coll[1];
+        if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s0));
+        if (comm->allreduce_max_u32(ctx->d_status, 1, s0)) {
+            ctx->err = std::string("collective failed: ") + comm->err;
+            return O2V_HIP_ERR_HIP;
+        }
+        if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s0));
+        O2V_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s0));
+        O2V_CHECK(hipStreamSynchronize(s0));
+        if (time_it) O2V_CHECK(hipEventElapsedTime(&parts_ms[0], ctx->ev_coll[0], ctx->ev_coll[1]));
+        if (rc_prepare) {
+            ctx->err = prepare_err;
+            return rc_prepare;
+        }
+        if (*ctx->h_status) {
+            ctx->err = "another rank could not prepare its sharded run";
+            return O2V_HIP_ERR_HIP;
+        }
     }
     const auto t0 = std::chrono::steady_clock::now();
     // this rank's share of the triangle list, in whole blocks of 256 (the unit of the block extents)
-    const uint64_t T = ctx->n_tris, n_blocks = (T + kBlock - 1) / kBlock;
-    const uint64_t bpr = std::max<uint64_t>(1, (n_blocks + world - 1) / world);
     const uint64_t b0 = std::min<uint64_t>(n_blocks, (uint64_t) rank * bpr), b1 = std::min<uint64_t>(n_blocks, (uint64_t) (rank + 1) * bpr);
     const uint64_t tri_begin = b0 * kBlock, tri_end = std::min<uint64_t>(T, b1 * kBlock);
     uint32_t n_bins = 0, bin_out = 0;
     float coll_ms = 0.f;
-    int rc = plan_passes(ctx, params, tri_begin, tri_end, comm, bpr, n_bins, bin_out, &coll_ms);
+    int rc = plan_passes(ctx, params, tri_begin, tri_end, comm, bpr, n_bins, bin_out, &coll_ms, parts_ms);
     if (rc) return rc;
     std::vector<uint32_t> cuts(world + 1);
     cuts_from_histogram(ctx->h_zhist, n_bins, bin_out, params->resolution, world, cuts.data());
@@ -1321,8 +1409,10 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
     O2V_CHECK(hipStreamSynchronize(s));
     float ms = 0.f;
     O2V_CHECK(hipEventElapsedTime(&ms, ctx->ev_coll[0], ctx->ev_coll[1]));
+    parts_ms[4] = ms;
     ctx->timings.plan_ms = plan_ms;
-    ctx->timings.collective_ms = coll_ms + ms;
+    ctx->timings.collective_ms = coll_ms + ms + parts_ms[0];
+    for (int i = 0; i < 5; ++i) ctx->timings.collective_parts_ms[i] = parts_ms[i];
     if (rc_vox) {
         ctx->err = vox_err;
         return rc_vox;

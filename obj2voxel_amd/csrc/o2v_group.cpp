@@ -126,12 +126,16 @@ struct o2v_hip_group {
         for (uint32_t r = 1; r < n; ++r) threads.emplace_back([&, r] { run(r); });
         run(0);
         for (std::thread &t : threads) t.join();
+        // every failing rank's message (the rank whose failure the others merely heard about is among them)
+        int first = O2V_HIP_OK;
+        std::string all;
         for (uint32_t r = 0; r < n; ++r)
             if (rc[r]) {
-                err = "rank " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + o2v_hip_last_error(ctx[r]);
-                return rc[r];
+                if (!first) first = rc[r];
+                all += (all.empty() ? "" : "; ") + ("rank " + std::to_string(r) + " (device " + std::to_string(devices[r]) + "): " + o2v_hip_last_error(ctx[r]));
             }
-        return O2V_HIP_OK;
+        if (first) err = all;
+        return first;
     }
 };
 
@@ -247,12 +251,15 @@ int o2v_hip_group_set_triangles(o2v_hip_group *g, const float *verts, const floa
     }
     const o2v::TriHints hints = o2v::ctx_tri_hints(g->ctx[0]);
     const o2v::TriBuffers src = o2v::ctx_tri_buffers(g->ctx[0]);
+    // Every rank allocates before any rank enters a collective: a rank whose allocation fails would otherwise return while
+    // the others wait for it in the broadcast (on_every_rank reports the failure after all ranks are back).
+    rc = g->on_every_rank([&](uint32_t r) -> int {
+        return r == 0 ? O2V_HIP_OK
+                      : o2v::ctx_alloc_triangles(g->ctx[r], count, uvs != nullptr, types != nullptr, colors != nullptr, texids != nullptr);
+    });
+    if (rc) return rc;
     return g->on_every_rank([&](uint32_t r) -> int {
         o2v_hip_ctx *c = g->ctx[r];
-        if (r != 0) {
-            const int rc2 = o2v::ctx_alloc_triangles(c, count, uvs != nullptr, types != nullptr, colors != nullptr, texids != nullptr);
-            if (rc2) return rc2;
-        }
         (void) hipSetDevice(o2v::ctx_device(c));
         const o2v::TriBuffers dst = o2v::ctx_tri_buffers(c);
         hipStream_t s = o2v::ctx_stream(c);

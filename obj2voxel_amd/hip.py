@@ -27,10 +27,12 @@ class _Texture(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("bounds_ms", C.c_float), ("expand_ms", C.c_float), ("voxelize_ms", C.c_float),
                 ("scan_ms", C.c_float), ("resolve_ms", C.c_float), ("total_ms", C.c_float), ("passes", C.c_uint32),
-                ("plan_ms", C.c_float), ("collective_ms", C.c_float)]
+                ("plan_ms", C.c_float), ("collective_ms", C.c_float), ("collective_parts_ms", C.c_float * 5)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["collective_parts_ms"] = [float(x) for x in self.collective_parts_ms]   # status, bounds, histogram, block extents, counts
+        return d
 
 
 class Stats(C.Structure):
@@ -332,28 +334,40 @@ class Comm:
         def array(ptr, n, ctype):
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,))
 
+        def guarded(fn):
+            # ctypes prints and swallows an exception raised inside a callback and the C side would see 0 = success: the
+            # library would then plan its slabs from un-reduced data.  Any failure is reported as a failed collective.
+            def wrapper(*args):
+                try:
+                    fn(*args)
+                    return 0
+                except BaseException as e:  # noqa: BLE001 - must not propagate into the C caller
+                    import sys
+                    print(f"obj2voxel_amd: collective callback failed: {type(e).__name__}: {e}", file=sys.stderr)
+                    return 1
+            return wrapper
+
         def allreduce(op, ctype):
             def fn(user, buf, n):
                 a = array(buf, n, ctype)
                 t = torch.from_numpy(a.astype(np.int64)).to(dev)  # gloo has no unsigned reductions; the values fit int64
                 dist.all_reduce(t, op=op)
                 a[:] = t.cpu().numpy().astype(a.dtype)
-                return 0
-            return fn
+            return guarded(fn)
 
+        @guarded
         def allgather(user, buf, bytes_per_rank):
             a = array(buf, bytes_per_rank * world, C.c_uint8)
             parts = [torch.empty(bytes_per_rank, dtype=torch.uint8, device=dev) for _ in range(world)]
             dist.all_gather(parts, torch.from_numpy(a[rank * bytes_per_rank:(rank + 1) * bytes_per_rank].copy()).to(dev))
             a[:] = torch.cat(parts).cpu().numpy()
-            return 0
 
+        @guarded
         def broadcast(user, buf, n, root):
             a = array(buf, n, C.c_uint8)
             t = torch.from_numpy(a.copy()).to(dev)
             dist.broadcast(t, src=root)
             a[:] = t.cpu().numpy()
-            return 0
 
         F = dict(_Callbacks._fields_)
         cb = _Callbacks(None,

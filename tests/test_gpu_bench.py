@@ -61,3 +61,23 @@ def test_bench_line_routes_and_assets(tmp_path):
     blend = line["routes"][names.index("config2_blend")]
     assert {"k_scatter", "k_scan_bricks", "k_resolve<4>"} <= set(blend["kernels_ms"])
     assert line["build_id"] and "kernels_ms" in line
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N > 1 bench plumbing on a single-GPU box: two processes (torch.distributed launch, gloo), both on GPU 0, the
+    library's collectives through host-memory callbacks.  The line carries the world size, the per-collective times and the
+    upload comparison (the RCCL broadcast leg needs the nccl backend and is absent here)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--same-device", "--workload", "weak", "--resolution", "256", "--nv", "120"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "zslab2" and line["value"] > 0
+    col = line["config"]["collectives"]
+    assert col["world"] == 2 and col["backend"] == "callbacks"
+    assert set(col["per_collective_ms_rank0"]) == {"ready_allreduce_4B", "bounds_allreduce_24B", "histogram_allreduce_16KiB",
+                                                   "block_extents_allgather", "slab_counts_allgather"}
+    assert sum(col["per_collective_ms_rank0"].values()) > 0
+    up = line["config"]["upload"]
+    assert up["h2d_per_rank_ms"] > 0 and "h2d_rank0_plus_rccl_broadcast_ms" not in up

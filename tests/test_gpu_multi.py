@@ -199,3 +199,95 @@ def test_one_process_per_rank_gloo(tmp_path, oracle):
         for r, p in enumerate(parts):
             assert ((p[:, 2] >= cuts[r]) & (p[:, 2] < cuts[r + 1])).all()
         assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), want)
+
+
+def test_a_failing_rank_does_not_leave_the_others_in_a_collective(monkeypatch):
+    """A rank that cannot prepare its sharded run (allocation failure, simulated by O2V_TEST_FAIL_RANK) reports it through the
+    status all-reduce that precedes the planning collectives: every rank returns an error instead of waiting for it."""
+    import threading
+    from obj2voxel_amd import hip
+    g = hip.DeviceGroup(_devices(3))
+    try:
+        g.set_triangles(meshes.uv_sphere(30))
+        monkeypatch.setenv("O2V_TEST_FAIL_RANK", "1")
+        result = {}
+
+        def run():
+            try:
+                g.voxelize(64, read=False)
+                result["ok"] = True
+            except hip.DeviceError as e:
+                result["err"] = str(e)
+        t = threading.Thread(target=run)
+        t.start()
+        t.join(60)
+        assert not t.is_alive(), "the group is stuck in a collective"
+        assert "err" in result and "rank 1" in result["err"], result
+        monkeypatch.delenv("O2V_TEST_FAIL_RANK")
+        counts, cuts = g.voxelize(64, read=False)      # the group is usable afterwards
+        assert sum(counts) > 0
+    finally:
+        g.close()
+
+
+def test_an_exception_in_a_collective_callback_fails_the_call():
+    """hip.Comm.torch_distributed wraps its callbacks: a Python exception inside one becomes a failed collective, not a
+    silent success with un-reduced data (ctypes would print and swallow it and return 0)."""
+    from obj2voxel_amd import hip
+
+    class FakeDist:
+        class ReduceOp:
+            MIN, MAX, SUM = 0, 1, 2
+
+        @staticmethod
+        def get_rank():
+            return 0
+
+        @staticmethod
+        def get_world_size():
+            return 1
+
+        @staticmethod
+        def get_backend():
+            return "gloo"
+
+        @staticmethod
+        def all_reduce(t, op=None):
+            raise RuntimeError("simulated timeout")
+
+        all_gather = broadcast = all_reduce
+    import os
+    os.environ["O2V_TEST_FORCE_COLLECTIVES"] = "1"
+    comm = hip.Comm.torch_distributed(FakeDist)
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_triangles(meshes.uv_sphere(10))
+        with pytest.raises(hip.DeviceError, match="collective"):
+            d.voxelize_sharded(comm, 32)
+    finally:
+        os.environ.pop("O2V_TEST_FORCE_COLLECTIVES", None)
+        d.close()
+        comm.close()
+
+
+def test_block_list_gives_the_same_slabs(oracle, monkeypatch):
+    """After a slab plan k_expand_roots visits only the listed blocks of 256 triangles that meet its slab (k_list_blocks):
+    same records as without the list, for every slab; a plan made with other parameters must not be used."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(90)         # 32 040 triangles = 126 blocks
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_triangles(v)
+        plain = [meshes.sorted_voxels(d.voxelize(200, zslab=z)) for z in ((0, 70), (70, 71), (71, 200))]
+        monkeypatch.setenv("O2V_TEST_BLOCK_LIST", "1")
+        cuts, bnd = d.plan_slabs(200, 3)
+        listed = [meshes.sorted_voxels(d.voxelize(200, zslab=z)) for z in ((0, 70), (70, 71), (71, 200))]
+        for a, b in zip(plain, listed):
+            assert np.array_equal(a, b)
+        assert d.stats()["leaves"] < len(v)           # the slab saw only its own triangles
+        # another resolution: the extents belong to another transform, the list is not used (and the result is still right)
+        other = meshes.sorted_voxels(d.voxelize(90, zslab=(10, 50)))
+        want = meshes.sorted_voxels(oracle.voxelize(v, 90, zslab=(10, 50)))
+        assert np.array_equal(other, want)
+    finally:
+        d.close()

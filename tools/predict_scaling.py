@@ -3,7 +3,9 @@
 mesh, same resolution, same cuts as o2v_hip_voxelize_sharded derives) and reports each slab's device time and voxel count.
 The plan itself is timed as the full, unsharded passes (o2v_hip_plan_slabs): an upper bound, since the N ranks share those
 passes (each streams 1/N of the triangles) and add two small all-reduces and two all-gathers instead.
-predicted efficiency = (job voxels / (slowest slab + plan / N)) / (N * N=1 rate).
+predicted efficiency = (job voxels / (slowest slab + plan / N)) / (N * N=1 rate); the speed-up over the N = 1 bench job compares
+two different jobs (the N = 1 line runs configs[2]), so the same-job strong scaling (sum of the slabs / slowest slab) is
+printed beside it.  Neither is a measurement of an N-GPU run: xGMI and RCCL latencies are not in them.
 usage: predict_scaling.py [N] [weak|config4]"""
 import json
 import sys
@@ -55,4 +57,7 @@ print(json.dumps({"n": n, "workload": name, "resolution": res, "triangles": len(
                   "max_slab_ms": max(r["ms"] for r in rows), "mean_slab_ms": round(sum(r["ms"] for r in rows) / n, 3),
                   "predicted_step_ms": round(worst, 3), "predicted_mvoxels_per_s": round(total / worst / 1e3, 1),
                   "predicted_speedup_over_n1": round((total / worst) / (v1 / t1), 2),
-                  "predicted_weak_scaling_efficiency": round((total / worst) / (n * v1 / t1), 3)}))
+                  "predicted_weak_scaling_efficiency": round((total / worst) / (n * v1 / t1), 3),
+                  # the same job on one GPU = its slabs one after the other (the whole grid may not even fit one GPU)
+                  "same_job_one_gpu_ms": round(sum(r["ms"] for r in rows) + plan_ms, 3),
+                  "predicted_same_job_strong_scaling": round((sum(r["ms"] for r in rows) + plan_ms) / worst, 2)}))

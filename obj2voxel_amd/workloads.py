@@ -115,7 +115,8 @@ def run(name, steps=5, warmup=2, dv=None, kernel_steps=0, loaded=None):
         for _ in range(steps):
             n = dv.voxelize(res, read=False, **kw)
             for k, v in dv.timings().items():
-                acc[k] = acc.get(k, 0.0) + v
+                if isinstance(v, (int, float)):
+                    acc[k] = acc.get(k, 0.0) + v
         dt = (time.perf_counter() - t0) / max(steps, 1)
         st = dv.stats()
         passes = dv.timings()["passes"]

@@ -48,7 +48,7 @@ for r in range(n):
     wall = sorted(walls)[len(walls) // 2]   # median: a single host hiccup must not decide the slowest slab
     st, t = dv.stats(), dv.timings()
     rows.append({"rank": r, "z": [cuts[r], cuts[r + 1]], "voxels": cnt, "leaves": st["leaves"], "hits": st["hits"],
-                 "ms": round(wall, 3), "stages": {k: round(v, 3) for k, v in t.items() if k.endswith("_ms")}})
+                 "ms": round(wall, 3), "stages": {k: round(v, 3) for k, v in t.items() if k.endswith("_ms") and isinstance(v, float)}})
     print(json.dumps(rows[-1]), flush=True)
 worst = max(r["ms"] for r in rows) + plan_ms / n
 total = sum(r["voxels"] for r in rows)

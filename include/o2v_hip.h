@@ -150,6 +150,12 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
 int o2v_hip_plan_slabs(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t n_slabs, uint32_t *out_z,
                        float *out_bounds);
 
+/* The thickest z-slab (in output layers, a multiple of 4 unless it is the whole grid) whose dense grids fit the device memory
+ * that is free right now (plus what the context already holds), leaving room for the work buffers: a voxelization of
+ * `params` can be run as ceil(resolution / layers) calls with consecutive slabs.  obj2voxel_voxelize() does that by itself
+ * (the reference's sparse VoxelMap has no such limit: src/util.hpp:179-208); 0 layers = not even one brick layer fits. */
+int o2v_hip_max_slab_layers(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t *out_layers);
+
 /* Copies voxels [first, first+count) of the last result to host memory as (x, y, z, argb) uint32 quadruples,
  * the layout of the reference's voxel callback (include/obj2voxel.h:35,200-209).  Order is unspecified. */
 int o2v_hip_read_voxels(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count);

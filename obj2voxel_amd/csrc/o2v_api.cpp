@@ -392,7 +392,14 @@ void release_session(Session *s, bool from_cache)
 {
     if (!s) return;
     const char *cache = std::getenv("O2V_CONTEXT_CACHE");
-    const bool keep = !(cache && cache[0] == '0');
+    bool keep = !(cache && cache[0] == '0');
+    // a session whose grids grew beyond 32 GiB (a voxelization that ran in memory-sized z-slabs holds most of the device)
+    // is not worth keeping: the next, smaller job would find the device full
+    for (uint32_t r = 0; keep && r < s->ranks(); ++r) {
+        o2v_hip_stats st{};
+        o2v_hip_get_stats(s->rank_ctx(r), &st);
+        if (st.grid_bytes > (32ull << 30)) keep = false;
+    }
     {
         std::lock_guard<std::mutex> lock{g_session_mutex};
         if (from_cache) {
@@ -456,23 +463,6 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session,
 
     const uint32_t n_ranks = session->ranks();
     std::vector<uint64_t> counts(n_ranks, 0);
-    if (session->group) {
-        if (o2v_hip_group_voxelize(session->group, &params, counts.data(), nullptr) != O2V_HIP_OK)
-            return device_error("device voxelization failed");
-    }
-    else if (o2v_hip_voxelize(session->ctx, &params, &counts[0]) != O2V_HIP_OK) {
-        return device_error("device voxelization failed");
-    }
-    const double ms_device = clock.lap_ms();
-    for (uint32_t r = 0; r < n_ranks; ++r) {
-        o2v_hip_timings tm{};
-        o2v_hip_get_timings(session->rank_ctx(r), &tm);
-        log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "device " + std::to_string(devices[r]) + " pipeline: " + std::to_string(tm.total_ms) + " ms, " +
-                                                   std::to_string(counts[r]) + " voxels, " + std::to_string(tm.passes) + " pass(es)" +
-                                                   (n_ranks > 1 ? ", plan " + std::to_string(tm.plan_ms) + " ms (collectives " +
-                                                                      std::to_string(tm.collective_ms) + " ms)"
-                                                                : std::string()));
-    }
 
     // Hand the (x, y, z, argb) records to the sink in batches (reference obj2voxel.cpp:298-303; the callback may be
     // invoked any number of times, in any order), rank by rank.  Two pinned staging buffers: while the sink consumes one
@@ -486,31 +476,90 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session,
         session->pinned_records = session->pinned[0] && session->pinned[1] ? kBatch : 0;
         if (!session->pinned_records) return device_error("allocating read-back staging failed");
     }
-    struct Batch {
-        uint32_t rank;
-        uint64_t first, n;
+    double ms_device = 0.0, ms_sink = 0.0;
+    auto drain_to_sink = [&]() -> obj2voxel_error_t {
+        struct Batch {
+            uint32_t rank;
+            uint64_t first, n;
+        };
+        std::vector<Batch> batches;
+        for (uint32_t r = 0; r < n_ranks; ++r)
+            for (uint64_t first = 0; first < counts[r]; first += kBatch) batches.push_back({r, first, std::min<uint64_t>(kBatch, counts[r] - first)});
+        auto start_read = [&](size_t k) {
+            const Batch &b = batches[k];
+            return o2v_hip_read_voxels_async(session->rank_ctx(b.rank), session->pinned[k & 1], b.first, b.n) == O2V_HIP_OK;
+        };
+        if (!batches.empty() && !start_read(0)) return device_error("reading voxels failed");
+        for (size_t k = 0; k < batches.size(); ++k) {
+            if (!inst.sink->can_write()) break;
+            if (o2v_hip_read_voxels_wait(session->rank_ctx(batches[k].rank)) != O2V_HIP_OK) return device_error("reading voxels failed");
+            if (k + 1 < batches.size() && !start_read(k + 1)) return device_error("reading voxels failed");
+            inst.sink->write(session->pinned[k & 1], batches[k].n);
+        }
+        if (!inst.sink->can_write()) {
+            log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "Voxelization failed because of IO error");
+            return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
+        }
+        return OBJ2VOXEL_ERR_OK;
     };
-    std::vector<Batch> batches;
-    for (uint32_t r = 0; r < n_ranks; ++r)
-        for (uint64_t first = 0; first < counts[r]; first += kBatch) batches.push_back({r, first, std::min<uint64_t>(kBatch, counts[r] - first)});
-    auto start_read = [&](size_t k) {
-        const Batch &b = batches[k];
-        return o2v_hip_read_voxels_async(session->rank_ctx(b.rank), session->pinned[k & 1], b.first, b.n) == O2V_HIP_OK;
+    auto log_pipeline = [&]() {
+        for (uint32_t r = 0; r < n_ranks; ++r) {
+            o2v_hip_timings tm{};
+            o2v_hip_get_timings(session->rank_ctx(r), &tm);
+            log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "device " + std::to_string(devices[r]) + " pipeline: " + std::to_string(tm.total_ms) + " ms, " +
+                                                       std::to_string(counts[r]) + " voxels, " + std::to_string(tm.passes) + " pass(es)" +
+                                                       (n_ranks > 1 ? ", plan " + std::to_string(tm.plan_ms) + " ms (collectives " +
+                                                                          std::to_string(tm.collective_ms) + " ms)"
+                                                                    : std::string()));
+        }
     };
-    if (!batches.empty() && !start_read(0)) return device_error("reading voxels failed");
-    for (size_t k = 0; k < batches.size(); ++k) {
-        if (!inst.sink->can_write()) break;
-        if (o2v_hip_read_voxels_wait(session->rank_ctx(batches[k].rank)) != O2V_HIP_OK) return device_error("reading voxels failed");
-        if (k + 1 < batches.size() && !start_read(k + 1)) return device_error("reading voxels failed");
-        inst.sink->write(session->pinned[k & 1], batches[k].n);
+
+    if (session->group) {
+        if (o2v_hip_group_voxelize(session->group, &params, counts.data(), nullptr) != O2V_HIP_OK)
+            return device_error("device voxelization failed");
+        ms_device = clock.lap_ms();
+        log_pipeline();
+        const obj2voxel_error_t rc_sink = drain_to_sink();
+        if (rc_sink != OBJ2VOXEL_ERR_OK) return rc_sink;
+        ms_sink = clock.lap_ms();
     }
-    if (!inst.sink->can_write()) {
-        log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "Voxelization failed because of IO error");
-        return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;
+    else {
+        // One GPU.  The dense grids of the whole resolution may not fit the device (4 + 8 bytes per cell: 8192^3, the reference
+        // README's showcase resolution, would take 6.6 TB), where the reference's sparse VoxelMap just grows (util.hpp:179-208):
+        // the grid is then voxelized as consecutive z-slabs as thick as the free memory allows - the reference's chunk
+        // mechanism again (obj2voxel.cpp:226-243, voxelization.cpp:440-444) - each slab's records going to the sink before the
+        // next slab starts.  The mesh bounds and the z extents of the triangle blocks (which let a slab skip the blocks it
+        // cannot meet) are computed once, by the slab plan.
+        uint32_t layers = 0;
+        if (o2v_hip_max_slab_layers(session->ctx, &params, &layers) != O2V_HIP_OK) return device_error("querying device memory failed");
+        if (const char *force = std::getenv("O2V_TEST_SLAB_LAYERS")) layers = std::min<uint32_t>(layers, (uint32_t) std::atoi(force));  // test hook
+        if (layers == 0) {
+            log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "resolution " + std::to_string(params.resolution) + ": not even one 4-layer slab of the dense grid fits the device memory");
+            return OBJ2VOXEL_ERR_DEVICE;
+        }
+        if (layers < params.resolution) {
+            const uint32_t n_slabs = (params.resolution + layers - 1) / layers;
+            log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "the dense grid does not fit the device: " + std::to_string(n_slabs) + " z-slabs of " +
+                                                       std::to_string(layers) + " layers");
+            uint32_t cuts[2];
+            float bounds[6];
+            if (o2v_hip_plan_slabs(session->ctx, &params, 1, cuts, bounds) != O2V_HIP_OK) return device_error("device slab plan failed");
+            params.bounds_known = 1;
+            for (int i = 0; i < 6; ++i) params.bounds[i] = bounds[i];
+        }
+        for (uint32_t z0 = 0; z0 < params.resolution; z0 += layers) {
+            params.z_begin = layers < params.resolution ? z0 : 0;
+            params.z_end = layers < params.resolution ? std::min<uint32_t>(params.resolution, z0 + layers) : 0;
+            if (o2v_hip_voxelize(session->ctx, &params, &counts[0]) != O2V_HIP_OK) return device_error("device voxelization failed");
+            ms_device += clock.lap_ms();
+            log_pipeline();
+            const obj2voxel_error_t rc_sink = drain_to_sink();
+            if (rc_sink != OBJ2VOXEL_ERR_OK) return rc_sink;
+            ms_sink += clock.lap_ms();
+        }
     }
-    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: session + upload " + std::to_string(ms_upload) + " ms, device call " +
-                                               std::to_string(ms_device) + " ms, read back + sink " +
-                                               std::to_string(clock.lap_ms()) + " ms");
+    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: session + upload " + std::to_string(ms_upload) + " ms, device call(s) " +
+                                               std::to_string(ms_device) + " ms, read back + sink " + std::to_string(ms_sink) + " ms");
     log_message(OBJ2VOXEL_LOG_LEVEL_INFO, "Voxelized " + std::to_string(T) + " triangles, writing any buffered voxels ...");
     inst.sink->finalize();
     if (!inst.sink->can_write()) return OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE;

@@ -199,7 +199,11 @@ __device__ __forceinline__ Piece<UV> stack_load(const PieceStack<UV> &st, uint32
 // rounding is covered too (below); the plane axis uses the unnormalised normal e0 x e1 with an explicit error bound (for
 // a sliver, whose normal direction is numerically meaningless, the bound exceeds the radius and the plane axis simply
 // never separates), and all comparisons are written so that a NaN rejects nothing.  Not reference arithmetic.
+// For leaves far from the origin the clip's own rounding grows with the coordinates - a vertex of a sub-piece drifts by up to
+// 1.2e-6 x the largest |coordinate| m over the five generations (see piece_masks) - so the inflation does too:
+// sat_margin(m) = max(0.02, 2.5e-6 m), twice that drift (0.02 up to m = 8000, 0.16 at m = 65536).
 constexpr float kSatMargin = 0.02f;
+__device__ __forceinline__ float sat_margin(float m) { return fmaxf(kSatMargin, 2.5e-6f * m); }
 
 // The test is solved for x: for one row of candidate voxels (fixed y and z of the leaf's clamped AABB) every axis is a
 // linear function of the voxel centre's x, so it bounds x to an interval; the row's candidates are the voxels whose centre
@@ -222,9 +226,8 @@ struct RowClip {
         }
     }
 };
-__device__ __forceinline__ void row_clip_edge(RowClip &rc, V3 E, V3 U, V3 W, float cy, float cz, float slack)
+__device__ __forceinline__ void row_clip_edge(RowClip &rc, V3 E, V3 U, V3 W, float cy, float cz, float slack, float h)
 {
-    const float h = 0.5f + kSatMargin;
     // axis x x E = (0, -E.z, E.y): the same for every voxel of the row
     {
         const float pu = E.z * (U.y - cy) - E.y * (U.z - cz), pw = E.z * (W.y - cy) - E.y * (W.z - cz);
@@ -247,9 +250,9 @@ __device__ __forceinline__ void row_clip_edge(RowClip &rc, V3 E, V3 U, V3 W, flo
 // p0, p1, p2: the leaf's vertices relative to the AABB origin; cy, cz: the row's voxel centre; [xlo, xhi]: the row's
 // voxels that belong to the tile.  Returns the first admissible voxel and their number.
 __device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, float cz, uint32_t xlo, uint32_t xhi, float extent,
-                                             uint32_t &first)
+                                             float margin, uint32_t &first)
 {
-    const float h = 0.5f + kSatMargin;
+    const float h = 0.5f + margin;  // margin = sat_margin(the leaf's largest |coordinate|)
     const float slack = 0.01f + 4e-6f * extent;
     RowClip rc{(float) xlo + 0.5f, (float) xhi + 0.5f, true};
     const V3 e0 = p1 - p0, e1 = p2 - p1, e2 = p0 - p2;
@@ -262,9 +265,9 @@ __device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, floa
         const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) + 1e-5f * l0 * l1 * (far + 1.0f);
         rc.bound(n.x, -rad - rest, rad - rest, slack);
     }
-    row_clip_edge(rc, e0, p0, p2, cy, cz, slack);
-    row_clip_edge(rc, e1, p1, p0, cy, cz, slack);
-    row_clip_edge(rc, e2, p2, p1, cy, cz, slack);
+    row_clip_edge(rc, e0, p0, p2, cy, cz, slack, h);
+    row_clip_edge(rc, e1, p1, p0, cy, cz, slack, h);
+    row_clip_edge(rc, e2, p2, p1, cy, cz, slack, h);
     // voxel x has its centre at x + 0.5; the interval is clamped to the row before the conversion
     const float fa = ceilf(rc.lo - 0.5f), fb = floorf(rc.hi - 0.5f);
     if (!rc.any || !(fa <= fb)) {
@@ -289,11 +292,13 @@ __device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, floa
 //         nothing before.  The margin (out_margin) is eight times that plus twice the 2^-16 planarity band.  The piece is
 //         dropped at once.
 //   near  planes the piece does not pass whole by more than the same margin (a superset of fail), see single_plane.
-// All are only computed for jobs whose leaf has all |coordinates| < 8192 (`small`; false for NaN too, and for every leaf
+// All are only computed for jobs whose leaf has all |coordinates| < 2^17 (`small`: the margins scale with the coordinates and
+// the sample grid has at most 65 535 voxels per axis, so this only excludes meshes reaching far outside the grid, whose
+// float arithmetic is too coarse to argue about; false for NaN too, and for every leaf
 // in exact mode, Params::exact_clip); other jobs get fail = near = planes, out = 0, i.e. every plane is classified, which
 // is always exact (single_plane then only fires at the last plane, hi z, where no later plane exists and the number of
 // kept pieces is the classification's by definition).
-constexpr float kSmallCoord = 8192.0f;
+constexpr float kSmallCoord = 131072.0f;
 
 // (once per staged leaf: q = its nine vertex coordinates; m = the largest |coordinate|)
 __device__ __forceinline__ bool leaf_is_small(const uint32_t *q, float &m)
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
     __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-candidate chunk's first candidate
     __shared__ float s_inv_dx[kVoxTiles], s_inv_dy[kVoxTiles];
     __shared__ float s_margin[kVoxTiles];  // out_margin of the tile's leaf (piece_masks)
+    __shared__ float s_satm[kVoxTiles];    // sat_margin of the tile's leaf (row_span)
     __shared__ uint32_t s_trow0[kVoxTiles];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
     __shared__ uint32_t s_rprefix[kVoxTiles + 6];  // rows before tile k (+ total + padding, as s_tprefix)
     __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct;
@@ -544,6 +550,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             const bool is_small = leaf_is_small(lf, m) && !p.exact_clip;
             s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u);
             s_margin[threadIdx.x] = out_margin(m);
+            s_satm[threadIdx.x] = sat_margin(m);
             s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
             if (my_count) {
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         const V3 p0{__uint_as_float(lf[0]) - ox, __uint_as_float(lf[1]) - oy, __uint_as_float(lf[2]) - oz};
                         const V3 p1{__uint_as_float(lf[3]) - ox, __uint_as_float(lf[4]) - oy, __uint_as_float(lf[5]) - oz};
                         const V3 p2{__uint_as_float(lf[6]) - ox, __uint_as_float(lf[7]) - oy, __uint_as_float(lf[8]) - oz};
-                        n_out = row_span(p0, p1, p2, (float) ly + 0.5f, (float) lz + 0.5f, xlo, xhi, (float) (dx + dy + dz), x_first);
+                        n_out = row_span(p0, p1, p2, (float) ly + 0.5f, (float) lz + 0.5f, xlo, xhi, (float) (dx + dy + dz), s_satm[k], x_first);
                     }
                 }
                 // inclusive prefix of the rows' survivor counts over the wavefront

@@ -1430,6 +1430,31 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
     return O2V_HIP_OK;
 }
 
+int o2v_hip_max_slab_layers(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t *out_layers)
+{
+    if (!ctx || !params || !out_layers || !params->resolution) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *out_layers = 0;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    size_t free_b = 0, total_b = 0;
+    O2V_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t G = params->resolution;
+    const uint64_t per_layer_bricks = ((G + kBrickX - 1) / kBrickX) * ((G + kBrickY - 1) / kBrickY);
+    // per brick: the 32-bit counter grid + dirty flag + dirty-list entry, and for the MAX strategy the 64-bit grid with its own
+    const bool max_grid = params->strategy == 0u;
+    const uint64_t per_brick = kBrickCells * 4ull + 1 + 4 + (max_grid ? kBrickCells * 8ull + 1 + 4 : 0ull);
+    // what the context already holds of these grids is reusable
+    const uint64_t held = ctx->grid_cells * 4ull + ctx->brick_cap * 5ull + ctx->maxgrid_cells * 8ull + ctx->maxgrid_brick_cap * 5ull;
+    // the work buffers (leaves, tiles, hit pool, sorted records, output) scale with the mesh, not with the grid: a quarter of
+    // the device, at least 8 GiB, stays free for them
+    const uint64_t reserve = std::max<uint64_t>(8ull << 30, total_b / 4);
+    const uint64_t avail = (uint64_t) free_b + held > reserve ? (uint64_t) free_b + held - reserve : 0;
+    uint64_t brick_layers = avail / (per_layer_bricks * per_brick);
+    brick_layers = std::min<uint64_t>(brick_layers, ((1ull << 31) - 1) / per_layer_bricks);  // 32-bit brick ids
+    const uint64_t layers = brick_layers * kBrickZ;
+    *out_layers = layers >= G ? (uint32_t) G : (uint32_t) layers;
+    return O2V_HIP_OK;
+}
+
 int o2v_hip_read_voxels(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, uint64_t count)
 {
     if (!ctx || (!out && count)) return O2V_HIP_ERR_BAD_ARGUMENT;

@@ -272,3 +272,55 @@ def test_streamed_upload_optional_arrays_appear_late(oracle):
     types = np.concatenate([np.full(n0, 1, np.uint32), np.full(len(tv), 3, np.uint32)])
     want = oracle.voxelize(verts, 200, uvs=uvs, types=types, texids=np.zeros(T, np.int32), textures=[(tex_pixels, 1)], strategy=1)
     assert np.array_equal(meshes.sorted_voxels(out.voxels()), meshes.sorted_voxels(want))
+
+
+def _voxelize_collect(a, verts, res, bounds=None, strategy=0):
+    from obj2voxel_amd import capi
+    inst, inp = _instance(a, verts)
+    out = capi.CollectingOutput()
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    a.obj2voxel_set_resolution(inst, res)
+    a.obj2voxel_set_color_strategy(inst, strategy)
+    if bounds is not None:
+        arr = (C.c_float * 6)(*bounds)
+        a.obj2voxel_set_mesh_boundaries(inst, arr)
+    err = a.obj2voxel_voxelize(inst)
+    a.obj2voxel_free(inst)
+    assert err == capi.ERR_OK
+    return meshes.sorted_voxels(out.voxels())
+
+
+def test_grid_voxelized_as_consecutive_slabs_when_it_does_not_fit(oracle, monkeypatch):
+    """obj2voxel_voxelize() runs the grid as z-slabs when its dense grids exceed the device memory (here forced: slabs of 8
+    layers); records, counts and the sink protocol are those of the single pass."""
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    v = meshes.uv_sphere(24)
+    whole = _voxelize_collect(a, v, 72)
+    monkeypatch.setenv("O2V_TEST_SLAB_LAYERS", "8")
+    for strategy in (0, 1):
+        slabbed = _voxelize_collect(a, v, 72, strategy=strategy)
+        assert np.array_equal(slabbed[:, :3], whole[:, :3])
+        assert np.array_equal(slabbed, meshes.sorted_voxels(oracle.voxelize(v, 72, strategy=strategy)))
+    a.obj2voxel_set_log_level(capi.LOG_INFO)
+
+
+def test_resolution_16384_runs_in_slabs_on_one_gpu(oracle):
+    """A grid far beyond what fits densely (16384^3 cells x 12 bytes = 53 TB): the library picks the slab thickness from the
+    free device memory.  The mesh sits in the far corner of user bounds that make the mesh transform x -> x + 0.5, so that
+    the oracle's chunk maps stay small; compared bit for bit, occupancy and colours."""
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    S = 16384
+    rng = np.random.default_rng(77)
+    c = np.array([S - 130.0, S - 140.0, S - 120.0]) + 100.0 * rng.random((3000, 1, 3))
+    v = (c + np.exp(rng.uniform(np.log(0.5), np.log(30.0), size=(3000, 1, 1))) * (rng.random((3000, 3, 3)) - 0.5))
+    v = np.clip(v, 0.0, S - 1.0).astype(np.float32).reshape(-1, 9)
+    bounds = meshes.stress_bounds(S)
+    got = _voxelize_collect(a, v, S, bounds=bounds, strategy=1)
+    a.obj2voxel_set_log_level(capi.LOG_INFO)
+    want = meshes.sorted_voxels(oracle.voxelize(v, S, bounds=bounds, strategy=1))
+    assert len(want) > 50_000 and got[:, :3].max() > 16300
+    assert got.shape == want.shape and np.array_equal(got, want)

@@ -28,6 +28,8 @@ WORKLOADS = [
     ("mixed_2048_ss2_max", "mixed", T_FULL, 2048, 2, 0, "color", None),
     ("mixed_4096_slab_blend_tex", "mixed", T_FULL, 4096, 1, 1, "tex", (1792, 2304)),
     ("planar_1024_ss2_max", "planar", T_FULL, 512, 2, 0, "none", None),
+    # far from the origin (float32 has 8 .. 9 fraction bits): the margins that scale with the coordinates
+    ("mixed_32768_far_slab_blend", "mixed", 400_000, 32768, 1, 1, "color", (20000, 20008)),
 ]
 
 
@@ -54,6 +56,8 @@ def test_fast_equals_exact(oracle, name, kind, T, res, ss, strategy, materials, 
     seed = [w[0] for w in WORKLOADS].index(name)
     S = res * ss
     z_range = None if zslab is None else (zslab[0] * ss - 40.0, zslab[1] * ss + 40.0)
+    if zslab is not None and zslab[1] - zslab[0] < 64:
+        z_range = (zslab[0] * ss - 6.0, zslab[1] * ss + 6.0)   # a thin slab: keep most triangles inside it
     v = meshes.stress_soup(kind, T, S, seed=seed, z_range=z_range)
     mat, textures = _materials(materials, len(v), seed)
     kw = dict(supersampling=ss, strategy=strategy, bounds=meshes.stress_bounds(S))
@@ -70,7 +74,7 @@ def test_fast_equals_exact(oracle, name, kind, T, res, ss, strategy, materials, 
         # the switch really changes the kernel's work: without the row test every candidate of the AABBs is a job candidate
         assert st_exact["jobs"] > st_fast["jobs"], (st_fast, st_exact)
         assert st_fast["hits"] == st_exact["hits"], (name, st_fast["hits"], st_exact["hits"])
-        assert len(fast) > 1_000_000, len(fast)
+        assert len(fast) > (1_000_000 if T >= 1_000_000 else 200_000), len(fast)
         assert fast.shape == exact.shape, (name, fast.shape, exact.shape)
         assert np.array_equal(fast, exact), name
         # ... and a sample against the oracle (every 40th triangle: what the CPU finishes in seconds)

@@ -112,34 +112,36 @@ def test_planar_stress_case(dv, oracle, seed):
     assert np.array_equal(got, want), seed
 
 
-def _far_corner_case(seed):
-    """Small triangles around coordinate 8192 (the limit below which k_voxelize judges pieces by their bounding boxes,
-    o2v_dev_k2_voxelize.hpp: piece_masks / single_plane), below it and far above it, in a thin z-slab at the top of a
-    16000^3 grid.  float32 has 10 fraction bits there, so vertices sit on voxel planes or one ulp (2^-10) beside them,
-    and the offsets straddle the leaf margin (~0.1 at this magnitude) that decides which pieces are settled early."""
-    rng = np.random.default_rng(7000 + seed)
-    S = 16000
+def _far_corner_case(seed, S=16000):
+    """Small triangles far from the origin, where float32 is coarse and the margins of k_voxelize's work-removal logic
+    (o2v_dev_k2_voxelize.hpp: sat_margin, out_margin - both grow with the coordinates) are what keeps it conservative: in a
+    thin z-slab at the top of a 16000^3 grid (10 fraction bits: vertices sit on voxel planes or one ulp beside them, offsets
+    straddling the leaf margin of ~0.1), or of a 60000^3 grid (7 fraction bits, margins of 0.15 .. 0.6 voxels)."""
+    rng = np.random.default_rng(7000 + seed + (0 if S == 16000 else 500))
     T = 500
-    base_xy = rng.choice([4090.0, 8186.0, 8190.0, 12000.0], size=(T, 1, 1))
+    base_xy = rng.choice([4090.0, 8186.0, 8190.0, 12000.0] if S == 16000 else [16380.0, 32766.0, 45000.0, 59980.0], size=(T, 1, 1))
     k = np.empty((T, 3, 3))
     k[:, :, 0:2] = base_xy + rng.integers(0, 8, size=(T, 3, 2))
-    k[:, :, 2] = rng.integers(15985, 15999, size=(T, 3))
+    zspan = 15 if S == 16000 else 7      # (the 60000^2 x 8 slab alone takes 117 GB of counter grid)
+    k[:, :, 2] = rng.integers(S - zspan, S - 1, size=(T, 3))
     # keep the triangles a few voxels wide: vertices 1 and 2 close to vertex 0
     k[:, 1:, :] = k[:, :1, :] + rng.integers(-3, 4, size=(T, 2, 3))
-    k[:, :, 2] = np.clip(k[:, :, 2], 15985, 15998)
-    noise = rng.choice([0.0, 0.0, 2.0 ** -10, -2.0 ** -10, 0.03, -0.03, 0.06, -0.06, 0.09, -0.09, 0.12, -0.12, 0.17, 0.25, 0.5],
+    k[:, :, 2] = np.clip(k[:, :, 2], S - zspan, S - 2)
+    ulp = 2.0 ** -10 if S == 16000 else 2.0 ** -7
+    noise = rng.choice([0.0, 0.0, ulp, -ulp, 0.03, -0.03, 0.06, -0.06, 0.09, -0.09, 0.12, -0.12, 0.17, 0.25, 0.5],
                        size=(T, 3, 3))
     v = (k - 0.5 + noise).astype(np.float32).reshape(T, 9)
     bounds = [-0.25] * 3 + [S - 0.75] * 3   # mesh transform x -> x + 0.5 up to rounding (see _planar_case)
-    kw = dict(strategy=seed % 2, bounds=bounds, zslab=(15984, 16000))
+    kw = dict(strategy=seed % 2 if S == 16000 else 1, bounds=bounds, zslab=(S - zspan - 1, S))
     mat = dict(types=np.full(T, 2, np.uint32), colors=rng.random((T, 3)).astype(np.float32))
     return v, S, kw, mat
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_far_corner_case(oracle, seed):
+@pytest.mark.parametrize("seed,S", [(0, 16000), (1, 16000), (2, 16000), (3, 16000), (0, 60000), (1, 60000), (2, 60000)])
+def test_far_corner_case(oracle, seed, S):
     from obj2voxel_amd import hip
-    v, res, kw, mat = _far_corner_case(seed)
+    v, res, kw, mat = _far_corner_case(seed, S)
+    hip._bind().o2v_release_cached_device_memory()   # (a session obj2voxel_voxelize() may have left behind)
     d = hip.DeviceVoxelizer(0)   # own context: the 16000 x 16000 x 16 slab takes 49 GB of grids
     try:
         d.set_triangles(v, **mat)
@@ -148,8 +150,8 @@ def test_far_corner_case(oracle, seed):
         d.close()
     want = meshes.sorted_voxels(oracle.voxelize(v, res, **mat, **kw))
     assert len(want) > 1000
-    assert got.shape == want.shape, (seed, got.shape, want.shape)
-    assert np.array_equal(got, want), seed
+    assert got.shape == want.shape, (seed, S, got.shape, want.shape)
+    assert np.array_equal(got, want), (seed, S)
 
 
 @pytest.mark.parametrize("seed", range(12))

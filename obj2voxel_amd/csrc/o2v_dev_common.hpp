@@ -158,6 +158,7 @@ struct Params {
     Materials mat;
     uint32_t *pick_extra;  // the same records for the winners of cells resolved by replay: 6 words each, cap_vox of them
     unsigned long long *maxgrid;
+    uint8_t *occgrid;   // occupancy-only mode: the same buffer as one byte per cell (non-zero = the voxel is hit)
     uint8_t *dirty_max;
 };
 

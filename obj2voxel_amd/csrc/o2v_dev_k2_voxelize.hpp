@@ -810,7 +810,13 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                     const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
                     const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
                     const uint32_t keyhi = (sub << 29) | lf[18];
-                    if (direct) {
+                    if (direct && occ_only) {
+                        // occupancy only: the voxel is hit, nothing else about it matters (plain stores; benign races: every
+                        // writer stores the same value)
+                        p.occgrid[cell] = 1;
+                        p.dirty_max[brick] = 1;
+                    }
+                    else if (direct) {
                         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
                         p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
                         if (UV && mine < p.cap_hits) {

@@ -710,3 +710,71 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
     const uint32_t n = s_n;
     if (n) flush(n);
 }
+
+// Occupancy-only mode (Params::occupancy_only): the dirty bricks of the one-byte-per-cell grid (64 bytes each: one 4-byte load
+// per lane, four bricks per wavefront load) become white (x, y, z, argb) records and are zeroed again.
+constexpr uint32_t kOccBricksPerWave = 2;  // (the staging buffer then takes 48 KiB: three workgroups per CU)
+constexpr uint32_t kOccBricksPerRound = (kBlock / 64) * kOccBricksPerWave * kBricksPerLoad;
+constexpr uint32_t kOccFlushAt = 1024;
+constexpr uint32_t kOccCap = kOccFlushAt + kOccBricksPerRound * kBrickCells;
+__global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict__ dirty_list, Counters *c, uint4 *out, Params p)
+{
+    static_assert(kLanesPerBrick * 4u == kBrickCells, "one 4-byte load per lane covers four cells");
+    __shared__ uint4 s_rec[kOccCap];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t white = pack_argb(1.f, 1.f, 1.f);  // colorAt_f of a material-less triangle, triangle.hpp:181-194
+    const uint32_t n_dirty = c->n_dirty_max < p.cap_dirty ? c->n_dirty_max : p.cap_dirty;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_rounds = (n_dirty + kOccBricksPerRound - 1) / kOccBricksPerRound;
+    auto flush = [&](uint32_t n) {
+        if (threadIdx.x == 0) s_base = atomicAdd(&c->n_out, n);
+        __syncthreads();
+        const uint32_t base = s_base;
+        for (uint32_t i = threadIdx.x; i < n; i += kBlock)
+            if (base + i < p.cap_vox) out[base + i] = s_rec[i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    };
+    uint32_t *grid4 = reinterpret_cast<uint32_t *>(p.occgrid);
+    for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
+        uint32_t brick[kOccBricksPerWave], cells4[kOccBricksPerWave];
+#pragma unroll
+        for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
+            const uint32_t item = r * kOccBricksPerRound + (wave * kOccBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
+            brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kOccBricksPerWave; ++k)
+            cells4[k] = brick[k] != 0xffffffffu ? grid4[(uint64_t) brick[k] * kLanesPerBrick + lane % kLanesPerBrick] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
+            if (cells4[k]) {
+                const uint32_t row = brick[k] / p.NBx;
+                const uint32_t bx = brick[k] - row * p.NBx;
+                const uint32_t bz = row / p.NBy;
+                const uint32_t by = row - bz * p.NBy;
+#pragma unroll
+                for (uint32_t e = 0; e < 4; ++e) {
+                    if ((cells4[k] >> (8u * e)) & 0xffu) {
+                        const uint32_t local = (lane % kLanesPerBrick) * 4u + e;
+                        const uint32_t slot = atomicAdd(&s_n, 1u);
+                        s_rec[slot] = make_uint4((bx << kBrickXs) + (local & (kBrickX - 1u)),
+                                                 (by << kBrickYs) + ((local >> kBrickXs) & (kBrickY - 1u)),
+                                                 (bz << kBrickZs) + (local >> (kBrickXs + kBrickYs)) + p.zo0, white);
+                    }
+                }
+                grid4[(uint64_t) brick[k] * kLanesPerBrick + lane % kLanesPerBrick] = 0u;  // clean for the next run
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        __syncthreads();  // (every thread has read n before anyone adds to s_n again: the decision below must be uniform)
+        if (n >= kOccFlushAt) flush(n);
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (n) flush(n);
+}

@@ -133,7 +133,7 @@ struct o2v_hip_ctx {
     unsigned long long *d_maxgrid = nullptr;  // direct MAX path: one 64-bit cell per output voxel (same bricked layout)
     uint8_t *d_dirty_max = nullptr;           // ... its dirty-brick flags and list
     uint32_t *d_dirty_list_max = nullptr;
-    uint64_t maxgrid_cells = 0, maxgrid_brick_cap = 0, maxgrid_map_bytes = 0;
+    uint64_t maxgrid_bytes = 0, maxgrid_brick_cap = 0, maxgrid_map_bytes = 0;
     hipEvent_t ev_k1 = nullptr;               // after K1: its counters decide which stages follow k_voxelize
     bool maxgrid_dirty = false;
     uint64_t brick_cap = 0;
@@ -409,7 +409,10 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         if (run_emit && p.pick_max) {
             O2V_LAUNCH("k_pick", s, k_pick, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_ctr, p);
         }
-        if (run_emit) {
+        if (run_emit && p.occupancy_only) {
+            O2V_LAUNCH("k_emit_occ", s, k_emit_occ, dim3((uint32_t) ctx->num_cus * 3u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, ctx->d_out, p);
+        }
+        else if (run_emit) {
             // every voxel's winner is in the 64-bit grid now (k_voxelize: unsplit triangles, resolve: the rest)
             O2V_LAUNCH("k_emit_max", s, k_emit_max, dim3((uint32_t) ctx->num_cus * 3u), dim3(kBlock), 0, s, ctx->d_dirty_list_max, ctx->d_ctr, m,
                                ctx->d_out, p);
@@ -848,93 +851,95 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     const bool use_uv = ctx->d_uvs && ctx->any_textured;
     ctx->sorted_stride = use_uv ? 6u : 4u;
 
-    // dense grid for the slab (bricked, see cell_index) + one dirty flag per brick; allocated zeroed, kept clean
-    // by k_scan_flags / k_scan_bricks
+    // Dense grids for the slab (bricked, see cell_index), each with one dirty flag per brick; allocated zeroed, kept clean by
+    // the scan / reset / emission kernels.  Which ones a run needs depends on the mesh and the strategy:
+    //   occupancy-only (no triangle has a material: every STL, an OBJ without materials)   1 byte per cell
+    //   MAX strategy                       64-bit max grid (direct path) + 32-bit counter grid (subdivided triangles)
+    //   BLEND strategy                     32-bit counter grid
     const uint64_t cells = n_bricks * kBrickCells;
     ctx->stats.grid_cells = cells;
-    ctx->stats.grid_bytes = cells * sizeof(uint32_t) + n_bricks;
-    if (cells > ctx->grid_cells || !ctx->d_grid) {
-        for (void *q : {(void *) ctx->d_grid, (void *) ctx->d_brick_dirty, (void *) ctx->d_dirty_list})
-            if (q) O2V_CHECK(hipFree(q));
-        ctx->d_grid = nullptr;
-        ctx->d_brick_dirty = nullptr;
-        ctx->d_dirty_list = nullptr;
-        ctx->grid_cells = 0;
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_grid), cells * sizeof(uint32_t)));
-        ctx->grid_cells = cells;
-        ctx->brick_cap = (n_bricks + 15u) & ~15ull;
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_brick_dirty), ctx->brick_cap));
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list), std::min<uint64_t>(ctx->brick_cap, kDirtyListMax) * sizeof(uint32_t)));
-        ctx->grid_dirty = true;
-    }
-    if (ctx->grid_dirty) {
-        O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
-        O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
-        ctx->grid_dirty = false;
-    }
-    // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
+    ctx->stats.grid_bytes = 0;
+    const uint64_t brick_cap_want = (n_bricks + 15u) & ~15ull;
     {
         const char *off = std::getenv("O2V_NO_DIRECT_MAX");
         // occupancy-only mode (Params::occupancy_only): no triangle has a material, so the result is the set of hit voxels,
         // all white, with either strategy.  Not in exact mode: the fast-vs-exact comparison covers this shortcut too.
         const char *no_occ = std::getenv("O2V_NO_OCCUPANCY_ONLY");
         p.occupancy_only = (!ctx->d_types && !use_uv && !p.exact_clip && !(off && off[0] == '1') && !(no_occ && no_occ[0] == '1')) ? 1u : 0u;
+        // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
         p.direct_max = ((params->strategy == 0u || p.occupancy_only) && !(off && off[0] == '1')) ? 1u : 0u;
         p.pick_max = (p.direct_max && use_uv) ? 1u : 0u;  // textured: the winner's colour is picked afterwards (k_pick)
         p.mat = Materials{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
     }
     if (p.direct_max) {
-        if (cells > ctx->maxgrid_cells || !ctx->d_maxgrid) {
+        // the max grid: 8 bytes per cell, or - occupancy only - the same buffer used as 1 byte per cell
+        const uint64_t want_bytes = cells * (p.occupancy_only ? 1ull : sizeof(unsigned long long));
+        if (want_bytes > ctx->maxgrid_bytes || n_bricks > ctx->maxgrid_brick_cap || !ctx->d_maxgrid) {
             for (void *q : {(void *) ctx->d_maxgrid, (void *) ctx->d_dirty_max, (void *) ctx->d_dirty_list_max})
                 if (q) O2V_CHECK(hipFree(q));
             ctx->d_maxgrid = nullptr;
             ctx->d_dirty_max = nullptr;
             ctx->d_dirty_list_max = nullptr;
-            ctx->maxgrid_cells = 0;
-            // 8 bytes per cell on top of the counter grid's 4: if that does not fit (4096^3 on one GPU), every hit takes
-            // the sort-and-replay route instead
-            if (hipMalloc(reinterpret_cast<void **>(&ctx->d_maxgrid), cells * sizeof(unsigned long long)) != hipSuccess) {
+            ctx->maxgrid_bytes = 0;
+            ctx->maxgrid_brick_cap = 0;
+            // if it does not fit (8 bytes per cell at 4096^3 on one GPU), every hit takes the sort-and-replay route instead.
+            // All three buffers exist before the capacity is published: a context (cached process-wide by the C API) whose later
+            // allocation failed must not look ready.
+            const bool ok = hipMalloc(reinterpret_cast<void **>(&ctx->d_maxgrid), want_bytes) == hipSuccess &&
+                            hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), brick_cap_want) == hipSuccess &&
+                            hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), std::min<uint64_t>(brick_cap_want, kDirtyListMax) * sizeof(uint32_t)) == hipSuccess;
+            if (!ok) {
                 (void) hipGetLastError();
+                for (void *q : {(void *) ctx->d_maxgrid, (void *) ctx->d_dirty_max, (void *) ctx->d_dirty_list_max})
+                    if (q) (void) hipFree(q);
                 ctx->d_maxgrid = nullptr;
+                ctx->d_dirty_max = nullptr;
+                ctx->d_dirty_list_max = nullptr;
                 p.direct_max = 0;
                 p.pick_max = 0;
                 p.occupancy_only = 0;
             }
             else {
-                // all three buffers exist before the capacity is published: a context (cached process-wide by the C API)
-                // whose later allocation failed must not look ready
-                const uint64_t brick_cap = (n_bricks + 15u) & ~15ull, map_bytes = brick_cap;
-                const bool ok = hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_max), map_bytes) == hipSuccess &&
-                                hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list_max), std::min<uint64_t>(brick_cap, kDirtyListMax) * sizeof(uint32_t)) == hipSuccess;
-                if (!ok) {
-                    (void) hipGetLastError();
-                    for (void *q : {(void *) ctx->d_maxgrid, (void *) ctx->d_dirty_max, (void *) ctx->d_dirty_list_max})
-                        if (q) (void) hipFree(q);
-                    ctx->d_maxgrid = nullptr;
-                    ctx->d_dirty_max = nullptr;
-                    ctx->d_dirty_list_max = nullptr;
-                    p.direct_max = 0;
-                    p.pick_max = 0;
-                    p.occupancy_only = 0;
-                }
-                else {
-                    ctx->maxgrid_cells = cells;
-                    ctx->maxgrid_brick_cap = brick_cap;
-                    ctx->maxgrid_map_bytes = map_bytes;
-                    ctx->maxgrid_dirty = true;
-                }
+                ctx->maxgrid_bytes = want_bytes;
+                ctx->maxgrid_brick_cap = brick_cap_want;
+                ctx->maxgrid_map_bytes = brick_cap_want;
+                ctx->maxgrid_dirty = true;
             }
         }
     }
     if (p.direct_max) {
         if (ctx->maxgrid_dirty) {
-            O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
+            O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_bytes, ctx->stream));
             O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_map_bytes, ctx->stream));
             ctx->maxgrid_dirty = false;
         }
         p.maxgrid = ctx->d_maxgrid;
+        p.occgrid = reinterpret_cast<uint8_t *>(ctx->d_maxgrid);
         p.dirty_max = ctx->d_dirty_max;
-        ctx->stats.grid_bytes += cells * sizeof(unsigned long long) + n_bricks;
+        ctx->stats.grid_bytes += cells * (p.occupancy_only ? 1ull : sizeof(unsigned long long)) + n_bricks;
+    }
+    if (!p.occupancy_only) {
+        // the counter grid (no pooled hits exist in occupancy-only mode)
+        ctx->stats.grid_bytes += cells * sizeof(uint32_t) + n_bricks;
+        if (cells > ctx->grid_cells || !ctx->d_grid) {
+            for (void *q : {(void *) ctx->d_grid, (void *) ctx->d_brick_dirty, (void *) ctx->d_dirty_list})
+                if (q) O2V_CHECK(hipFree(q));
+            ctx->d_grid = nullptr;
+            ctx->d_brick_dirty = nullptr;
+            ctx->d_dirty_list = nullptr;
+            ctx->grid_cells = 0;
+            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_grid), cells * sizeof(uint32_t)));
+            ctx->grid_cells = cells;
+            ctx->brick_cap = brick_cap_want;
+            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_brick_dirty), ctx->brick_cap));
+            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list), std::min<uint64_t>(ctx->brick_cap, kDirtyListMax) * sizeof(uint32_t)));
+            ctx->grid_dirty = true;
+        }
+        if (ctx->grid_dirty) {
+            O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
+            O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
+            ctx->grid_dirty = false;
+        }
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
     if (!ctx->d_jobq)
@@ -980,16 +985,18 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         }
     }
     ctx->force_general = false;
-    ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
+    if (!p.occupancy_only) ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
     if (p.direct_max) ctx->maxgrid_dirty = true;
     for (uint32_t pass = 1; pass <= 12; ++pass) {
         int rc;
         if (pass > 1) {
             // a pass that overflowed a buffer may have left counters / offsets in cells it could not list
-            O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
-            O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
+            if (!p.occupancy_only) {
+                O2V_CHECK(hipMemsetAsync(ctx->d_grid, 0, ctx->grid_cells * sizeof(uint32_t), ctx->stream));
+                O2V_CHECK(hipMemsetAsync(ctx->d_brick_dirty, 0, ctx->brick_cap, ctx->stream));
+            }
             if (p.direct_max) {
-                O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_cells * sizeof(unsigned long long), ctx->stream));
+                O2V_CHECK(hipMemsetAsync(ctx->d_maxgrid, 0, ctx->maxgrid_bytes, ctx->stream));
                 O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_map_bytes, ctx->stream));
             }
         }
@@ -1038,7 +1045,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         ctx->timings.passes = pass;
         if (h.err_flags) {
             // (a dirty-list overflow leaves bricks behind that no list names: the grids stay marked for a full clear)
-            if (!(h.err_flags & kErrDirtyList)) ctx->grid_dirty = false;
+            if (!(h.err_flags & kErrDirtyList) && !p.occupancy_only) ctx->grid_dirty = false;
             ctx->err = (h.err_flags & kErrLeafTooLarge) ? "a leaf's voxel AABB has 2^32 or more candidate voxels"
                        : (h.err_flags & kErrDepth)      ? "subdivision deeper than 15 levels"
                        : (h.err_flags & kErrDirtyList)  ? "more than 2^27 bricks of the slab hold voxels; use more z-slabs"
@@ -1078,7 +1085,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             again = true;
         }
         if (!again) {
-            ctx->grid_dirty = false;
+            if (!p.occupancy_only) ctx->grid_dirty = false;
             ctx->maxgrid_dirty = false;
             const bool direct = p.direct_max && (p.occupancy_only || h.n_nodes[0] <= h.n_root_leaves);  // direct_active() on the device
             const uint64_t n_final = direct ? h.n_out : h.n_vox;
@@ -1439,11 +1446,14 @@ int o2v_hip_max_slab_layers(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint
     O2V_CHECK(hipMemGetInfo(&free_b, &total_b));
     const uint64_t G = params->resolution;
     const uint64_t per_layer_bricks = ((G + kBrickX - 1) / kBrickX) * ((G + kBrickY - 1) / kBrickY);
-    // per brick: the 32-bit counter grid + dirty flag + dirty-list entry, and for the MAX strategy the 64-bit grid with its own
+    // per brick: occupancy only (no triangle of the uploaded mesh has a material) one byte per cell; else the 32-bit counter
+    // grid and, for the MAX strategy, the 64-bit grid; each with a dirty flag and a dirty-list entry
+    const bool occupancy_only = !ctx->d_types && !(ctx->d_uvs && ctx->any_textured);
     const bool max_grid = params->strategy == 0u;
-    const uint64_t per_brick = kBrickCells * 4ull + 1 + 4 + (max_grid ? kBrickCells * 8ull + 1 + 4 : 0ull);
+    const uint64_t per_brick = occupancy_only ? kBrickCells * 1ull + 1 + 4
+                                              : kBrickCells * 4ull + 1 + 4 + (max_grid ? kBrickCells * 8ull + 1 + 4 : 0ull);
     // what the context already holds of these grids is reusable
-    const uint64_t held = ctx->grid_cells * 4ull + ctx->brick_cap * 5ull + ctx->maxgrid_cells * 8ull + ctx->maxgrid_brick_cap * 5ull;
+    const uint64_t held = (occupancy_only ? 0ull : ctx->grid_cells * 4ull + ctx->brick_cap * 5ull) + ctx->maxgrid_bytes + ctx->maxgrid_brick_cap * 5ull;
     // the work buffers (leaves, tiles, hit pool, sorted records, output) scale with the mesh, not with the grid: a quarter of
     // the device, at least 8 GiB, stays free for them
     const uint64_t reserve = std::max<uint64_t>(8ull << 30, total_b / 4);

@@ -347,21 +347,25 @@ def test_full_size_supersampled_2048(dv):
     assert np.array_equal(meshes.sorted_voxels(dv.voxelize(res, supersampling=2, strategy=1)), whole)
 
 
-def test_4096_grid_in_eight_slabs(dv):
-    """BASELINE.json configs[4] layout: a 4096^3 grid split into 8 z-slabs (34 GB of dense grid each), here run one
-    after the other on a single GPU. The slab counts of the unit cube must add up to the reference's closed form
-    (test/main.cpp:120-126) and every voxel must lie in its slab."""
+@pytest.mark.parametrize("coloured", [False, True])
+def test_4096_grid_in_eight_slabs(dv, coloured):
+    """BASELINE.json configs[4] layout: a 4096^3 grid split into 8 z-slabs, here run one after the other on a single GPU.
+    Material-less (the configs[4] mesh): one byte per cell, 8.6 GB per slab; with colours and BLEND the 32-bit counter grid,
+    34 GB per slab.  The slab counts of the unit cube must add up to the reference's closed form (test/main.cpp:120-126) and
+    every voxel must lie in its slab."""
     res, n = 4096, 8
-    dv.set_triangles(meshes.unit_cube())
+    v = meshes.unit_cube()
+    kw = dict(types=np.full(len(v), 2, np.uint32), colors=meshes.triangle_colors(len(v))) if coloured else {}
+    dv.set_triangles(v, **kw)
     total = 0
     for r in range(n):
         z0, z1 = r * res // n, (r + 1) * res // n
-        vox = dv.voxelize(res, zslab=(z0, z1))
+        vox = dv.voxelize(res, zslab=(z0, z1), strategy=1 if coloured else 0)
         assert ((vox[:, 2] >= z0) & (vox[:, 2] < z1)).all()
         total += len(vox)
     assert total == 8 + 12 * (res - 2) + 6 * (res - 2) ** 2
     st = dv.stats()
-    assert st["grid_bytes"] > 34e9
+    assert st["grid_bytes"] > (34e9 if coloured else 8.5e9) and st["grid_bytes"] < (40e9 if coloured else 10e9)
 
 
 def test_buffer_overflow_regrow_paths(oracle, monkeypatch):

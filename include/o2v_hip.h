@@ -101,6 +101,8 @@ typedef struct {
     uint64_t pool_slots;  /* hit-pool slots reserved (hits + chunk slack) */
     uint64_t direct_hits; /* hits that went straight into the 64-bit max grid (MAX strategy, unsplit triangles) */
     uint64_t jobs;        /* candidates that passed the plane cull and the separating-axis pre-test: voxel jobs of the clip loop */
+    uint64_t certain_hits;/* occupancy-only mode: hits established without a voxel job (the voxel centre's column meets the leaf
+                             well inside both), included in hits and direct_hits */
 } o2v_hip_stats;
 
 int o2v_hip_device_count(void);

@@ -117,6 +117,7 @@ struct Counters {
                                    // pad2: k_tri_extent's result at upload time, pick records of the replay tiers in a pass
     unsigned long long n_direct;
     float xform[12];
+    unsigned long long n_certain;   // occupancy-only mode: hits established without a voxel job (certain_prepare)
     unsigned long long n_jobs;      // candidate voxels that passed phase 1 of k_voxelize (= voxel jobs of phase 2)
     unsigned long long dbg[16];  // event counts of an instrumented build (-DO2V_INSTRUMENT, tools/instrument.sh); else zero
 };

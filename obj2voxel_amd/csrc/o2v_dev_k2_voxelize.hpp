@@ -364,6 +364,61 @@ __device__ __forceinline__ uint32_t single_plane_kept(const Piece<UV> &q, uint32
     return s_kept[classify_index(comp(q.a, axis), comp(q.b, axis), comp(q.c, axis), plane) | (keep_lo ? 64u : 0u)];
 }
 
+// ---- occupancy-only mode: hits that need no clipping ---------------------------------------------------------------------
+// In occupancy-only mode (Params::occupancy_only) a voxel job only has to establish that the clip leaves at least one piece.
+// For most hit voxels that is certain beforehand: if a point q of the leaf lies inside the voxel by a margin D and inside the
+// leaf (in its plane) by a margin rho, the piece of the clip that contains q cannot vanish - the float clip's pieces cover
+// the exact intersection of leaf and voxel except for a band along its boundary no wider than the drift of their vertices
+// (< 1.2e-6 x the largest |coordinate| m over the five generations, see piece_masks) plus the 2^-16 planarity band (a vertex
+// that close to a plane counts as on it; a piece with two such vertices goes to the third one's side: both move the boundary
+// by < 2^-16).  With D = rho = certain_margin(m) = 1.5 sat_margin(m) >= 0.03 that band is thirty times narrower than the
+// margins.  The point tried is the one the voxel centre's column along the normal's dominant axis d meets the leaf's plane
+// in: q = centre - t e_d, t = n . (centre - v0) / n_d.  It lies in the voxel by 0.5 in the two other axes and by 0.5 - |t| in
+// d; its barycentric coordinates - computed in the projection along d, which preserves them - say how far inside the leaf it
+// is: lambda_i x (altitude on vertex i) is its distance from the edge opposite i.  So the test is
+//     |t| <= 0.5 - D   and   lambda_0, lambda_1, lambda_2 >= tau = rho / (smallest altitude) + 1e-4
+// and it is tried not only for the centre's column but for every column through five lines across the voxel (spaced 0.22
+// or less in one of the two other axes, any offset within 0.5 - D along the other: along a line all conditions are linear
+// inequalities in the offset, which leave an interval), so that q stays inside the voxel by >= D in those axes too.  Some 150
+// instructions per candidate, all lanes busy, against a voxel job's ~4000 on partly idle lanes.  A sliver has tau > 1/3 and is never certain; a
+// degenerate or non-finite leaf is excluded outright, as is a leaf of a triangle of zero area (its weight would be zero:
+// no hit, voxelization.cpp:466).  Not reference arithmetic: like the separating-axis test it only removes work, and the
+// fast-vs-exact comparison (tests/test_gpu_exact_ab.py) runs with it switched off on the exact side.
+#ifndef O2V_CERTAIN_N
+#define O2V_CERTAIN_N 5
+#define O2V_CERTAIN_STEP 0.22f
+#endif
+struct CertainPrep {
+    float m00, m01, m10, m11, tau;
+    uint32_t axis;  // dominant axis of the normal; tau = +inf: the leaf has no certain hits
+};
+__device__ __forceinline__ float certain_margin(float m) { return 1.5f * sat_margin(m); }
+__device__ __forceinline__ CertainPrep certain_prepare(V3 v0, V3 v1, V3 v2, V3 nrm, float m, bool small, float parent_area)
+{
+    CertainPrep c{0.f, 0.f, 0.f, 0.f, __builtin_inff(), 0u};
+    const float ax = abs_f(nrm.x), ay = abs_f(nrm.y), az = abs_f(nrm.z);
+    c.axis = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
+    const uint32_t iu = c.axis == 0u ? 1u : 0u, iw = c.axis == 2u ? 1u : 2u;  // the two other axes
+    const V3 e1 = v1 - v0, e2 = v2 - v0, e3 = v2 - v1;
+    const float e1u = comp(e1, iu), e1w = comp(e1, iw), e2u = comp(e2, iu), e2w = comp(e2, iw);
+    const float det = e1u * e2w - e1w * e2u;
+    const V3 cr = cross(e1, e2);
+    const float twice_area = __builtin_sqrtf(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z);
+    const float longest = __builtin_sqrtf(fmaxf(fmaxf(e1.x * e1.x + e1.y * e1.y + e1.z * e1.z, e2.x * e2.x + e2.y * e2.y + e2.z * e2.z),
+                                                e3.x * e3.x + e3.y * e3.y + e3.z * e3.z));
+    // (all comparisons false for NaN: such a leaf keeps tau = +inf)
+    if (small && parent_area > 0.f && twice_area > 1e-12f && abs_f(det) > 1e-12f && longest > 0.f) {
+        const float h_min = twice_area / longest;
+        const float inv = 1.0f / det;
+        c.m00 = e2w * inv;
+        c.m01 = -e2u * inv;
+        c.m10 = -e1w * inv;
+        c.m11 = e1u * inv;
+        c.tau = certain_margin(m) / h_min + 1e-4f;
+    }
+    return c;
+}
+
 #ifndef O2V_FLUSH_AT
 #define O2V_FLUSH_AT 48
 #endif
@@ -389,7 +444,11 @@ struct VoxShape {
     static constexpr uint32_t block = UV ? O2V_VOX_BLOCK_UV : O2V_VOX_BLOCK;  // threads per workgroup
     static constexpr uint32_t tiles = block;                                  // tiles staged at once (at most)
     static constexpr uint32_t queue = 64u * block;  // job queue records (= candidate voxels at most) per sub-batch and workgroup
-    static constexpr uint32_t batches = block >= 256u ? 4u : 2u, batches_large = block >= 256u ? 6u : 3u;
+#ifndef O2V_BATCHES
+#define O2V_BATCHES 4
+#define O2V_BATCHES_LARGE 6
+#endif
+    static constexpr uint32_t batches = block >= 256u ? O2V_BATCHES : 2u, batches_large = block >= 256u ? O2V_BATCHES_LARGE : 3u;
     static constexpr uint32_t finer_min = 32u * block / 256u;
 };
 constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf straddles at least this many voxel planes is queued first
@@ -450,7 +509,10 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                                                      uint2 *jobq_all, Params p)
 {
     constexpr uint32_t kVoxBlock = VoxShape<UV>::block, kVoxTiles = VoxShape<UV>::tiles, kQueueCap = VoxShape<UV>::queue;
-    constexpr uint32_t kBatchesPerBlock = VoxShape<UV>::batches, kBatchesPerBlockLarge = VoxShape<UV>::batches_large;
+    // (occupancy-only mode: most candidates are settled in phase 1, so a batch leaves few voxel jobs - half as many, larger
+    // batches keep phase 2's lanes busier: bench mesh 0.54 -> 0.50 ms)
+    const uint32_t kBatchesPerBlock = (!UV && p.occupancy_only) ? (VoxShape<UV>::batches + 1u) / 2u : VoxShape<UV>::batches;
+    const uint32_t kBatchesPerBlockLarge = (!UV && p.occupancy_only) ? (VoxShape<UV>::batches_large + 1u) / 2u : VoxShape<UV>::batches_large;
     constexpr uint32_t kFinerBatchMinTiles = VoxShape<UV>::finer_min;
     __shared__ uint32_t s_leaf[kVoxTiles * kLeafStride];
     __shared__ uint32_t s_tleaf[kVoxTiles];
@@ -465,7 +527,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
     __shared__ float s_satm[kVoxTiles];    // sat_margin of the tile's leaf (row_span)
     __shared__ uint32_t s_trow0[kVoxTiles];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
     __shared__ uint32_t s_rprefix[kVoxTiles + 6];  // rows before tile k (+ total + padding, as s_tprefix)
-    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct;
+    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct, s_certain;
     // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
     // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
     // voxel (the long ones) are filed from the front, the others from the back, and the queue is served front to back:
@@ -514,6 +576,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
     if (threadIdx.x == 0) {
         s_hits = 0;
         s_direct = 0;
+        s_certain = 0;
     }
     if (threadIdx.x < 64u) s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
     for (uint32_t i = threadIdx.x; i < 128u; i += kVoxBlock) s_kept[i] = (uint8_t) classify_kept(i & 63u, i >= 64u);
@@ -551,6 +614,21 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u);
             s_margin[threadIdx.x] = out_margin(m);
             s_satm[threadIdx.x] = sat_margin(m);
+            if (!UV && occ_only) {
+                // the certain-hit test's per-leaf part goes where the staged leaf keeps its uv coordinates (unused without uv)
+                uint32_t *lw = &s_leaf[threadIdx.x * kLeafStride];
+                const CertainPrep cp = certain_prepare(V3{__uint_as_float(lw[0]), __uint_as_float(lw[1]), __uint_as_float(lw[2])},
+                                                       V3{__uint_as_float(lw[3]), __uint_as_float(lw[4]), __uint_as_float(lw[5])},
+                                                       V3{__uint_as_float(lw[6]), __uint_as_float(lw[7]), __uint_as_float(lw[8])},
+                                                       V3{__uint_as_float(lw[9]), __uint_as_float(lw[10]), __uint_as_float(lw[11])}, m, is_small,
+                                                       __uint_as_float(lw[23]));
+                lw[12] = __float_as_uint(cp.m00);
+                lw[13] = __float_as_uint(cp.m01);
+                lw[14] = __float_as_uint(cp.m10);
+                lw[15] = __float_as_uint(cp.m11);
+                lw[16] = __float_as_uint(cp.tau);
+                lw[17] = cp.axis;
+            }
             s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
             if (my_count) {
@@ -686,7 +764,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         src &= 63u;  // (lanes beyond the total look at lane 63; they are masked below)
                     }
                     const uint32_t r_exc = __shfl(exc, (int) src, 64), r_xk = __shfl(xk, (int) src, 64), r_yz = __shfl(yz, (int) src, 64);
-                    bool keep = false, heavy = false;
+                    bool keep = false, heavy = false, certain = false;
                     uint2 rec = make_uint2(0u, 0u);
                     if (o < total) {
                         const uint32_t kk = r_xk >> 16, lx = (r_xk & 0xffffu) + (o - r_exc);
@@ -697,8 +775,64 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
                         const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
                         // plane distance cull, voxelization.cpp:451-458
-                        const float sd = dot(nrm, V3{(float) qx + 0.5f, (float) qy + 0.5f, (float) qz + 0.5f} - v0);
+                        const V3 rel = V3{(float) qx + 0.5f, (float) qy + 0.5f, (float) qz + 0.5f} - v0;
+                        const float sd = dot(nrm, rel);
                         keep = !(abs_f(sd) > kPlaneDistanceLimit);
+                        if (!UV && occ_only && keep) {
+                            // certain hit (see certain_prepare): no voxel job, the voxel is marked here.  Tried are the columns
+                            // through a 5 x 5 lattice of points around the voxel centre (every quantity of the test is linear in
+                            // the offset); the lattice stays inside the voxel by the margin D.
+                            const uint32_t axis = lf[17];
+                            const uint32_t iu = axis == 0u ? 1u : 0u, iw = axis == 2u ? 1u : 2u;
+                            const float tau = __uint_as_float(lf[16]);
+                            if (tau < 0.34f) {  // (else no point of the leaf is far enough from its edges)
+                                const float lim = 0.5f - (1.5f * s_satm[kk] + 1e-3f);  // 0.5 - D, D = certain_margin(m)
+                                // kN lines across the voxel (constant offset in the second lattice axis); along a line every
+                                // condition is a linear inequality in the offset o: they leave an interval, the point exists if it is
+                                // not empty (by a slack that absorbs this code's own rounding)
+                                constexpr int kN = O2V_CERTAIN_N;
+                                const float half = 0.5f * (float) (kN - 1);
+                                const float step = fminf(O2V_CERTAIN_STEP, lim / fmaxf(half, 0.5f));
+                                const float m00 = __uint_as_float(lf[12]), m01 = __uint_as_float(lf[13]), m10 = __uint_as_float(lf[14]), m11 = __uint_as_float(lf[15]);
+                                const float rnd = __builtin_amdgcn_rcpf(comp(nrm, axis));
+                                const float tu = comp(nrm, iu) * rnd, tw = comp(nrm, iw) * rnd * step;  // dt per unit of o / per line
+                                const float pu = comp(rel, iu), pw = comp(rel, iw) - half * step;       // the first line's centre
+                                float l1 = m00 * pu + m01 * pw, l2 = m10 * pu + m11 * pw, t0 = sd * rnd - half * tw;
+                                const float d1w = m01 * step, d2w = m11 * step;
+                                // a * o >= b  ->  o >= b / a (a > 0), o <= b / a (a < 0), or b <= 0 (a = 0)
+                                const float a1 = m00, a2 = m10, a0 = -(m00 + m10), a3 = tu, a4 = -tu;
+                                auto inv = [](float a) { return abs_f(a) > 1e-12f ? __builtin_amdgcn_rcpf(a) : 0.f; };
+                                const float r1 = inv(a1), r2 = inv(a2), r0 = inv(a0), r3 = inv(a3), r4 = -r3;
+#pragma unroll
+                                for (int jw = 0; jw < kN; ++jw) {
+                                    float lo = -lim, hi = lim;
+                                    bool ok = true;
+                                    auto bound = [&](float a, float ra, float bb) {
+                                        const float x = bb * ra;
+                                        lo = (ra > 0.f) ? fmaxf(lo, x) : lo;
+                                        hi = (ra < 0.f) ? fminf(hi, x) : hi;
+                                        ok = ok && (ra != 0.f || bb <= 0.f);
+                                    };
+                                    bound(a1, r1, tau - l1);
+                                    bound(a2, r2, tau - l2);
+                                    bound(a0, r0, tau - ((1.0f - l1) - l2));
+                                    bound(a3, r3, -lim - t0);
+                                    bound(a4, r4, t0 - lim);
+                                    certain |= ok && hi - lo >= 2e-3f;
+                                    l1 += d1w;
+                                    l2 += d2w;
+                                    t0 += tw;
+                                }
+                            }
+                            if (certain) {
+                                keep = false;
+                                const uint32_t ox = qx >> p.ss_shift, oy = qy >> p.ss_shift, oz = qz >> p.ss_shift;
+                                uint32_t brick;
+                                const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                                p.occgrid[cell] = 1;      // (plain stores; benign races: every writer stores the same value)
+                                p.dirty_max[brick] = 1;
+                            }
+                        }
                         if (keep) {
                             // the job record: position, tile slot, the planes of this voxel the leaf does not pass whole
                             const bool small = (s_tcount[kk] >> 31) != 0u;
@@ -711,6 +845,10 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             rec = make_uint2(qx | (qy << 16), qz | (kk << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u));
                             heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
                         }
+                    }
+                    if (!UV && occ_only) {
+                        const unsigned long long mc = __ballot(certain);
+                        if (mc && lane == 0) atomicAdd(&s_certain, (uint32_t) __popcll(mc));
                     }
                     const unsigned long long mh = __ballot(keep && heavy), ml = __ballot(keep && !heavy);
                     if (mh | ml) {
@@ -1045,6 +1183,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
         for (uint32_t k = 0; k < 4; ++k) atomicAdd(&c->dbg[12 + k], tmr[k]);  // summed over the wavefronts
 #endif
     __syncthreads();
-    if (threadIdx.x == 0 && s_hits) atomicAdd(&c->n_hits, (unsigned long long) s_hits);
-    if (threadIdx.x == 0 && s_direct) atomicAdd(&c->n_direct, (unsigned long long) s_direct);
+    // (a certain hit is a hit, a direct one, and a voxel job that did not have to run)
+    if (threadIdx.x == 0 && (s_hits | s_certain)) atomicAdd(&c->n_hits, (unsigned long long) s_hits + s_certain);
+    if (threadIdx.x == 0 && (s_direct | s_certain)) atomicAdd(&c->n_direct, (unsigned long long) s_direct + s_certain);
+    if (threadIdx.x == 0 && s_certain) atomicAdd(&c->n_certain, (unsigned long long) s_certain);
 }

@@ -1098,6 +1098,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->stats.voxels = n_final;
             ctx->stats.direct_hits = h.n_direct;
             ctx->stats.jobs = h.n_jobs;
+            ctx->stats.certain_hits = h.n_certain;
             ctx->stats.bricks = p.n_bricks;
             ctx->stats.dirty_bricks = direct ? h.n_dirty_max : h.n_dirty;
             ctx->stats.pool_slots = h.n_hits_reserved;

@@ -713,10 +713,14 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
     const uint32_t chunks_per_axis = (sample_res + O2V_CHUNK - 1) / O2V_CHUNK; /* :580-581 */
 
     const double t_begin = omp_get_wtime();
+    /* the memory-bound steps around the chunk loop use a few threads only: with one thread per core of a large host the page
+     * faults of the freshly allocated arrays contend in the kernel and the steps get slower than serial (measured: 0.58 s
+     * with 256 threads against 0.035 s with one, 870 k triangles) */
+    const int aux_threads = g_threads < 4 ? g_threads : 4;
     cached_tri *tris = (cached_tri *) calloc(T, sizeof(cached_tri));
     /* (the harness around the reference's algorithm is parallel too - copy, bounds, transform, binning, merge - so that the
      * multi-threaded baseline measures the algorithm, not a serial prelude; results do not depend on the thread count) */
-#pragma omp parallel for num_threads(g_threads) schedule(static)
+#pragma omp parallel for num_threads(aux_threads) schedule(static)
     for (int64_t i = 0; i < (int64_t) T; ++i) {
         const float *p = verts + i * 9;
         for (unsigned k = 0; k < 3; ++k) {
@@ -750,7 +754,7 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
     else {
         /* batches are merged under a mutex in the reference (boundsMutex); min / max are exact and order-free */
         const int64_t n_batches = (int64_t) ((T + O2V_BATCH - 1) / O2V_BATCH);
-#pragma omp parallel for num_threads(g_threads) schedule(static)
+#pragma omp parallel for num_threads(aux_threads) schedule(static)
         for (int64_t bi = 0; bi < n_batches; ++bi) {
             const uint64_t b = (uint64_t) bi * O2V_BATCH;
             uint64_t end = b + O2V_BATCH < T ? b + O2V_BATCH : T;
@@ -779,7 +783,7 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
     affine xf = compute_mesh_transform(mesh_min, mesh_max, sample_res, unit ? unit : ident);
 
     /* applyMeshTransform, obj2voxel.cpp:202-224 */
-#pragma omp parallel for num_threads(g_threads) schedule(static)
+#pragma omp parallel for num_threads(aux_threads) schedule(static)
     for (int64_t i = 0; i < (int64_t) T; ++i) {
         for (unsigned k = 0; k < 3; ++k) tris[i].geo.v[k] = affine_apply(&xf, tris[i].geo.v[k]);
         uint32_t lo[3], hi[3];
@@ -797,12 +801,12 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
     const size_t nchunks = (size_t) chunks_per_axis * chunks_per_axis * chunks_per_axis;
     uint64_t *chunk_start = (uint64_t *) calloc(nchunks + 1, sizeof(uint64_t));
     {
-        int n_ranges = g_threads;
+        int n_ranges = aux_threads;
         while (n_ranges > 1 && (size_t) n_ranges * nchunks > ((size_t) 1 << 26)) n_ranges /= 2;
         uint32_t *cnt = (uint32_t *) calloc((size_t) n_ranges * nchunks, sizeof(uint32_t));
         uint32_t *chunk_items = NULL;
         for (int pass = 0; pass < 2; ++pass) {
-#pragma omp parallel for num_threads(g_threads) schedule(static, 1)
+#pragma omp parallel for num_threads(aux_threads) schedule(static, 1)
             for (int r = 0; r < n_ranges; ++r) {
                 const uint64_t i0 = T * (uint64_t) r / (uint64_t) n_ranges, i1 = T * (uint64_t) (r + 1) / (uint64_t) n_ranges;
                 uint32_t *row = cnt + (size_t) r * nchunks;
@@ -884,11 +888,16 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                     ov.d = (uint32_t *) malloc(sizeof(uint32_t) * 4 * (total ? total : 1));
                     ov.n = ov.cap = total;
                 }
-                {
-                    size_t before = 0;
-                    for (int k = 0; k < omp_get_thread_num(); ++k) before += per_thread[k].n;
-                    if (lov.n) memcpy(ov.d + before * 4, lov.d, sizeof(uint32_t) * 4 * lov.n);
+#pragma omp barrier
+                if (omp_get_thread_num() < aux_threads) {
+                    /* a few threads copy all lists (see aux_threads) */
+                    for (int k = omp_get_thread_num(); k < g_threads; k += aux_threads) {
+                        size_t before = 0;
+                        for (int j = 0; j < k; ++j) before += per_thread[j].n;
+                        if (per_thread[k].n) memcpy(ov.d + before * 4, per_thread[k].d, sizeof(uint32_t) * 4 * per_thread[k].n);
+                    }
                 }
+#pragma omp barrier
                 free(lov.d);
             }
             g_phase_seconds[1] = t_merge - t_vox;

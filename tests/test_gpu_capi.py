@@ -324,3 +324,36 @@ def test_resolution_16384_runs_in_slabs_on_one_gpu(oracle):
     want = meshes.sorted_voxels(oracle.voxelize(v, S, bounds=bounds, strategy=1))
     assert len(want) > 50_000 and got[:, :3].max() > 16300
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_callback_that_sets_nothing_repeats_the_previous_triangle(oracle):
+    """The object handed to the triangle callback is reused (reference obj2voxel.cpp:585: `CachedTriangle triangle{}` outside
+    the loop), so a callback that returns true without calling a setter caches the previous triangle again - also when the
+    setters write straight into the upload staging block."""
+    from obj2voxel_amd import capi
+    a = capi.api()
+    a.obj2voxel_set_log_level(capi.LOG_SILENT)
+    v = meshes.uv_sphere(12)
+    state = {"i": 0, "calls": 0}
+
+    def feed(_data, tri):
+        state["calls"] += 1
+        if state["calls"] % 3 == 0:
+            return True                     # nothing set: the previous triangle once more
+        if state["i"] >= len(v):
+            return False
+        a.obj2voxel_set_triangle_basic(tri, capi._fptr(v[state["i"]]))
+        state["i"] += 1
+        return True
+    cb = capi.TRIANGLE_CB(feed)
+    inst = a.obj2voxel_alloc()
+    a.obj2voxel_set_input_callback(inst, cb, None)
+    out = capi.CollectingOutput()
+    a.obj2voxel_set_output_callback(inst, out.callback, None)
+    a.obj2voxel_set_resolution(inst, 64)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    a.obj2voxel_free(inst)
+    a.obj2voxel_set_log_level(capi.LOG_INFO)
+    assert state["calls"] > len(v) * 1.4
+    # duplicates of material-less triangles change nothing: the sphere's voxels
+    assert np.array_equal(meshes.sorted_voxels(out.voxels()), meshes.sorted_voxels(oracle.voxelize(v, 64)))

@@ -448,7 +448,11 @@ struct VoxShape {
 #define O2V_BATCHES 4
 #define O2V_BATCHES_LARGE 6
 #endif
-    static constexpr uint32_t batches = block >= 256u ? O2V_BATCHES : 2u, batches_large = block >= 256u ? O2V_BATCHES_LARGE : 3u;
+#ifndef O2V_BATCHES_UV
+#define O2V_BATCHES_UV 2
+#define O2V_BATCHES_LARGE_UV 3
+#endif
+    static constexpr uint32_t batches = block >= 256u ? O2V_BATCHES : O2V_BATCHES_UV, batches_large = block >= 256u ? O2V_BATCHES_LARGE : O2V_BATCHES_LARGE_UV;
     static constexpr uint32_t finer_min = 32u * block / 256u;
 };
 constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf straddles at least this many voxel planes is queued first

@@ -52,6 +52,9 @@ def _case(seed):
     tex_a = (rng.integers(0, 256, size=(int(rng.integers(1, 40)), int(rng.integers(1, 40)), 3))).astype(np.uint8)
     tex_b = (rng.integers(0, 256, size=(16, 8, 4))).astype(np.uint8)
     textures = [(tex_a, int(rng.integers(0, 2))), (tex_b, int(rng.integers(0, 2)))]
+    if seed % 4 == 3:
+        # no materials at all: occupancy-only mode (first surviving piece decides, hits without clipping, byte grid)
+        mat = {}
     return v, res, kw, mat, textures
 
 
@@ -99,6 +102,8 @@ def _planar_case(seed):
     kw = dict(strategy=int(rng.integers(0, 2)), bounds=bounds)
     types = np.full(T, 2, np.uint32)
     mat = dict(types=types, colors=rng.random((T, 3)).astype(np.float32))
+    if seed % 3 == 2:
+        mat = {}    # occupancy-only mode on planar / epsilon cases
     return v, S, kw, mat
 
 
@@ -134,6 +139,8 @@ def _far_corner_case(seed, S=16000):
     bounds = [-0.25] * 3 + [S - 0.75] * 3   # mesh transform x -> x + 0.5 up to rounding (see _planar_case)
     kw = dict(strategy=seed % 2 if S == 16000 else 1, bounds=bounds, zslab=(S - zspan - 1, S))
     mat = dict(types=np.full(T, 2, np.uint32), colors=rng.random((T, 3)).astype(np.float32))
+    if seed % 2 == 1:
+        mat = {}    # occupancy-only mode far from the origin (its margins scale with the coordinates too)
     return v, S, kw, mat
 
 

@@ -128,9 +128,17 @@ __device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, 
                    tot_big = (uint32_t) (tot >> 42) & 2047u, tot_node = (uint32_t) (tot >> 53) & 2047u;
     __syncthreads();
     if (threadIdx.x == 0) {
-        s_base[0] = tot_leaf ? atomicAdd(&c->n_leaves, tot_leaf) : 0u;
+        // leaves and tiles are reserved with ONE 64-bit atomic on the pair (n_leaves, n_tiles): atomics on one cache line
+        // serialise (~88 per us), and with a thousand workgroups reserving at once they were most of k_expand_roots' time
+        static_assert(offsetof(Counters, n_leaves) % 8 == 0 && offsetof(Counters, n_tiles) == offsetof(Counters, n_leaves) + 4, "pair");
+        s_base[0] = s_base[1] = 0u;
+        if (tot_leaf | tot_tile) {
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&c->n_leaves),
+                                                     (unsigned long long) tot_leaf | ((unsigned long long) tot_tile << 32));
+            s_base[0] = (uint32_t) old;
+            s_base[1] = (uint32_t) (old >> 32);
+        }
         if (tot_leaf && node_round == 0) atomicAdd(&c->n_root_leaves, tot_leaf);
-        s_base[1] = tot_tile ? atomicAdd(&c->n_tiles, tot_tile) : 0u;
         s_base[2] = tot_big ? atomicAdd(&c->n_big, tot_big) : 0u;
         s_base[3] = tot_node ? atomicAdd(&c->n_nodes[node_round], tot_node) : 0u;
     }

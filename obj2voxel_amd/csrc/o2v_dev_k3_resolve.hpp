@@ -739,35 +739,51 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
         __syncthreads();
     };
     uint32_t *grid4 = reinterpret_cast<uint32_t *>(p.occgrid);
+    // the list entries of a round are requested one round ahead (the brick loads depend on them: two round trips per round
+    // otherwise)
+    auto list_entry = [&](uint32_t r, uint32_t k) -> uint32_t {
+        const uint32_t item = r * kOccBricksPerRound + (wave * kOccBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
+        return (r < n_rounds && item < n_dirty) ? dirty_list[item] : 0xffffffffu;
+    };
+    uint32_t next_brick[kOccBricksPerWave];
+#pragma unroll
+    for (uint32_t k = 0; k < kOccBricksPerWave; ++k) next_brick[k] = list_entry(blockIdx.x, k);
     for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
         uint32_t brick[kOccBricksPerWave], cells4[kOccBricksPerWave];
 #pragma unroll
         for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
-            const uint32_t item = r * kOccBricksPerRound + (wave * kOccBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
-            brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
+            brick[k] = next_brick[k];
+            next_brick[k] = list_entry(r + gridDim.x, k);
         }
 #pragma unroll
         for (uint32_t k = 0; k < kOccBricksPerWave; ++k)
             cells4[k] = brick[k] != 0xffffffffu ? grid4[(uint64_t) brick[k] * kLanesPerBrick + lane % kLanesPerBrick] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
-            if (cells4[k]) {
-                const uint32_t row = brick[k] / p.NBx;
-                const uint32_t bx = brick[k] - row * p.NBx;
-                const uint32_t bz = row / p.NBy;
-                const uint32_t by = row - bz * p.NBy;
+            // (wavefront-uniform loop over the four cells of a lane: the staging slots are reserved with one LDS atomic per
+            // wavefront and cell position, not one per voxel)
+            const uint32_t row = brick[k] == 0xffffffffu ? 0u : brick[k] / p.NBx;
+            const uint32_t bx = brick[k] - row * p.NBx;
+            const uint32_t bz = row / p.NBy;
+            const uint32_t by = row - bz * p.NBy;
 #pragma unroll
-                for (uint32_t e = 0; e < 4; ++e) {
-                    if ((cells4[k] >> (8u * e)) & 0xffu) {
+            for (uint32_t e = 0; e < 4; ++e) {
+                const bool set = ((cells4[k] >> (8u * e)) & 0xffu) != 0u;
+                const unsigned long long m = __ballot(set);
+                if (m) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_n, (uint32_t) __popcll(m));
+                    base = __shfl(base, 0, 64);
+                    if (set) {
                         const uint32_t local = (lane % kLanesPerBrick) * 4u + e;
-                        const uint32_t slot = atomicAdd(&s_n, 1u);
+                        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
                         s_rec[slot] = make_uint4((bx << kBrickXs) + (local & (kBrickX - 1u)),
                                                  (by << kBrickYs) + ((local >> kBrickXs) & (kBrickY - 1u)),
                                                  (bz << kBrickZs) + (local >> (kBrickXs + kBrickYs)) + p.zo0, white);
                     }
                 }
-                grid4[(uint64_t) brick[k] * kLanesPerBrick + lane % kLanesPerBrick] = 0u;  // clean for the next run
             }
+            if (cells4[k]) grid4[(uint64_t) brick[k] * kLanesPerBrick + lane % kLanesPerBrick] = 0u;  // clean for the next run
         }
         __syncthreads();
         const uint32_t n = s_n;

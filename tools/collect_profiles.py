@@ -122,5 +122,5 @@ if "config2" in summary:
 for extra in ("predict_scaling_8_weak.jsonl", "predict_scaling_8_config4.jsonl"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(out_dir, extra))
-if os.path.exists(os.path.join(src, "bench_line.json")):
+if os.path.exists(os.path.join(src, "bench_line.json")) and os.path.getsize(os.path.join(src, "bench_line.json")):
     shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(out_dir, "bench_line.json"))

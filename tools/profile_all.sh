@@ -23,12 +23,19 @@ for W in $WL; do
   timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OUT/${W}_sq2 -o p -- $CMD $S2 > $OUT/${W}_sq2.log 2>&1
   grep "^{" $OUT/${W}_stats.log | tail -1 > $OUT/${W}_line.json
 done
-# the bench line itself (with the CPU baseline and the C API wall time), unprofiled
 python -c "from obj2voxel_amd import hip; print(hip.build_id())" > $OUT/build_id.txt
+# the summaries are made here, so that the bench line below reads the counters of THIS build (profiles/current.json), and
+# travel back under gpurun_out/ (copy gpurun_out/prof/profiles/* into profiles/ afterwards)
+ROUND=${O2V_ROUND:-r03}
+python tools/collect_profiles.py $ROUND > $OUT/collect.log 2>&1
+# the bench line itself (with the routes, the CPU baseline and the C API wall time), unprofiled
 timeout -k 5 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+cp $OUT/bench_line.json profiles/$ROUND/bench_line.json
 # predicted multi-GPU balance (one GPU runs the planned slabs of the N = 8 jobs one after the other)
 timeout -k 5 200 python tools/predict_scaling.py 8 weak > $OUT/predict_scaling_8_weak.jsonl 2>&1
-timeout -k 5 400 python tools/predict_scaling.py 8 config4 > $OUT/predict_scaling_8_config4.jsonl 2>&1
+timeout -k 5 500 python tools/predict_scaling.py 8 config4 > $OUT/predict_scaling_8_config4.jsonl 2>&1
+cp $OUT/predict_scaling_8_*.jsonl profiles/$ROUND/ 2>/dev/null
+mkdir -p $OUT/profiles && cp -r profiles/$ROUND profiles/current.json $OUT/profiles/
 # keep the merge small: only the summaries travel back
-find $OUT -name "*_agent_info.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*_agent_info.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete
 du -sh $OUT; tail -c 400 $OUT/bench_line.json

@@ -361,6 +361,7 @@ def report(args, n, run, dv, comm):
     REC = 16                               # sorted record: 16 bytes for a mesh without textured triangles (these workloads)
     CPB = st["grid_cells"] // max(st["bricks"], 1)   # cells per brick of the dense grids (o2v_dev_common.hpp: kBrickCells)
     direct = Hd > 0
+    occ = "k_emit_occ" in (run.get("kernels_ms") or {}) or bool(st.get("certain_hits"))   # occupancy-only mode (material-less mesh)
     alg = {
         "bounds": 36 * T,
         "expand": 36 * T + 96 * L + 8 * tiles,
@@ -386,6 +387,12 @@ def report(args, n, run, dv, comm):
         stage_kernels["resolve"] = ["k_emit_max"]
         alg["scan"] = 2 * B
         alg["resolve"] -= B
+    if occ:
+        # one byte per cell: a job record per remaining voxel job, a byte + a flag per hit; the emission reads and zeroes 64
+        # bytes per dirty brick and writes the records
+        alg["voxelize"] = 96 * L + 8 * tiles + 16 * st["jobs"] + 2 * H
+        stage_kernels["resolve"] = ["k_emit_occ"]
+        alg["resolve"] = 2 * CPB * D + 16 * Vr
     bound_of = {"bounds": "hbm", "expand": "hbm", "voxelize": "valu", "scan": "hbm", "resolve": "hbm"}
     stages = []
     for name in ("bounds", "expand", "voxelize", "scan", "resolve"):

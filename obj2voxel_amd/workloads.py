@@ -161,6 +161,10 @@ def kernel_algorithmic_bytes(stats, textured, strategy_blend):
         out["k_scatter"] = 32 * slots + (4 + rec) * Hp
         out["k_reset_bricks"] = 4 * cpb * D
         out["k_resolve<6>" if textured else "k_resolve<4>"] = 16 * V + rec * Hp + 16 * V   # (all tiers together: cells + records + output)
-    if direct:
+    if direct and stats.get("certain_hits"):
+        # occupancy-only mode: a job record per remaining voxel job, a byte and a flag per hit; 64 bytes per dirty brick
+        out["k_voxelize<false>"] = 96 * L + 8 * tiles + 16 * jobs + 2 * H
+        out["k_emit_occ"] = 2 * cpb * D + 16 * V
+    elif direct:
         out["k_emit_max"] = 8 * cpb * D + 32 * V + 16 * V
     return {k: int(v) for k, v in out.items()}

@@ -789,19 +789,6 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             const uint32_t axis = lf[17];
                             const uint32_t iu = axis == 0u ? 1u : 0u, iw = axis == 2u ? 1u : 2u;
                             const float tau = __uint_as_float(lf[16]);
-                            {
-                                // A vertex of the leaf strictly inside the voxel: splitTriangle hands a vertex that is on the kept
-                                // side of the plane and not within 2^-16 of it on unchanged, as a vertex of a kept piece, in every
-                                // one of its cases (voxelization.cpp:190-331), so after the six planes a piece with that vertex
-                                // is left.  (Exact vertices: no drift to allow for; tau < inf: the triangle's area is non-zero
-                                // and the leaf finite.)
-                                const float fx0 = (float) qx, fy0 = (float) qy, fz0 = (float) qz, e2 = 2.0f * kEpsilon;
-                                auto inside = [&](V3 a) {
-                                    return a.x >= fx0 + e2 && a.x < fx0 + (1.0f - e2) && a.y >= fy0 + e2 && a.y < fy0 + (1.0f - e2) &&
-                                           a.z >= fz0 + e2 && a.z < fz0 + (1.0f - e2);
-                                };
-                                certain = tau < __builtin_inff() && (inside(v0) || inside(v1) || inside(v2));
-                            }
                             if (tau < 0.34f) {  // (else no point of the leaf is far enough from its edges)
                                 const float lim = 0.5f - (1.5f * s_satm[kk] + 1e-3f);  // 0.5 - D, D = certain_margin(m)
                                 // kN lines across the voxel (constant offset in the second lattice axis); along a line every

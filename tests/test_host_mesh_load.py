@@ -49,3 +49,18 @@ def test_obj_with_materials(tmp_path):
 def test_build_id_is_a_source_hash():
     bid = hip.build_id()
     assert len(bid) == 16 and int(bid, 16) >= 0
+
+
+def test_build_id_matches_the_device_sources():
+    """The id embedded in the library is the hash the Makefile computes over the device sources: a library whose device
+    object was not rebuilt after a source change would carry counters' trust it does not deserve (bench.py compares it with
+    the id recorded in profiles/current.json)."""
+    import glob
+    import hashlib
+    import os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "obj2voxel_amd", "csrc")
+    files = [os.path.join(csrc, "o2v_device.hip")] + sorted(glob.glob(os.path.join(csrc, "o2v_dev_*.hpp"))) + [os.path.join(csrc, "o2v_math.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(f, "rb").read())
+    assert hip.build_id() == h.hexdigest()[:16]

@@ -261,6 +261,62 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wave /*
     return base + inc - v;
 }
 
+// colorAt_f in three steps, for code that looks several colours up at once: the loads of one step are independent of each
+// other (and of the other colours' loads), so n lookups cost three memory round trips instead of 3 n.
+struct MatFetch {  // step 1: what the triangle's material is (independent loads)
+    uint32_t type, texid;
+    float r, g, b;
+};
+__device__ __forceinline__ MatFetch mat_fetch(const Materials &m, uint32_t tri)
+{
+    MatFetch f;
+    f.type = m.types ? m.types[tri] : (uint32_t) kTriMaterialless;
+    f.texid = m.texids ? (uint32_t) m.texids[tri] : 0u;
+    f.r = m.colors ? m.colors[(size_t) tri * 3 + 0] : 0.f;
+    f.g = m.colors ? m.colors[(size_t) tri * 3 + 1] : 0.f;
+    f.b = m.colors ? m.colors[(size_t) tri * 3 + 2] : 0.f;
+    return f;
+}
+// step 2: the texel's address (texture get, triangle.hpp:161-166; getPixel semantics: see DESIGN.md)
+__device__ __forceinline__ const uint8_t *texel_address(const DevTexture &tx, float u, float v)
+{
+    float tu = u, tv = 1 - v;
+    if (tx.wrap) {
+        tu = tu - floor_f(tu);
+        tv = tv - floor_f(tv);
+    }
+    else {
+        tu = tu < 0.f ? 0.f : (tu > 1.f ? 1.f : tu);
+        tv = tv < 0.f ? 0.f : (tv > 1.f ? 1.f : tv);
+    }
+    uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
+    if (px >= tx.width) px = tx.width - 1;
+    if (py >= tx.height) py = tx.height - 1;
+    return tx.pixels + ((size_t) py * tx.width + px) * tx.channels + (tx.channels == 4 ? 1u : 0u);
+}
+// step 3: the colour from the material and the three texel bytes
+__device__ __forceinline__ void mat_color(const MatFetch &f, bool have_textures, uint8_t q0, uint8_t q1, uint8_t q2, float &r, float &g, float &b)
+{
+    if (f.type == kTriMaterialless) {
+        r = g = b = 1.f;
+    }
+    else if (f.type == kTriUntextured) {
+        r = f.r;
+        g = f.g;
+        b = f.b;
+    }
+    else if (f.type == kTriTextured && have_textures) {
+        r = (float) q0 / 255.f;
+        g = (float) q1 / 255.f;
+        b = (float) q2 / 255.f;
+    }
+    else {
+        r = 1.f;
+        g = 0.f;
+        b = 1.f;
+    }
+}
+
 // colorAt_f, triangle.hpp:181-194 (+ texture get, triangle.hpp:161-166; getPixel semantics: see DESIGN.md)
 __device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float u, float v, float &r, float &g, float &b)
 {

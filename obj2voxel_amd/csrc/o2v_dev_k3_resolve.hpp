@@ -90,6 +90,37 @@ __device__ __forceinline__ void emit_cell(const Occ &o, uint32_t argb, float w, 
 }
 
 
+// The fold over one cell's (sub-voxel, triangle) groups, each already reduced to {weight, colour}: CellFold's close_tri /
+// close_sub sequence (moveUvBufferIntoVoxels, voxelization.cpp:513-526; downscale, voxelization.hpp:82-85) without the
+// per-hit part and without its memory accesses.  Groups must be added in ascending key order.
+struct GroupFold {
+    bool have_sub = false, have_cell = false;
+    uint32_t cur = 0, sub_key = 0, cell_key = 0;
+    WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
+    __device__ __forceinline__ void close_sub(uint32_t blend)
+    {
+        if (!have_cell || (!blend && sub_acc.w > cell_acc.w)) cell_key = sub_key;
+        cell_acc = have_cell ? wcombine(blend, sub_acc, cell_acc) : sub_acc;
+        have_cell = true;
+        have_sub = false;
+    }
+    __device__ __forceinline__ void add(uint32_t blend, uint32_t keyhi, const WCol &fresh)
+    {
+        if (have_sub && (keyhi >> 29) != (cur >> 29)) close_sub(blend);
+        if (!have_sub || (!blend && fresh.w > sub_acc.w)) sub_key = keyhi;  // wmax keeps the existing value on a tie
+        sub_acc = have_sub ? wcombine(blend, fresh, sub_acc) : fresh;
+        have_sub = true;
+        cur = keyhi;
+    }
+    __device__ __forceinline__ uint32_t finish(uint32_t blend)
+    {
+        if (have_sub) close_sub(blend);
+        return pack_argb(cell_acc.r, cell_acc.g, cell_acc.b);
+    }
+};
+
+constexpr uint32_t kTexCache = 16;  // texture descriptors k_resolve keeps in LDS (more textures: read from global memory)
+
 // Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
 // from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
 template <uint32_t STRIDE>
@@ -100,7 +131,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
     __shared__ uint64_t s_key[kShortList][kBlock];
     __shared__ float s_w[kShortList][kBlock], s_u[kUv ? kShortList : 1][kBlock], s_v[kUv ? kShortList : 1][kBlock];
     const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads below stay branch-free
+    __shared__ DevTexture s_tex[kTexCache];  // the first textures' descriptors (the colour lookup reads them per group)
     if (pass_overflowed(c, p)) return;
+    if (kUv) {
+        for (uint32_t t = threadIdx.x; t < kTexCache && t < m.n_textures; t += kBlock) s_tex[t] = m.textures[t];
+        __syncthreads();
+    }
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
@@ -132,19 +168,89 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
                 }
             }
         }
-        CellFold f;
-        for (uint32_t t = 0; t < o.count; ++t)
-            f.add(m, p.blend, (uint32_t) (s_key[t][threadIdx.x] >> 32), s_w[t][threadIdx.x],
-                  kUv ? s_u[t][threadIdx.x] : 0.f, kUv ? s_v[t][threadIdx.x] : 0.f);
-        const uint32_t argb = f.finish(m, p.blend);
+        // The fold in two passes.  First the (sub-voxel, triangle) groups - the leaves of one triangle in one (sub-)voxel,
+        // insertWeighted<BLEND> (voxelization.cpp:466-468) - are reduced to {key, weight, uv} in place (group g <= record t).
+        // Then their colours (colorAt_f) are looked up four at a time, every step's loads independent of each other: a colour is
+        // a chain of dependent loads (type -> colour or texture index -> texel), and folding record by record walked that
+        // chain once per group, one after the other.  Last the cell's chain over the groups (GroupFold).
+        uint32_t ng = 0;
+        {
+            uint32_t cur = (uint32_t) (s_key[0][threadIdx.x] >> 32);
+            WUv acc{s_w[0][threadIdx.x], kUv ? s_u[0][threadIdx.x] : 0.f, kUv ? s_v[0][threadIdx.x] : 0.f};
+            for (uint32_t t = 1; t < o.count; ++t) {
+                const uint32_t kh = (uint32_t) (s_key[t][threadIdx.x] >> 32);
+                const WUv hit{s_w[t][threadIdx.x], kUv ? s_u[t][threadIdx.x] : 0.f, kUv ? s_v[t][threadIdx.x] : 0.f};
+                if (kh != cur) {
+                    s_key[ng][threadIdx.x] = (uint64_t) cur << 32;
+                    s_w[ng][threadIdx.x] = acc.w;
+                    if (kUv) {
+                        s_u[ng][threadIdx.x] = acc.u;
+                        s_v[ng][threadIdx.x] = acc.v;
+                    }
+                    ++ng;
+                    cur = kh;
+                    acc = hit;
+                }
+                else {
+                    acc = wmix(hit, acc);
+                }
+            }
+            s_key[ng][threadIdx.x] = (uint64_t) cur << 32;
+            s_w[ng][threadIdx.x] = acc.w;
+            if (kUv) {
+                s_u[ng][threadIdx.x] = acc.u;
+                s_v[ng][threadIdx.x] = acc.v;
+            }
+            ++ng;
+        }
+        GroupFold f;
+        for (uint32_t g0 = 0; g0 < ng; g0 += 4u) {
+            uint32_t hi4[4];
+            float w4[4];
+            MatFetch mf[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t g = g0 + j < ng ? g0 + j : g0;  // (a valid group: the loads below are unconditional)
+                hi4[j] = (uint32_t) (s_key[g][threadIdx.x] >> 32);
+                w4[j] = s_w[g][threadIdx.x];
+                mf[j] = mat_fetch(m, hi4[j] & 0x1fffffffu);
+            }
+            uint8_t q[4][3] = {};
+            if (kUv && m.n_textures) {
+                const uint8_t *qa[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t g = g0 + j < ng ? g0 + j : g0;
+                    uint32_t id = mf[j].texid < m.n_textures ? mf[j].texid : 0u;
+                    const DevTexture tx = id < kTexCache ? s_tex[id] : m.textures[id];
+                    // (a group that is not textured reads three bytes of texture 0's first texel: any valid address)
+                    qa[j] = mf[j].type == kTriTextured ? texel_address(tx, s_u[g][threadIdx.x], s_v[g][threadIdx.x]) : s_tex[0].pixels;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    q[j][0] = qa[j][0];
+                    q[j][1] = qa[j][1];
+                    q[j][2] = qa[j][2];
+                }
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (g0 + j < ng) {
+                    float cr, cg, cb;
+                    mat_color(mf[j], kUv && m.n_textures != 0u, q[j][0], q[j][1], q[j][2], cr, cg, cb);
+                    f.add(p.blend, hi4[j], WCol{w4[j], cr, cg, cb});
+                }
+            }
+        }
+        const uint32_t argb = f.finish(p.blend);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
 
 // Tier 2: cells with 9..64 hits, W = 16, 32 or 64 lanes per cell (64 / W cells per wavefront).  Every lane loads one
 // record; the (key, position) pairs are bitonic-sorted across the W lanes with cross-lane moves only (no LDS, no
-// barrier); the payload is gathered to its sorted lane and the cell is folded in order, every lane of the group
-// running the same fold on broadcast values.
+// barrier); the payload is gathered to its sorted lane; the groups are folded and coloured in parallel by the lanes at their
+// first records, and the cell's chain over the groups runs on every lane of the cell on broadcast values.
 template <uint32_t W>
 __global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restrict__ list, const uint32_t *n_list,
                                                          const Counters *c, const Occ *__restrict__ occ,
@@ -195,28 +301,42 @@ __global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restr
         w = __shfl(w, src, 64);
         u = __shfl(u, src, 64);
         v = __shfl(v, src, 64);
-        CellFold f;
+        // Lane sl now holds the cell's sl-th record in the reference's order.  The records of one (sub-voxel, triangle) group -
+        // the leaves of one triangle in one (sub-)voxel - are neighbours: the lane at a group's first record folds the group
+        // (insertWeighted<BLEND>, voxelization.cpp:466-468) and looks its colour up (colorAt_f), ALL GROUPS AT ONCE: the colour
+        // lookup is a chain of dependent loads (type -> colour or texture index -> texture -> texel), and folding the cell
+        // record by record would walk that chain once per group, one after the other (it did: 4.0 ms on configs[3]).
+        const uint32_t prev_hi = __shfl_up(hi, 1u, 64);
+        const bool start = sl < n && (sl == 0u || prev_hi != hi);
+        WUv acc{w, u, v};
+        {
+            bool open = start;
+            for (uint32_t d = 1; d < W; ++d) {  // (wavefront-uniform trip count: the longest group)
+                const uint32_t nh = __shfl_down(hi, d, 64);
+                const float nw = __shfl_down(w, d, 64), nu = __shfl_down(u, d, 64), nv = __shfl_down(v, d, 64);
+                open = open && sl + d < n && nh == hi;
+                if (!__any(open)) break;
+                if (open) acc = wmix(WUv{nw, nu, nv}, acc);
+            }
+        }
+        WCol fresh{0.f, 0.f, 0.f, 0.f};
+        if (start) {
+            float cr, cg, cb;
+            color_at(m, hi & 0x1fffffffu, acc.u, acc.v, cr, cg, cb);
+            fresh = WCol{acc.w, cr, cg, cb};
+        }
+        // ... then the chain over the groups, in order, on values that are already there (every lane of the cell runs it)
+        GroupFold f;
         for (uint32_t t = 0; t < W; ++t) {
             if (!__any(t < n)) break;
-            uint32_t hh;
-            float ww, uu, vv;
-            if (W == 64) {
-                // one cell per wavefront: the source lane is uniform, the values come straight out of its registers
-                hh = (uint32_t) __builtin_amdgcn_readlane((int) hi, (int) t);
-                ww = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(w), (int) t));
-                uu = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(u), (int) t));
-                vv = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), (int) t));
-            }
-            else {
-                const int from = (int) (base_lane + t);
-                hh = __shfl(hi, from, 64);
-                ww = __shfl(w, from, 64);
-                uu = __shfl(u, from, 64);
-                vv = __shfl(v, from, 64);
-            }
-            if (t < n) f.add(m, p.blend, hh, ww, uu, vv);
+            const int from = (int) (base_lane + t);
+            const bool st = __shfl((int) start, from, 64) != 0;
+            if (!__any(st)) continue;
+            const uint32_t hh = __shfl(hi, from, 64);
+            const WCol g{__shfl(fresh.w, from, 64), __shfl(fresh.r, from, 64), __shfl(fresh.g, from, 64), __shfl(fresh.b, from, 64)};
+            if (st) f.add(p.blend, hh, g);
         }
-        const uint32_t argb = f.finish(m, p.blend);
+        const uint32_t argb = f.finish(p.blend);
         if (n != 0 && sl == 0) emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }

@@ -179,16 +179,32 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
                                            : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
-            if (h[k].x | h[k].y | h[k].z | h[k].w) {
-                const uint32_t hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
+            // The occupied cells are staged in (brick, cell) order - the lanes of a load hold consecutive groups of four cells
+            // of consecutive bricks - so that the offsets scan_flush hands out follow the cells' order inside a brick:
+            // neighbouring cells then own neighbouring ranges of the sorted array, and the hits k_scatter places for one row of
+            // voxels fall into the same few lines.  One LDS atomic per wavefront and load.
+            const uint32_t hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
+            const uint32_t mine = (hv[0] ? 1u : 0u) + (hv[1] ? 1u : 0u) + (hv[2] ? 1u : 0u) + (hv[3] ? 1u : 0u);
+            uint32_t inc = mine;
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            const uint32_t total = __shfl(inc, 63, 64);
+            if (total) {
+                uint32_t base = 0;
+                if (lane == 63) base = atomicAdd(&s_n, total);
+                base = __shfl(base, 63, 64);
+                uint32_t slot = base + inc - mine;
 #pragma unroll
                 for (uint32_t e = 0; e < 4; ++e) {
                     if (hv[e]) {
                         const uint64_t cell = (uint64_t) brick[k] * kBrickCells + (lane % kLanesPerBrick) * 4u + e;
-                        const uint32_t slot = atomicAdd(&s_n, 1u);
                         s_lo[slot] = (uint32_t) cell;
                         s_hi[slot] = (uint32_t) (cell >> 32);
                         s_cnt[slot] = hv[e];
+                        ++slot;
                     }
                 }
             }

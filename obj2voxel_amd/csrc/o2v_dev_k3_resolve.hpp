@@ -121,128 +121,170 @@ struct GroupFold {
 
 constexpr uint32_t kTexCache = 16;  // texture descriptors k_resolve keeps in LDS (more textures: read from global memory)
 
-// Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are insertion-sorted in registers
-// from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
+// Tier 1: one lane per occupied cell.  Cells with up to 8 hits (the common case) are sorted in the lane's registers (a
+// sorting network) from their contiguous records; longer ones are deferred, by hit count, to the cooperative kernels below.
+// Batcher's odd-even merge sort as a list of compare-exchange pairs (N a power of two): 19 pairs for 8 keys, 63 for 16.
+template <uint32_t N>
+struct SortNet {
+    uint8_t a[N * 4], b[N * 4];
+    uint32_t n = 0;
+    constexpr SortNet() : a{}, b{}
+    {
+        for (uint32_t q = 1; q < N; q *= 2)
+            for (uint32_t k = q; k >= 1; k /= 2)
+                for (uint32_t j = k % q; j + k < N; j += 2 * k)
+                    for (uint32_t i = 0; i < k && i + j + k < N; ++i)
+                        if ((i + j) / (2 * q) == (i + j + k) / (2 * q)) {
+                            a[n] = (uint8_t) (i + j);
+                            b[n] = (uint8_t) (i + j + k);
+                            ++n;
+                        }
+    }
+};
+
+// One cell with up to N hits, resolved by one lane out of its registers (compile-time indices only): the records are sorted
+// by a sorting network, reduced to their (sub-voxel, triangle) groups in one forward pass, coloured four groups at a time
+// and folded.  Returns the cell's ARGB; `f` holds the winner for the direct MAX path.
+template <uint32_t STRIDE, uint32_t N>
+__device__ __forceinline__ uint32_t resolve_cell_in_registers(const Occ &o, const SortedView &sorted, const Materials &m, const DevTexture *s_tex,
+                                                              const Params &p, GroupFold &f)
+{
+    constexpr bool kUv = STRIDE == 6;  // 16-byte records carry no uv
+    // All loads are issued before anything is consumed (independent round trips overlap); slots beyond the cell's count get
+    // the greatest key and sort to the end.
+    uint64_t key[N];
+    float w[N], u[N], v[N];
+    {
+        SortedRec r[N];
+#pragma unroll
+        for (uint32_t k = 0; k < N; ++k) r[k] = sorted.load(o.offset + (k < o.count ? k : 0u));
+#pragma unroll
+        for (uint32_t k = 0; k < N; ++k) {
+            key[k] = k < o.count ? (((uint64_t) r[k].keyhi << 32) | r[k].keylo) : ~0ull;
+            w[k] = r[k].w;
+            u[k] = kUv ? r[k].u : 0.f;
+            v[k] = kUv ? r[k].v : 0.f;
+        }
+    }
+    // no memory, no data-dependent loop (round 2 insertion-sorted a private LDS column: 40 KiB per workgroup, three wavefronts
+    // per SIMD, a dependent LDS round trip per step)
+    constexpr SortNet<N> net{};
+#pragma unroll
+    for (uint32_t e = 0; e < net.n; ++e) {
+        const uint32_t a = net.a[e], b = net.b[e];
+        const bool sw = key[a] > key[b];
+        const uint64_t ka = key[a], kb = key[b];
+        key[a] = sw ? kb : ka;
+        key[b] = sw ? ka : kb;
+        const float wa = w[a], wb = w[b];
+        w[a] = sw ? wb : wa;
+        w[b] = sw ? wa : wb;
+        if (kUv) {
+            const float ua = u[a], ub = u[b], va = v[a], vb = v[b];
+            u[a] = sw ? ub : ua;
+            u[b] = sw ? ua : ub;
+            v[a] = sw ? vb : va;
+            v[b] = sw ? va : vb;
+        }
+    }
+    // The fold in three steps.  (1) One pass forward reduces every (sub-voxel, triangle) group - the leaves of one triangle
+    // in one (sub-)voxel, insertWeighted<BLEND> (voxelization.cpp:466-468) - into the slot of its LAST record.
+    // (2) The groups' colours (colorAt_f) are looked up four slots at a time, every step's loads independent of each other:
+    // a colour is a chain of dependent loads (type -> colour or texture index -> texel), and folding record by record
+    // walked that chain once per group, one after the other.  (3) The cell's chain over the groups (GroupFold).
+    uint32_t hi[N];
+    bool last[N];
+    {
+        WUv acc{0.f, 0.f, 0.f};
+#pragma unroll
+        for (uint32_t t = 0; t < N; ++t) {
+            hi[t] = (uint32_t) (key[t] >> 32);
+            const bool start = t == 0 || hi[t] != hi[t - 1];
+            const WUv hit{w[t], u[t], v[t]};
+            acc = start ? hit : wmix(hit, acc);
+            last[t] = t < o.count && (t + 1 >= o.count || (uint32_t) (key[t + 1 < N ? t + 1 : t] >> 32) != hi[t]);
+            w[t] = acc.w;
+            u[t] = acc.u;
+            v[t] = acc.v;
+        }
+    }
+#pragma unroll
+    for (uint32_t g0 = 0; g0 < N; g0 += 4u) {
+        if (g0 >= o.count) continue;
+        MatFetch mf[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j)
+            mf[j] = mat_fetch(m, (last[g0 + j] ? hi[g0 + j] : hi[0]) & 0x1fffffffu);  // (a valid triangle: the loads are unconditional)
+        uint8_t q[4][3] = {};
+        if (kUv && m.n_textures) {
+            const uint8_t *qa[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t id = mf[j].texid < m.n_textures ? mf[j].texid : 0u;
+                const DevTexture tx = id < kTexCache ? s_tex[id] : m.textures[id];
+                // (a slot that is not a textured group reads three bytes of texture 0's first texel: any valid address)
+                qa[j] = (last[g0 + j] && mf[j].type == kTriTextured) ? texel_address(tx, u[g0 + j], v[g0 + j]) : s_tex[0].pixels;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                q[j][0] = qa[j][0];
+                q[j][1] = qa[j][1];
+                q[j][2] = qa[j][2];
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (last[g0 + j]) {
+                float cr, cg, cb;
+                mat_color(mf[j], kUv && m.n_textures != 0u, q[j][0], q[j][1], q[j][2], cr, cg, cb);
+                f.add(p.blend, hi[g0 + j], WCol{w[g0 + j], cr, cg, cb});
+            }
+        }
+    }
+    return f.finish(p.blend);
+}
+
 template <uint32_t STRIDE>
 __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn,
                                                     const Counters *c, Materials m, uint4 *out, Params p)
 {
-    constexpr bool kUv = STRIDE == 6;  // 16-byte records carry no uv: the columns shrink to 24 KiB, 6 workgroups per CU
-    __shared__ uint64_t s_key[kShortList][kBlock];
-    __shared__ float s_w[kShortList][kBlock], s_u[kUv ? kShortList : 1][kBlock], s_v[kUv ? kShortList : 1][kBlock];
-    const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads below stay branch-free
+    const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
     __shared__ DevTexture s_tex[kTexCache];  // the first textures' descriptors (the colour lookup reads them per group)
     if (pass_overflowed(c, p)) return;
-    if (kUv) {
+    if (STRIDE == 6) {
         for (uint32_t t = threadIdx.x; t < kTexCache && t < m.n_textures; t += kBlock) s_tex[t] = m.textures[t];
         __syncthreads();
     }
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
-        if (o.count > kShortList) continue;  // filed for a cooperative tier by k_scan_bricks
-        // all loads are issued before anything is consumed (independent round trips overlap), then the records are
-        // insertion-sorted into this lane's private LDS column and folded by a rolled loop
-        SortedRec r[kShortList];
-#pragma unroll
-        for (uint32_t k = 0; k < kShortList; ++k) r[k] = sorted.load(o.offset + (k < o.count ? k : 0u));
-#pragma unroll
-        for (uint32_t k = 0; k < kShortList; ++k) {
-            if (k < o.count) {
-                const uint64_t key = ((uint64_t) r[k].keyhi << 32) | r[k].keylo;
-                uint32_t j = k;
-                while (j > 0 && s_key[j - 1][threadIdx.x] > key) {
-                    s_key[j][threadIdx.x] = s_key[j - 1][threadIdx.x];
-                    s_w[j][threadIdx.x] = s_w[j - 1][threadIdx.x];
-                    if (kUv) {
-                        s_u[j][threadIdx.x] = s_u[j - 1][threadIdx.x];
-                        s_v[j][threadIdx.x] = s_v[j - 1][threadIdx.x];
-                    }
-                    --j;
-                }
-                s_key[j][threadIdx.x] = key;
-                s_w[j][threadIdx.x] = r[k].w;
-                if (kUv) {
-                    s_u[j][threadIdx.x] = r[k].u;
-                    s_v[j][threadIdx.x] = r[k].v;
-                }
-            }
-        }
-        // The fold in two passes.  First the (sub-voxel, triangle) groups - the leaves of one triangle in one (sub-)voxel,
-        // insertWeighted<BLEND> (voxelization.cpp:466-468) - are reduced to {key, weight, uv} in place (group g <= record t).
-        // Then their colours (colorAt_f) are looked up four at a time, every step's loads independent of each other: a colour is
-        // a chain of dependent loads (type -> colour or texture index -> texel), and folding record by record walked that
-        // chain once per group, one after the other.  Last the cell's chain over the groups (GroupFold).
-        uint32_t ng = 0;
-        {
-            uint32_t cur = (uint32_t) (s_key[0][threadIdx.x] >> 32);
-            WUv acc{s_w[0][threadIdx.x], kUv ? s_u[0][threadIdx.x] : 0.f, kUv ? s_v[0][threadIdx.x] : 0.f};
-            for (uint32_t t = 1; t < o.count; ++t) {
-                const uint32_t kh = (uint32_t) (s_key[t][threadIdx.x] >> 32);
-                const WUv hit{s_w[t][threadIdx.x], kUv ? s_u[t][threadIdx.x] : 0.f, kUv ? s_v[t][threadIdx.x] : 0.f};
-                if (kh != cur) {
-                    s_key[ng][threadIdx.x] = (uint64_t) cur << 32;
-                    s_w[ng][threadIdx.x] = acc.w;
-                    if (kUv) {
-                        s_u[ng][threadIdx.x] = acc.u;
-                        s_v[ng][threadIdx.x] = acc.v;
-                    }
-                    ++ng;
-                    cur = kh;
-                    acc = hit;
-                }
-                else {
-                    acc = wmix(hit, acc);
-                }
-            }
-            s_key[ng][threadIdx.x] = (uint64_t) cur << 32;
-            s_w[ng][threadIdx.x] = acc.w;
-            if (kUv) {
-                s_u[ng][threadIdx.x] = acc.u;
-                s_v[ng][threadIdx.x] = acc.v;
-            }
-            ++ng;
-        }
+        if (o.count > kShortList) continue;  // filed for another tier by k_scan_bricks
         GroupFold f;
-        for (uint32_t g0 = 0; g0 < ng; g0 += 4u) {
-            uint32_t hi4[4];
-            float w4[4];
-            MatFetch mf[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t g = g0 + j < ng ? g0 + j : g0;  // (a valid group: the loads below are unconditional)
-                hi4[j] = (uint32_t) (s_key[g][threadIdx.x] >> 32);
-                w4[j] = s_w[g][threadIdx.x];
-                mf[j] = mat_fetch(m, hi4[j] & 0x1fffffffu);
-            }
-            uint8_t q[4][3] = {};
-            if (kUv && m.n_textures) {
-                const uint8_t *qa[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const uint32_t g = g0 + j < ng ? g0 + j : g0;
-                    uint32_t id = mf[j].texid < m.n_textures ? mf[j].texid : 0u;
-                    const DevTexture tx = id < kTexCache ? s_tex[id] : m.textures[id];
-                    // (a group that is not textured reads three bytes of texture 0's first texel: any valid address)
-                    qa[j] = mf[j].type == kTriTextured ? texel_address(tx, s_u[g][threadIdx.x], s_v[g][threadIdx.x]) : s_tex[0].pixels;
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    q[j][0] = qa[j][0];
-                    q[j][1] = qa[j][1];
-                    q[j][2] = qa[j][2];
-                }
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                if (g0 + j < ng) {
-                    float cr, cg, cb;
-                    mat_color(mf[j], kUv && m.n_textures != 0u, q[j][0], q[j][1], q[j][2], cr, cg, cb);
-                    f.add(p.blend, hi4[j], WCol{w4[j], cr, cg, cb});
-                }
-            }
-        }
-        const uint32_t argb = f.finish(p.blend);
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>(o, sorted, m, s_tex, p, f);
+        emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
+    }
+}
+
+// Tier 1b: cells with 9..16 hits, from their list: the same, one lane per cell with sixteen records in its registers (round 2
+// gave such a cell sixteen lanes that all ran its chain: 4.0 ms on configs[3]).
+template <uint32_t STRIDE>
+__global__ __launch_bounds__(kBlock) void k_resolve_list16(const uint32_t *__restrict__ list, const uint32_t *n_list, const Counters *c,
+                                                           const Occ *__restrict__ occ, SortedView sorted_dyn, Materials m, uint4 *out,
+                                                           uint32_t list_cap, Params p)
+{
+    const SortedView sorted{sorted_dyn.base, STRIDE};
+    __shared__ DevTexture s_tex[kTexCache];
+    if (pass_overflowed(c, p)) return;
+    if (STRIDE == 6) {
+        for (uint32_t t = threadIdx.x; t < kTexCache && t < m.n_textures; t += kBlock) s_tex[t] = m.textures[t];
+        __syncthreads();
+    }
+    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < total; item += gridDim.x * kBlock) {
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        GroupFold f;
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kLane16List>(o, sorted, m, s_tex, p, f);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }

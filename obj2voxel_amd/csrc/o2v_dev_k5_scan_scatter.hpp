@@ -66,7 +66,7 @@ constexpr uint32_t kScanFlushAt = 2048;
 constexpr uint32_t kScanCap = kScanFlushAt + kScanBricksPerRound * kBrickCells;
 
 constexpr uint32_t kShortList = 8;     // cells with up to this many hits are sorted in registers by k_resolve
-constexpr uint32_t kLane16List = 16;   // up to this: 16 lanes per cell, bitonic sort in registers (k_resolve_wave<16>)
+constexpr uint32_t kLane16List = 16;   // up to this: one lane per cell, sixteen records in registers (k_resolve_list16)
 constexpr uint32_t kLaneList = 32;     // up to this: 32 lanes per cell (k_resolve_wave<32>)
 constexpr uint32_t kWaveList = 64;     // up to this: one wavefront per cell (k_resolve_wave<64>)
 constexpr uint32_t kMidList = 256;     // up to this: one wavefront per cell, LDS bitonic sort

@@ -291,6 +291,14 @@ void o2v_mesh_free(o2v_mesh *mesh);
  * built with -DO2V_INSTRUMENT (make INSTR=1, tools/instrument.sh); the meaning of each slot is documented there. */
 int o2v_hip_debug_counters(const o2v_hip_ctx *ctx, uint64_t *out16);
 
+/* Self checks of the clip loop's short division forms on the device (obj2voxel_amd/csrc/o2v_dev_arith.hpp).
+ * _check_third: x / 3 against its three-instruction form for all 2^32 float32 bit patterns; out2[0] = differing inputs,
+ * out2[1] = the first of them + 1 (0 if none).
+ * _check_div: n / d against the lean form for `samples` pairs per pair of biased exponents (numerator, divisor);
+ * out65536[en * 256 + ed] = differing pairs.  The kernels only use the lean form inside the region that is all zero. */
+int o2v_hip_debug_check_third(o2v_hip_ctx *ctx, uint64_t *out2);
+int o2v_hip_debug_check_div(o2v_hip_ctx *ctx, uint32_t samples, uint64_t seed, uint32_t *out65536);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,7 @@ constexpr uint32_t kHoleBrick = 0xffffffffu;
 struct PickRec {  // 24 B: {cell lo, cell hi, keyhi, weight bits, argb, 0}
     uint32_t w[6];
 };
-constexpr uint32_t kPickRecord = 1u;  // HitRec::pad of a direct hit's {cell, key, argb (in keylo)} record (textured MAX)
+constexpr uint32_t kPickRecord = 1u;  // HitRec::pad of a direct hit's {cell, key, weight, uv} record (textured MAX): k_pick colours the winner
 constexpr unsigned long long kPickTag = 1ull << 63;  // a max-grid cell that already holds its final argb (low word)
 constexpr uint32_t kMaxRank = 1u << 24;
 

@@ -70,73 +70,105 @@ __device__ __forceinline__ uint32_t classify_index(float c0, float c1, float c2,
 // because later splits depend on it.
 template <bool UV>
 __device__ __forceinline__ uint32_t split_cut(Piece<UV> &cur, Piece<UV> &sec, uint32_t cls, uint32_t axis, float plane,
-                                              bool keep_lo)
+                                              bool keep_lo, bool lean /* wave-uniform: see lean_ok */)
 {
     const uint32_t r = (cls >> kClsRotShift) & 3u;
     const bool flag_lo = (cls & kClsFlagLo) != 0;
-    // rotate (a, b, c) left by r with two conditional cyclic shifts (18 selects instead of 54)
-    const bool s1 = r >= 1u, s2 = r == 2u;
-    const V3 P1 = s1 ? cur.b : cur.a, Q1 = s1 ? cur.c : cur.b, R1 = s1 ? cur.a : cur.c;
-    const V3 P = s2 ? Q1 : P1, Q = s2 ? R1 : Q1, R = s2 ? P1 : R1;
+    // rotate (a, b, c) left by r with two conditional cyclic shifts (18 selects instead of 54); every select names its lane
+    // mask (vsel: o2v_dev_arith.hpp)
+    const unsigned long long s1 = lane_mask(r >= 1u), s2 = lane_mask(r == 2u);
+    const V3 P1 = vsel(s1, cur.b, cur.a), Q1 = vsel(s1, cur.c, cur.b), R1 = vsel(s1, cur.a, cur.c);
+    const V3 P = vsel(s2, Q1, P1), Q = vsel(s2, R1, Q1), R = vsel(s2, P1, R1);
     V2 tP{}, tQ{}, tR{};
     if (UV) {
-        const V2 tP1 = s1 ? cur.tb : cur.ta, tQ1 = s1 ? cur.tc : cur.tb, tR1 = s1 ? cur.ta : cur.tc;
-        tP = s2 ? tQ1 : tP1;
-        tQ = s2 ? tR1 : tQ1;
-        tR = s2 ? tP1 : tR1;
+        const V2 tP1 = vsel(s1, cur.tb, cur.ta), tQ1 = vsel(s1, cur.tc, cur.tb), tR1 = vsel(s1, cur.ta, cur.tc);
+        tP = vsel(s2, tQ1, tP1);
+        tQ = vsel(s2, tR1, tQ1);
+        tR = vsel(s2, tP1, tR1);
     }
     const float cP = comp(P, axis), cQ = comp(Q, axis), cR = comp(R, axis);
     const bool regular = (cls & kClsModeMask) == 2u;
+    const unsigned long long m_reg = lane_mask(regular);
     // first intersection: regular case P->Q (voxelization.cpp:305-311), one-planar case Q->R (:262-266)
-    const V3 A0 = regular ? P : Q, A1 = regular ? Q : R;
-    const float cA0 = regular ? cP : cQ, cA1 = regular ? cQ : cR;
+    const V3 A0 = vsel(m_reg, P, Q), A1 = vsel(m_reg, Q, R);
+    const float cA0 = vsel(m_reg, cP, cQ), cA1 = vsel(m_reg, cQ, cR);
     const float d0 = -(cA1 - cA0);
-    const float i0 = abs_f(d0) < kEpsilon ? 0.f : (cA0 - plane) / d0;
+    const float i0 = abs_f(d0) < kEpsilon ? 0.f : (lean ? div_lean(cA0 - plane, d0) : (cA0 - plane) / d0);
     const V3 G0 = mix(A0, A1, i0);
     V2 x0{};
-    if (UV) x0 = mix(regular ? tP : tQ, regular ? tQ : tR, i0);
-    if (!regular) {
-        // splitTriangle_onePlanarCase: {P,Q,G} goes to Q's side, {P,G,R} to the other
-        if (flag_lo == keep_lo) {
-            cur.a = P; cur.b = Q; cur.c = G0;
-            if (UV) { cur.ta = tP; cur.tb = tQ; cur.tc = x0; }
-        }
-        else {
-            cur.a = P; cur.b = G0; cur.c = R;
-            if (UV) { cur.ta = tP; cur.tb = x0; cur.tc = tR; }
-        }
-        return 1;
-    }
-    // splitTriangle_regularCase, voxelization.cpp:279-331: P isolated, second intersection P->R
-    const float d1 = -(cR - cP);
-    const float i1 = abs_f(d1) < kEpsilon ? 0.f : (cP - plane) / d1;
-    const V3 G1 = mix(P, R, i1);
+    if (UV) x0 = mix(vsel(m_reg, tP, tQ), vsel(m_reg, tQ, tR), i0);
+    // second intersection, regular case only: P isolated, P->R (splitTriangle_regularCase, voxelization.cpp:279-331)
+    V3 G1{};
     V2 x1{};
-    if (UV) x1 = mix(tP, tR, i1);
-    if (flag_lo == keep_lo) {
-        cur.a = P; cur.b = G0; cur.c = G1;
-        if (UV) { cur.ta = tP; cur.tb = x0; cur.tc = x1; }
-        return 1;
+    if (regular) {
+        const float d1 = -(cR - cP);
+        const float i1 = abs_f(d1) < kEpsilon ? 0.f : (lean ? div_lean(cP - plane, d1) : (cP - plane) / d1);
+        G1 = mix(P, R, i1);
+        if (UV) x1 = mix(tP, tR, i1);
     }
-    cur.a = G0; cur.b = Q; cur.c = R;
-    sec.a = G0; sec.b = G1; sec.c = R;
+    // The kept pieces, in emission order:
+    //   one-planar (splitTriangle_onePlanarCase): {P, Q, G0} is on Q's side, {P, G0, R} on the other - the one on the kept
+    //     side stays;
+    //   regular, the isolated vertex is kept: {P, G0, G1};
+    //   regular, the other side is kept: the quad as {G0, Q, R} and {G0, G1, R}.
+    const bool same = flag_lo == keep_lo;
+    const bool quad = regular && !same;
+    const unsigned long long m_quad = lane_mask(quad);                      // a = G0, else P
+    const unsigned long long m_bq = lane_mask(quad || (!regular && same));  // b = Q, else G0
+    const unsigned long long m_cr = lane_mask(!same);                       // c = R, else (regular ? G1 : G0)
+    cur.a = vsel(m_quad, G0, P);
+    cur.b = vsel(m_bq, Q, G0);
+    cur.c = vsel(m_cr, R, vsel(m_reg, G1, G0));
+    sec.a = G0;
+    sec.b = G1;
+    sec.c = R;
     if (UV) {
-        cur.ta = x0; cur.tb = tQ; cur.tc = tR;
-        sec.ta = x0; sec.tb = x1; sec.tc = tR;
+        cur.ta = vsel(m_quad, x0, tP);
+        cur.tb = vsel(m_bq, tQ, x0);
+        cur.tc = vsel(m_cr, tR, vsel(m_reg, x1, x0));
+        sec.ta = x0;
+        sec.tb = x1;
+        sec.tc = tR;
     }
-    return 2;
+    return quad ? 2u : 1u;
 }
 
+// The lean divisions (o2v_dev_arith.hpp) are used for a voxel job whose operands are known to lie in the middle of float32's
+// range.  The cut parameter (n, d) = (c - plane, -(c' - c)): the leaf is `small` (finite coordinates below 2^17), n belongs to
+// a vertex that is not planar (|n| >= 2^-16, classify_index) and |d| >= 2^-16 by the branch around the division, so both
+// lie in [2^-16, 2^18].  The uv mean, (w u + area uc) / (w + area): the leaf's area is within [2^-30, 2^30] and its uv
+// coordinates are at most 2^20 in magnitude (kLeanArea*, kLeanUv: checked once per staged leaf), so the divisor lies in
+// [2^-30, 2^37] (w is a small multiple of area) and the quotient - a mean of uv coordinates - is at most ~2^20.  A numerator
+// that cancels to almost nothing (not +0, which is exact) could leave the box at its lower end: it shows as a quotient below
+// kLeanMinQuotient = 2^-50, and such a lane repeats the division the long way; any other numerator is at least 2^-81.
+constexpr float kLeanAreaMin = 9.313225746154785e-10f, kLeanAreaMax = 1073741824.0f;  // 2^-30, 2^30
+constexpr float kLeanUv = 1048576.0f;                                                   // 2^20
+constexpr float kLeanMinQuotient = 8.881784197001252e-16f;                              // 2^-50
+
 template <bool UV>
-__device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area, float &w, float &u, float &v)
+__device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area, float &w, float &u, float &v, bool lean /* wave-uniform */)
 {
     // result = mix(result, {area(inputTriangle), piece.textureCenter()}), voxelization.cpp:414-420, util.hpp:160-165
     const float ws = w + area;
     if (UV) {
-        const float uc = ((pc.ta.x + pc.tb.x) + pc.tc.x) / 3;
-        const float vc = ((pc.ta.y + pc.tb.y) + pc.tc.y) / 3;
-        u = (w * u + area * uc) / ws;
-        v = (w * v + area * vc) / ws;
+        const float uc = third((pc.ta.x + pc.tb.x) + pc.tc.x);
+        const float vc = third((pc.ta.y + pc.tb.y) + pc.tc.y);
+        const float nu = w * u + area * uc, nv = w * v + area * vc;
+        if (lean) {
+            const LeanRecip rc(ws);
+            float qu = rc.divide(nu), qv = rc.divide(nv);
+            const bool redo = (abs_f(qu) < kLeanMinQuotient && __float_as_uint(nu) != 0u) || (abs_f(qv) < kLeanMinQuotient && __float_as_uint(nv) != 0u);
+            if (redo) {
+                qu = nu / ws;
+                qv = nv / ws;
+            }
+            u = qu;
+            v = qv;
+        }
+        else {
+            u = nu / ws;
+            v = nv / ws;
+        }
     }
     w = ws;
 }
@@ -167,14 +199,15 @@ struct PieceStack {
 template <bool UV>
 __device__ __forceinline__ Piece<UV> sel_piece(bool take_x, const Piece<UV> &x, const Piece<UV> &y)
 {
+    const unsigned long long m = lane_mask(take_x);
     Piece<UV> r;
-    r.a = {take_x ? x.a.x : y.a.x, take_x ? x.a.y : y.a.y, take_x ? x.a.z : y.a.z};
-    r.b = {take_x ? x.b.x : y.b.x, take_x ? x.b.y : y.b.y, take_x ? x.b.z : y.b.z};
-    r.c = {take_x ? x.c.x : y.c.x, take_x ? x.c.y : y.c.y, take_x ? x.c.z : y.c.z};
+    r.a = vsel(m, x.a, y.a);
+    r.b = vsel(m, x.b, y.b);
+    r.c = vsel(m, x.c, y.c);
     if (UV) {
-        r.ta = {take_x ? x.ta.x : y.ta.x, take_x ? x.ta.y : y.ta.y};
-        r.tb = {take_x ? x.tb.x : y.tb.x, take_x ? x.tb.y : y.tb.y};
-        r.tc = {take_x ? x.tc.x : y.tc.x, take_x ? x.tc.y : y.tc.y};
+        r.ta = vsel(m, x.ta, y.ta);
+        r.tb = vsel(m, x.tb, y.tb);
+        r.tc = vsel(m, x.tc, y.tc);
     }
     return r;
 }
@@ -615,7 +648,20 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             float m;
             // (exact mode, O2V_HIP_FLAG_EXACT_CLIP: no leaf is `small`, so neither row_span nor the piece masks are used)
             const bool is_small = leaf_is_small(lf, m) && !p.exact_clip;
-            s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u);
+            // bit 30: the job's divisions may take the lean forms (accumulate_piece); without uv only the cut parameter is
+            // divided, for which `small` is all that is needed
+            bool lean_ok = is_small;
+            if (UV) {
+                const float a = __uint_as_float(lf[23]);
+                float uvmax = 0.f;
+#pragma unroll
+                for (int i = 12; i < 18; ++i) uvmax = fmaxf(uvmax, abs_f(__uint_as_float(lf[i])));
+                float uvsum = 0.f;
+#pragma unroll
+                for (int i = 12; i < 18; ++i) uvsum += __uint_as_float(lf[i]);  // NaN if any uv is NaN (fmaxf ignores NaN operands)
+                lean_ok = lean_ok && a >= kLeanAreaMin && a <= kLeanAreaMax && uvmax <= kLeanUv && uvsum == uvsum;
+            }
+            s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u) | (lean_ok ? 0x40000000u : 0u);
             s_margin[threadIdx.x] = out_margin(m);
             s_satm[threadIdx.x] = sat_margin(m);
             if (!UV && occ_only) {
@@ -722,7 +768,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         ly = row - lz * dy;
                     }
                     // the part of the row that belongs to this tile
-                    const uint32_t start = s_tstart[k], count = s_tcount[k] & 0x7fffffffu;
+                    const uint32_t start = s_tstart[k], count = s_tcount[k] & 0x3fffffffu;
                     const uint32_t xlo = i_row == 0u ? start - s_trow0[k] * dx : 0u;
                     const uint32_t xhi = i_row == last_row ? (start + count - 1u) - row * dx : dx - 1u;
                     x_first = xlo;
@@ -846,7 +892,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             leaf.c = v2;
                             uint32_t cf0, out_unused, near_unused;
                             piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused, near_unused);
-                            rec = make_uint2(qx | (qy << 16), qz | (kk << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u));
+                            rec = make_uint2(qx | (qy << 16), qz | (kk << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u) | ((s_tcount[kk] & 0x40000000u) << 1));
                             heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
                         }
                     }
@@ -884,6 +930,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             uint32_t cf = 0;     // planes the current piece does not pass whole (bit = level), see piece_masks
             uint32_t pmask = 0;  // the same for the pending siblings: 6 bits per stack entry
             bool active = false, has_job = false, small = false;
+            bool lean = false;   // this job's divisions may take the lean forms (lean_ok at staging)
             float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
             float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
             float margin = 0.f;                  // out_margin of the job's leaf
@@ -962,15 +1009,15 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
                         p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
                         if (UV && mine < p.cap_hits) {
-                            // moveUvBufferIntoVoxels' colour of this (triangle, voxel) pair (voxelization.cpp:513-526); the
-                            // triangle is unsplit, so (d_u, d_v) already is its whole uv mean in this voxel
-                            float cr, cg, cb;
-                            color_at(p.mat, lf[18], d_u, d_v, cr, cg, cb);
-                            pool[mine] = HitRec{brick, ((uint32_t) cell & (kBrickCells - 1u)) << 24, keyhi, pack_argb(cr, cg, cb), d_w, 0.f, 0.f, kPickRecord};
+                            // the triangle is unsplit, so (d_u, d_v) already is its whole uv mean in this voxel; k_pick looks the
+                            // colour up (moveUvBufferIntoVoxels, voxelization.cpp:513-526) for the cell's winner only
+                            pool[mine] = HitRec{brick, ((uint32_t) cell & (kBrickCells - 1u)) << 24, keyhi, 0u, d_w, d_u, d_v, kPickRecord};
                         }
                     }
                     else if (mine < p.cap_hits) {
                         // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
+                        // (handing the ranks out in k_scatter instead - no wait here - was measured: k_voxelize -2 %, k_scatter
+                        // +13 % on configs[3])
                         const uint32_t rank = atomicAdd(&grid[cell], 1u);
                         if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
                         brick_dirty[brick] = 1;  // benign race: every writer stores the same value
@@ -1032,6 +1079,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         fz = (float) (rec.y & 0xffffu);
                         cf = (rec.y >> 24) & 63u;
                         small = (rec.y >> 30) & 1u;
+                        lean = (rec.y >> 31) != 0u;
                         cur.a = {__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
                         cur.b = {__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
                         cur.c = {__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
@@ -1050,6 +1098,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         take_job();
                     }
                 }
+                // (wave-uniform: one job that needs the compiler's division sends the whole wavefront that way for the iteration)
+                const bool lean_all = __ballot(active && !lean) == 0ull;
                 O2V_EV(1, active);
 #ifdef O2V_INSTRUMENT
                 {
@@ -1064,7 +1114,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                     // triangle on unchanged, so they are skipped.
                     if (cf == 0u) {
                         O2V_EV(2, true);
-                        accumulate_piece<UV>(cur, area, w, u, v);  // inside all remaining planes
+                        accumulate_piece<UV>(cur, area, w, u, v, lean_all);  // inside all remaining planes
                         active = false;
                         if (occ_only) {
                             sp = 0;
@@ -1091,7 +1141,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         }
                         else {
                             O2V_EV(7, true);
-                            const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo);
+                            const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo, lean_all);
                             // What becomes of the kept pieces is decided at once, from their bounding boxes against the
                             // planes still ahead: a piece that passes them all is a final piece (accumulated now), one that
                             // lies beyond one of them (by a margin, see piece_masks) can only be discarded there, taking all
@@ -1132,8 +1182,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             const bool s_push = has_sec && !s_drop && !c_over && !s_acc_now;
                             const bool s_takes_over = c_over && s_live;  // next in depth-first order
                             if (UV) {
-                                if (c_done) accumulate_piece<UV>(cur, area, w, u, v);
-                                if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v);
+                                if (c_done) accumulate_piece<UV>(cur, area, w, u, v, lean_all);
+                                if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v, lean_all);
                             }
                             else {
                                 // w += area once per final piece (util.hpp:160-165 with equal addends: the order is immaterial)

@@ -774,7 +774,12 @@ __global__ __launch_bounds__(kBlock) void k_pick(const HitRec *__restrict__ pool
         if (r.brick == kHoleBrick || r.pad != kPickRecord) continue;
         const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
         const unsigned long long key = ((unsigned long long) __float_as_uint(r.w) << 32) | (0xffffffffu - r.keyhi);
-        if (p.maxgrid[cell] == key) p.maxgrid[cell] = kPickTag | r.keylo;
+        if (p.maxgrid[cell] == key) {
+            // the winner's colour (moveUvBufferIntoVoxels, voxelization.cpp:513-526): looked up here, once per voxel, not per hit
+            float cr, cg, cb;
+            color_at(p.mat, r.keyhi & 0x1fffffffu, r.u, r.v, cr, cg, cb);
+            p.maxgrid[cell] = kPickTag | pack_argb(cr, cg, cb);
+        }
     }
     const uint32_t n2 = c->pad2 < p.cap_vox ? c->pad2 : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n2; i += gridDim.x * kBlock) {

@@ -54,6 +54,7 @@ using namespace o2v;
 namespace {
 
 #include "o2v_dev_common.hpp"
+#include "o2v_dev_arith.hpp"
 #include "o2v_dev_k0_bounds_plan.hpp"
 #include "o2v_dev_k1_expand.hpp"
 #include "o2v_dev_k2_voxelize.hpp"
@@ -1584,6 +1585,44 @@ int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32)
         while ((1u << b) < o.count && b < 31) ++b;
         out32[b]++;
     }
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_debug_check_third(o2v_hip_ctx *ctx, uint64_t *out2)
+{
+    if (!ctx || !out2) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    O2V_CHECK(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    hipError_t e = hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_check_third, dim3((uint32_t) ctx->num_cus * 8u), dim3(256), 0, ctx->stream, d);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    unsigned long long got[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(got, d, sizeof(got), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    O2V_CHECK(e);
+    out2[0] = got[0];
+    out2[1] = got[0] ? got[1] : 0;
+    return O2V_HIP_OK;
+}
+
+int o2v_hip_debug_check_div(o2v_hip_ctx *ctx, uint32_t samples, uint64_t seed, uint32_t *out65536)
+{
+    if (!ctx || !out65536 || !samples) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    uint32_t *d = nullptr;
+    O2V_CHECK(hipMalloc(&d, 65536 * sizeof(uint32_t)));
+    hipError_t e = hipMemsetAsync(d, 0, 65536 * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_check_div, dim3(65536), dim3(256), 0, ctx->stream, d, samples, seed);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out65536, d, 65536 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    O2V_CHECK(e);
     return O2V_HIP_OK;
 }
 

@@ -67,6 +67,8 @@ def _bind():
     L.o2v_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.o2v_hip_get_transform.argtypes = [C.c_void_p, C.c_void_p]
     L.o2v_hip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+    L.o2v_hip_debug_check_third.argtypes = [C.c_void_p, C.c_void_p]
+    L.o2v_hip_debug_check_div.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
     L.o2v_hip_comm_unique_id.argtypes = [C.c_void_p]
     L.o2v_hip_comm_create_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.o2v_hip_comm_create_callbacks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -273,6 +275,18 @@ class DeviceVoxelizer:
         out = np.zeros(16, dtype=np.uint64)
         self._L.o2v_hip_debug_counters(self._ctx, _ptr(out))
         return out
+
+    def check_third(self):
+        """(differing inputs, first of them or None) of x / 3 against the clip loop's short form, all 2^32 float32 patterns."""
+        out = np.zeros(2, dtype=np.uint64)
+        self._check(self._L.o2v_hip_debug_check_third(self._ctx, _ptr(out)), "o2v_hip_debug_check_third")
+        return int(out[0]), (int(out[1]) - 1 if out[0] else None)
+
+    def check_div(self, samples=1024, seed=1):
+        """256 x 256 table [numerator's biased exponent, divisor's]: pairs out of `samples` whose lean quotient differs from n / d."""
+        out = np.zeros(65536, dtype=np.uint32)
+        self._check(self._L.o2v_hip_debug_check_div(self._ctx, samples, seed, _ptr(out)), "o2v_hip_debug_check_div")
+        return out.reshape(256, 256)
 
     def transform(self):
         out = np.zeros(12, dtype=np.float32)

@@ -4,7 +4,8 @@ The clip loop prefetches every lane's next job record with LDS-DMA (global_load_
 slot, no destination register) and waits for it explicitly right before the slot is read (o2v_dev_k2_voxelize.hpp: take_job /
 job_record).  hipcc's own s_waitcnt placement for LDS-DMA was seen to guard the wrong LDS reads across the loop's back edge,
 hence the explicit wait; this test pins the shape of the compiled code: the DMA loads are there, the only inline asm of the
-kernel is that wait, and the reads of the slot follow it in the same basic block."""
+kernel besides the selects with a pinned encoding (vsel, o2v_dev_arith.hpp) is that wait, and the reads of the slot follow it
+in the same basic block.  A second test pins what vsel is for: no long runs of two-operand v_cndmask in the clip loop."""
 import os
 import re
 import shutil
@@ -37,11 +38,26 @@ def test_job_prefetch_is_lds_dma_with_an_explicit_wait(device_asm, variant):
     assert len(dma) == 4, dma          # two dwords per record; issued before the loop and in the refill
     # no load of the record into registers by hand (the scheme this replaces), no other inline asm in the kernel
     blocks = [i for i, l in enumerate(body) if "#ASMSTART" in l]
-    assert len(blocks) == 1, blocks
-    i = blocks[0]
+    other = [i for i in blocks if not body[i + 1].startswith("v_cndmask_b32_e64")]
+    assert len(other) == 1, [body[i + 1] for i in other]
+    i = other[0]
     assert body[i + 1] == "s_waitcnt vmcnt(0)" and "#ASMEND" in body[i + 2]
     # the slot reads come after the wait, before control flow leaves the block
     rest = body[i + 3:i + 40]
     stop = next((k for k, l in enumerate(rest) if l.startswith(("s_cbranch", "s_branch", ".LBB"))), len(rest))
     reads = [l for l in rest[:stop] if l.startswith("ds_read_b32")]
     assert len(reads) >= 2, rest[:stop]
+
+
+@pytest.mark.parametrize("variant", ["Lb0E", "Lb1E"])
+def test_no_runs_of_two_operand_selects(device_asm, variant):
+    """A VOP2 v_cndmask directly after another costs 16+ cycles of its SIMD on gfx950 (profiles/r03/valu_rates.json); the
+    pieces of the clip loop are selected with the three-operand encoding (vsel), so no run of more than two remains."""
+    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_ZN\S*k_voxelizeI" + variant + r"\S*:", l))
+    end = next(i for i in range(start, len(device_asm)) if device_asm[i].startswith(".Lfunc_end"))
+    ops = [l.split()[0] for l in (x.strip() for x in device_asm[start:end]) if l and not l.startswith((";", ".")) and not l.endswith(":")]
+    longest = run = 0
+    for op in ops:
+        run = run + 1 if op == "v_cndmask_b32_e32" else 0
+        longest = max(longest, run)
+    assert longest <= 2, longest

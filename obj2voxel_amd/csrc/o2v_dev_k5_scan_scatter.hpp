@@ -222,6 +222,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
     if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
 }
 
+#ifndef O2V_SCATTER_UNROLL
+#define O2V_SCATTER_UNROLL 2
+#endif
 // ---- K5b: scatter --------------------------------------------------------------------------------------------
 // Streams the hit pool once (coalesced 32-byte records, holes skipped) and places every hit at
 // offset(cell) + rank, so that each cell's hits are contiguous for the resolve kernels.
@@ -236,14 +239,32 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const HitRec *__restrict__ p
     const uint32_t xcd = blockIdx.x % kXcds, local_block = blockIdx.x / kXcds, blocks_per_xcd = gridDim.x / kXcds;
     const uint32_t per = ((n + kXcds - 1) / kXcds + kBlock - 1) / kBlock * kBlock;
     const uint32_t lo = xcd * per, hi = lo + per < n ? lo + per : n;
-    for (uint32_t i = lo + local_block * kBlock + threadIdx.x; i < hi; i += blocks_per_xcd * kBlock) {
-        const HitRec r = pool[i];
-        if (r.brick == kHoleBrick || r.pad == kPickRecord) continue;
-        const uint64_t cell = (uint64_t) r.brick * kBrickCells + (r.local_rank >> 24);
-        const uint32_t pos = grid[cell] + (r.local_rank & (kMaxRank - 1u));
-        if (pos < p.cap_hits) {
-            if (stride == 4u) reinterpret_cast<uint4 *>(sorted)[pos] = make_uint4(r.keyhi, r.keylo, __float_as_uint(r.w), 0u);
-            else reinterpret_cast<SortedRec *>(sorted)[pos] = SortedRec{r.keyhi, r.keylo, r.w, r.u, r.v, 0u};
+    // kScatterUnroll records per lane and round, all loads of a step issued before any is used (the pool record, then the
+    // cell's offset: two dependent round trips per record, which only overlap across records)
+    constexpr uint32_t kScatterUnroll = O2V_SCATTER_UNROLL;
+    for (uint32_t i0 = lo + local_block * kBlock * kScatterUnroll + threadIdx.x; i0 < hi; i0 += blocks_per_xcd * kBlock * kScatterUnroll) {
+        HitRec r[kScatterUnroll];
+        bool live[kScatterUnroll];
+        uint32_t off[kScatterUnroll];
+#pragma unroll
+        for (uint32_t k = 0; k < kScatterUnroll; ++k) {
+            const uint32_t i = i0 + k * kBlock;
+            live[k] = i < hi;
+            r[k] = pool[live[k] ? i : lo];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kScatterUnroll; ++k) {
+            live[k] = live[k] && r[k].brick != kHoleBrick && r[k].pad != kPickRecord;
+            const uint64_t cell = (uint64_t) r[k].brick * kBrickCells + (r[k].local_rank >> 24);
+            off[k] = live[k] ? grid[cell] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kScatterUnroll; ++k) {
+            const uint32_t pos = off[k] + (r[k].local_rank & (kMaxRank - 1u));
+            if (live[k] && pos < p.cap_hits) {
+                if (stride == 4u) reinterpret_cast<uint4 *>(sorted)[pos] = make_uint4(r[k].keyhi, r[k].keylo, __float_as_uint(r[k].w), 0u);
+                else reinterpret_cast<SortedRec *>(sorted)[pos] = SortedRec{r[k].keyhi, r[k].keylo, r[k].w, r[k].u, r[k].v, 0u};
+            }
         }
     }
 }

@@ -172,19 +172,20 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const Occ &o, cons
 #pragma unroll
     for (uint32_t e = 0; e < net.n; ++e) {
         const uint32_t a = net.a[e], b = net.b[e];
-        const bool sw = key[a] > key[b];
-        const uint64_t ka = key[a], kb = key[b];
-        key[a] = sw ? kb : ka;
-        key[b] = sw ? ka : kb;
+        // (selects with the mask named: a run of two-operand v_cndmask is slow on gfx950, see vsel in o2v_dev_arith.hpp)
+        const unsigned long long sw = lane_mask(key[a] > key[b]);
+        const uint32_t alo = (uint32_t) key[a], ahi = (uint32_t) (key[a] >> 32), blo = (uint32_t) key[b], bhi = (uint32_t) (key[b] >> 32);
+        key[a] = ((uint64_t) vsel(sw, bhi, ahi) << 32) | vsel(sw, blo, alo);
+        key[b] = ((uint64_t) vsel(sw, ahi, bhi) << 32) | vsel(sw, alo, blo);
         const float wa = w[a], wb = w[b];
-        w[a] = sw ? wb : wa;
-        w[b] = sw ? wa : wb;
+        w[a] = vsel(sw, wb, wa);
+        w[b] = vsel(sw, wa, wb);
         if (kUv) {
             const float ua = u[a], ub = u[b], va = v[a], vb = v[b];
-            u[a] = sw ? ub : ua;
-            u[b] = sw ? ua : ub;
-            v[a] = sw ? vb : va;
-            v[b] = sw ? va : vb;
+            u[a] = vsel(sw, ub, ua);
+            u[b] = vsel(sw, ua, ub);
+            v[a] = vsel(sw, vb, va);
+            v[b] = vsel(sw, va, vb);
         }
     }
     // The fold in three steps.  (1) One pass forward reduces every (sub-voxel, triangle) group - the leaves of one triangle

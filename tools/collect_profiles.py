@@ -64,7 +64,7 @@ for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_m
             f, wr = sum(f) / len(f) * 1024, sum(wr) / len(wr) * 1024   # the counters are in KiB
             kernels[k].update({"fetch_size_raw_bytes": round(f), "write_size_bytes": round(wr), "hbm_bytes": round(2 * f + wr)})
     sq = {}
-    for part in ("sq1", "sq2"):
+    for part in ("sq1", "sq2", "sq3"):
         for k, d in counters(find(f"{src}/{w}_{part}/**/p_counter_collection.csv")).items():
             sq.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in d.items()})
     for k, d in sq.items():
@@ -81,8 +81,8 @@ for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_m
                        "launch: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (--kernel-trace only), counters in KiB, "
                        "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half "
                        "the bytes of wide coalesced reads; calibrated in round 1 on k_bounds = 36 B x triangles read and "
-                       "k_reset_bricks = the dirty bricks written); sq: two --pmc passes of 8 SQ counters, averages per launch "
-                       "(SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles).",
+                       "k_reset_bricks = the dirty bricks written); sq: two or three --pmc passes of 8 SQ counters, averages per launch "
+                       "(SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; SQ_CYCLES and SQ_BUSY_CYCLES are summed over the 32 shader engines).",
            "workload": w, "command": "python bench.py --no-cpu-baseline --no-capi --no-routes" if w == "config2" else f"python tools/run_workload.py {w}",
            "result_line": line, "hbm_bytes_per_step_all_kernels": round(step_traffic), "kernels": kernels}
     json.dump(doc, open(os.path.join(out_dir, f"{w}_profile.json"), "w"), indent=1)
@@ -119,7 +119,7 @@ if "config2" in summary:
         cur["workloads"][w] = {"source": f"profiles/{rnd}/{w}_profile.json", "kernels": ks,
                                "workload_stats": (doc.get("result_line") or {}).get("stats")}
     json.dump(cur, open("profiles/current.json", "w"), indent=1)
-for extra in ("predict_scaling_8_weak.jsonl", "predict_scaling_8_config4.jsonl"):
+for extra in ("predict_scaling_8_weak.jsonl", "predict_scaling_8_config4.jsonl", "valu_rates.json"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(out_dir, extra))
 if os.path.exists(os.path.join(src, "bench_line.json")) and os.path.getsize(os.path.join(src, "bench_line.json")):

@@ -11,6 +11,8 @@ OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 SQ1="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"
 SQ2="SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"
+# front end and pipes (instruction fetches, scalar unit cycles, the second VALU pipe, transcendentals, SE cycles)
+SQ3="SQ_IFETCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_TRANS_F32 SQ_INST_LEVEL_VMEM"
 WL="${@:-config2 config2_colored_max config2_blend config2_textured_max config1 config3}"
 for W in $WL; do
   if [ $W = config2 ]; then CMD="python bench.py --no-cpu-baseline --no-capi --no-routes"; S1="--steps 20 --warmup 3"; S2="--steps 3 --warmup 1"
@@ -21,9 +23,14 @@ for W in $WL; do
   done
   timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $OUT/${W}_sq1 -o p -- $CMD $S2 > $OUT/${W}_sq1.log 2>&1
   timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OUT/${W}_sq2 -o p -- $CMD $S2 > $OUT/${W}_sq2.log 2>&1
+  if [ $W = config2 ] || [ $W = config3 ] || [ $W = config2_blend ]; then
+    timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ3 --output-format csv -d $OUT/${W}_sq3 -o p -- $CMD $S2 > $OUT/${W}_sq3.log 2>&1
+  fi
   grep "^{" $OUT/${W}_stats.log | tail -1 > $OUT/${W}_line.json
 done
 python -c "from obj2voxel_amd import hip; print(hip.build_id())" > $OUT/build_id.txt
+# issue costs of the instructions the clip loop is made of (make -C tools/ubench here, before the gpurun call)
+[ -x tools/ubench/_build/valu_rates ] && timeout -k 5 60 tools/ubench/_build/valu_rates > $OUT/valu_rates.json 2>/dev/null
 # the summaries are made here, so that the bench line below reads the counters of THIS build (profiles/current.json), and
 # travel back under gpurun_out/ (copy gpurun_out/prof/profiles/* into profiles/ afterwards)
 ROUND=${O2V_ROUND:-r03}

@@ -2,7 +2,7 @@
 // Every kernel runs a loop of 64 copies of one instruction (dependent: each reads the previous result; independent: eight
 // rotating destinations) on W wavefronts per SIMD; reported is SIMD cycles per instruction = time x clock / (instructions of
 // one wavefront x W), i.e. 1 / throughput per SIMD, at an assumed 2.4 GHz.
-//   hipcc --offload-arch=gfx950 -O2 tools/ubench/valu_rates.hip -o gpurun_out/valu_rates && gpurun_out/valu_rates
+//   make -C tools/ubench && tools/ubench/_build/valu_rates        (inline asm clobbers scc: the loop counter lives in SGPRs)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -187,7 +187,8 @@ int main()
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            fprintf(stderr, "%s w%d first %.3f s second %.3f s kernel %.3f ms\n", c.name, w, t1 - t0, now() - t1, ms);
+            (void) t0;
+            (void) t1;
             const double cyc = ms * 1e-3 * ghz * 1e9 / ((double) iters * c.per_rep * w);
             printf("%s\"w%d\": %.2f", f2 ? "" : ", ", w, cyc);
             f2 = false;

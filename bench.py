@@ -39,7 +39,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0     # wave64 VALU instructions / ns: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G/s
+CLOCK_GHZ = 2.4                            # nominal (the SE cycle counters read 2.1 - 2.15 GHz under the clip kernel)
+N_SIMDS = 256 * 4
+VALU_PEAK_GINSTR = N_SIMDS * CLOCK_GHZ / 2.0   # wave64 VALU instructions / ns: 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G/s
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "current.json")   # rocprofv3 PMC summary of this command (tools/collect_profiles.py)
 
 
@@ -439,6 +441,10 @@ def report(args, n, run, dv, comm):
                     "unit": "G wave64-instr/s", "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
                     "active_lane_fraction": round(sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_INSTS_VALU"] / 64.0, 3) if sq.get("SQ_THREAD_CYCLES_VALU") else None,
                     "valu_instructions_per_launch": int(sq["SQ_INSTS_VALU"]), "traffic": dom["traffic_bytes"], "kernel_ms": dom["ms"],
+                    # SIMD cycles per VALU instruction at the nominal clock.  The peak above is the rate of the cheapest class
+                    # (v_mul / v_add / v_mov: 2 cycles); compares, selects, fma, min / max cost 4 (profiles/r03/valu_rates.json),
+                    # so a figure near 4 means the VALU pipes are full for the instructions this kernel is made of.
+                    "simd_cycles_per_valu_instruction": round(dom["ms"] * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMDS / sq["SQ_INSTS_VALU"], 2),
                     "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU: " + (prof or {}).get("source", "profiles/current.json")}
         if stale:
             # the summary was recorded with a library built from other device sources (o2v_hip_build_id differs): the count is

@@ -195,6 +195,11 @@ int o2v_hip_get_transform(const o2v_hip_ctx *ctx, float out12[12]);
 int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t *out, uint32_t max_records,
                             uint32_t *out_count);
 
+/* Debugging aid for parity work: every hit record of the last run, 8 words each (cell x, y, z, keyhi, keylo, bits of w, u, v):
+ * what the clip kernel computed per (leaf, voxel) pair, before any fold.  *n_hits receives the number of hits; records are
+ * written only if max_hits >= *n_hits (call with max_hits = 0 first).  Same restriction as o2v_hip_debug_cell_hits. */
+int o2v_hip_debug_hits(o2v_hip_ctx *ctx, uint32_t *out8, uint64_t max_hits, uint64_t *n_hits);
+
 /* Debugging aid: log2 histogram of hits per occupied cell of the last run (32 buckets; bucket b: 2^(b-1) < hits <= 2^b). */
 int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32);
 

@@ -1566,6 +1566,50 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
     return O2V_HIP_OK;
 }
 
+// Debugging aid for parity work: every hit record of the last run (general route), 8 words each: the cell's x, y, z, keyhi
+// (sub-voxel << 29 | triangle), keylo (leaf order key), and the bits of w, u, v - what k_voxelize computed per (leaf, voxel)
+// pair, before any fold.  Cells in emission order, a cell's hits in the (arbitrary) order of the sorted array.
+int o2v_hip_debug_hits(o2v_hip_ctx *ctx, uint32_t *out8, uint64_t max_hits, uint64_t *n_hits)
+{
+    if (!ctx || !n_hits || (!out8 && max_hits)) return O2V_HIP_ERR_BAD_ARGUMENT;
+    *n_hits = 0;
+    if (ctx->last_direct) {
+        ctx->err = "hit lists are not kept on the direct MAX path: run with O2V_NO_DIRECT_MAX=1 to inspect them";
+        return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
+    if (!ctx->n_vox) return O2V_HIP_OK;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    std::vector<Occ> occ(ctx->n_vox);
+    std::vector<uint4> vox(ctx->n_vox);
+    O2V_CHECK(hipMemcpy(occ.data(), ctx->d_occ, occ.size() * sizeof(Occ), hipMemcpyDeviceToHost));
+    O2V_CHECK(hipMemcpy(vox.data(), ctx->d_out, vox.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+    uint64_t total = 0, end = 0;
+    for (const Occ &o : occ) {
+        total += o.count;
+        end = std::max<uint64_t>(end, (uint64_t) o.offset + o.count);
+    }
+    *n_hits = total;
+    if (total > max_hits) return O2V_HIP_OK;  // (the caller sizes its buffer from *n_hits and calls again)
+    std::vector<uint32_t> raw((size_t) end * ctx->sorted_stride);
+    if (end) O2V_CHECK(hipMemcpy(raw.data(), ctx->d_sorted, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < ctx->n_vox; ++i) {
+        for (uint32_t h = 0; h < occ[i].count; ++h, ++k) {
+            const uint32_t *r = &raw[((size_t) occ[i].offset + h) * ctx->sorted_stride];
+            uint32_t *o = out8 + k * 8;
+            o[0] = vox[i].x;
+            o[1] = vox[i].y;
+            o[2] = vox[i].z;
+            o[3] = r[0];
+            o[4] = r[1];
+            o[5] = r[2];
+            o[6] = ctx->sorted_stride == 6 ? r[3] : 0u;
+            o[7] = ctx->sorted_stride == 6 ? r[4] : 0u;
+        }
+    }
+    return O2V_HIP_OK;
+}
+
 // Debugging aid: histogram of hits per occupied cell of the last run; bucket b counts cells with 2^(b-1) < hits <= 2^b
 // (bucket 0: exactly one hit), 32 buckets.
 int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32)

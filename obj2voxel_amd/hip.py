@@ -67,6 +67,7 @@ def _bind():
     L.o2v_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.o2v_hip_get_transform.argtypes = [C.c_void_p, C.c_void_p]
     L.o2v_hip_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+    L.o2v_hip_debug_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.o2v_hip_debug_check_third.argtypes = [C.c_void_p, C.c_void_p]
     L.o2v_hip_debug_check_div.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
     L.o2v_hip_comm_unique_id.argtypes = [C.c_void_p]
@@ -274,6 +275,15 @@ class DeviceVoxelizer:
     def debug_counters(self):
         out = np.zeros(16, dtype=np.uint64)
         self._L.o2v_hip_debug_counters(self._ctx, _ptr(out))
+        return out
+
+    def hits(self):
+        """Every hit record of the last run (general route): uint32 array [n, 8] = cell x, y, z, keyhi, keylo, bits of w, u, v."""
+        n = C.c_uint64(0)
+        self._check(self._L.o2v_hip_debug_hits(self._ctx, None, 0, C.byref(n)), "o2v_hip_debug_hits")
+        out = np.zeros((n.value, 8), dtype=np.uint32)
+        if n.value:
+            self._check(self._L.o2v_hip_debug_hits(self._ctx, _ptr(out), n.value, C.byref(n)), "o2v_hip_debug_hits")
         return out
 
     def check_third(self):

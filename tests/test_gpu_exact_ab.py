@@ -111,3 +111,45 @@ def test_exact_flag_via_environment(monkeypatch):
     finally:
         d.close()
     assert np.array_equal(fast, exact) and np.array_equal(fast, flagged)
+
+
+def _sorted_hits(h):
+    order = np.lexsort((h[:, 4], h[:, 3], h[:, 2], h[:, 1], h[:, 0]))
+    return h[order]
+
+
+@pytest.mark.parametrize("uv_scale", [2.0 ** -60, 2.0 ** -22, 1.0, 2.0 ** 19, 2.0 ** 21], ids=["uv2^-60", "uv2^-22", "uv1", "uv2^19", "uv2^21"])
+def test_hit_records_equal_in_exact_mode(uv_scale):
+    """Not only the voxels: every (leaf, voxel) hit's weight and uv mean, bit for bit.  The clip loop's shortened divisions
+    (third(), the lean forms of o2v_dev_arith.hpp) and its work-removal rules are all off in exact mode, so the two runs'
+    hit records - cell, triangle, leaf order key, w, u, v - must be the same multiset.  The uv scales put the running uv mean
+    on both sides of the lean forms' limits (|uv| <= 2^20 for the lean path at all; quotients below 2^-50 repeat the division
+    the long way), the tiny triangles near the origin have areas below 2^-30 (no lean path either)."""
+    from obj2voxel_amd import hip
+    S, T = 512, 160_000
+    v = meshes.stress_soup("mixed", T, S, seed=23)
+    rng = np.random.default_rng(77)
+    # 2 000 triangles of ~1e-4 x 1e-7 voxels inside the first voxels (areas ~1e-12 .. 1e-11 < 2^-30)
+    tiny_c = rng.random((2000, 1, 3)) * 3.0 + 0.2
+    tiny = (tiny_c + np.concatenate([np.zeros((2000, 1, 3)), rng.random((2000, 1, 3)) * 1e-4, rng.random((2000, 1, 3)) * 1e-7 + 1e-8], axis=1)).astype(np.float32)
+    v = np.concatenate([v.reshape(-1, 9), tiny.reshape(-1, 9)])
+    n = len(v)
+    types = rng.integers(1, 4, size=n).astype(np.uint32)
+    uvs = ((rng.random((n, 6)) * 2.5 - 0.7) * uv_scale).astype(np.float32)
+    uvs[rng.random(n) < 0.05] = 0.0          # +0 numerators
+    mat = dict(types=types, colors=rng.random((n, 3)).astype(np.float32), uvs=uvs, texids=rng.integers(0, 2, size=n).astype(np.int32))
+    textures = [(rng.integers(0, 256, size=(37, 53, 3)).astype(np.uint8), 1), (rng.integers(0, 256, size=(16, 8, 4)).astype(np.uint8), 0)]
+    kw = dict(strategy=1, bounds=meshes.stress_bounds(S))
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_textures(textures)
+        d.set_triangles(v, **mat)
+        n_fast = d.voxelize(S, read=False, **kw)
+        fast = _sorted_hits(d.hits())
+        n_exact = d.voxelize(S, read=False, exact_clip=True, **kw)
+        exact = _sorted_hits(d.hits())
+    finally:
+        d.close()
+    assert n_fast == n_exact and len(fast) == len(exact) > 1_000_000, (n_fast, n_exact, len(fast), len(exact))
+    same = (fast == exact).all(axis=1)
+    assert same.all(), (int((~same).sum()), fast[~same][:3], exact[~same][:3])

@@ -153,3 +153,28 @@ def test_hit_records_equal_in_exact_mode(uv_scale):
     assert n_fast == n_exact and len(fast) == len(exact) > 1_000_000, (n_fast, n_exact, len(fast), len(exact))
     same = (fast == exact).all(axis=1)
     assert same.all(), (int((~same).sum()), fast[~same][:3], exact[~same][:3])
+
+
+@pytest.mark.parametrize("kind,ss", [("mixed", 1), ("planar", 2)], ids=["mixed", "planar_ss2"])
+def test_hit_weights_equal_in_exact_mode_untextured(kind, ss):
+    """The same for k_voxelize<false>, whose fast mode settles pieces with one plane left from their classification alone
+    (single_plane: the number of final pieces, hence the weight, without cutting): every hit's weight, bit for bit."""
+    from obj2voxel_amd import hip
+    res = 512
+    S = res * ss
+    v = meshes.stress_soup(kind, 200_000, S, seed=31)
+    rng = np.random.default_rng(78)
+    mat = dict(types=np.full(len(v), 2, np.uint32), colors=rng.random((len(v), 3)).astype(np.float32))
+    kw = dict(strategy=1, supersampling=ss, bounds=meshes.stress_bounds(S))
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_triangles(v, **mat)
+        d.voxelize(res, read=False, **kw)
+        fast = _sorted_hits(d.hits())
+        d.voxelize(res, read=False, exact_clip=True, **kw)
+        exact = _sorted_hits(d.hits())
+    finally:
+        d.close()
+    assert len(fast) == len(exact) > 1_000_000, (len(fast), len(exact))
+    same = (fast == exact).all(axis=1)
+    assert same.all(), (int((~same).sum()), fast[~same][:3], exact[~same][:3])

@@ -179,24 +179,29 @@ def main():
         for _ in range(warmup):
             step()
         names = ("bounds_ms", "expand_ms", "voxelize_ms", "scan_ms", "resolve_ms", "total_ms", "plan_ms", "collective_ms")
-        acc = {k: 0.0 for k in names}
-        parts = [0.0] * 5
         barrier()
         t0 = time.perf_counter()
         count = 0
-        for _ in range(steps):
+        for _ in range(steps):   # the timed region: the steps and nothing else
             count, counts = step()
-            tm = dv.timings()
-            for k in names:
-                acc[k] += tm[k]
-            parts = [a + b for a, b in zip(parts, tm["collective_parts_ms"])]
         barrier()
         elapsed = time.perf_counter() - t0
         total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed,
                                                       device="cuda" if (dist is not None and args.backend == "nccl") else None)
+        # per-stage device times (hipEvent pairs the library records in every step) and, for N > 1, the collectives' shares:
+        # read in a few further steps outside the timed region (reading them is a library call and a dictionary per step)
+        stage_steps = min(5, max(steps, 1))
+        acc = {k: 0.0 for k in names}
+        parts = [0.0] * 5
+        for _ in range(stage_steps):
+            step()
+            tm = dv.timings()
+            for k in names:
+                acc[k] += tm[k]
+            parts = [a + b for a, b in zip(parts, tm["collective_parts_ms"])]
         run = {"name": name, "res": res, "nv": nv, "T": len(verts), "verts": verts, "voxels": total_voxels, "text": text, "kw": kw,
-               "collective_parts_ms": [x / steps for x in parts],
-               "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / steps for k in names}, "stats": dv.stats()}
+               "collective_parts_ms": [x / stage_steps for x in parts],
+               "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / stage_steps for k in names}, "stats": dv.stats()}
         if n == 1:
             # per-kernel times: two further steps with an event pair around every launch (outside the timed region: the
             # brackets cost a few microseconds per launch)

@@ -126,7 +126,7 @@ def test_hit_records_equal_in_exact_mode(uv_scale):
     on both sides of the lean forms' limits (|uv| <= 2^20 for the lean path at all; quotients below 2^-50 repeat the division
     the long way), the tiny triangles near the origin have areas below 2^-30 (no lean path either)."""
     from obj2voxel_amd import hip
-    S, T = 512, 160_000
+    S, T = 512, 100_000
     v = meshes.stress_soup("mixed", T, S, seed=23)
     rng = np.random.default_rng(77)
     # 2 000 triangles of ~1e-4 x 1e-7 voxels inside the first voxels (areas ~1e-12 .. 1e-11 < 2^-30)
@@ -150,7 +150,7 @@ def test_hit_records_equal_in_exact_mode(uv_scale):
         exact = _sorted_hits(d.hits())
     finally:
         d.close()
-    assert n_fast == n_exact and len(fast) == len(exact) > 1_000_000, (n_fast, n_exact, len(fast), len(exact))
+    assert n_fast == n_exact and len(fast) == len(exact) > 600_000, (n_fast, n_exact, len(fast), len(exact))
     same = (fast == exact).all(axis=1)
     assert same.all(), (int((~same).sum()), fast[~same][:3], exact[~same][:3])
 

@@ -60,7 +60,7 @@ static int g_threads = 1;
 static double g_phase_seconds[3] = {0, 0, 0};
 /* Chunk-parallel execution like the reference's worker pool (one VOXELIZE_CHUNK command per chunk,
  * obj2voxel.cpp:415-424,979): results do not depend on the thread count because chunks are independent. */
-void o2v_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void o2v_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 1024 ? 1024 : n); }
 
 /* optional trace of one sample-space voxel (debugging aid for parity work) */
 static int g_trace_on = 0;
@@ -555,7 +555,11 @@ static void voxelizer_voxelize(voxelizer *vz, const cached_tri *tri, const uint3
 {
     const float input_area = tri_area(&tri->geo); /* voxelization.cpp:416 evaluates this per piece; same value */
     g_trace_leaf = 0;
-    vz->serial++;
+    if (++vz->serial == 0u) {
+        /* (a voxelizer lives as long as its thread's slot in the harness: after 2^32 triangles the stamps start over) */
+        memset(vz->uv_stamp, 0, sizeof(uint32_t) * CHUNK_CELLS);
+        vz->serial = 1u;
+    }
     vz->uv_count = 0;
 
     if (roughly_axis_aligned(&tri->geo)) {
@@ -681,6 +685,14 @@ static void voxelize_chunk(voxelizer *vz, outvec *ov, const cached_tri *tris, co
     }
     for (uint32_t k = 0; k < vz->voxel_count; ++k) vz->has_voxel[vz->voxel_list[k]] = 0;
 }
+
+/* Per-thread state of the harness, kept between calls like the reference's worker threads keep theirs between chunks
+ * (obj2voxel.cpp:415-424): the voxelizer (10 MB of chunk-sized arrays) and the thread's output list.  Allocating and
+ * releasing them in every call was most of a many-threaded call's time (256 threads: 2.6 GB of fresh pages per call, the page
+ * faults and unmaps contending in the kernel; the chunk loop took 0.65 s where the single-threaded one takes 2.8 s). */
+#define O2V_MAX_THREADS 1024
+static voxelizer *g_vz_cache[O2V_MAX_THREADS];
+static outvec g_out_cache[O2V_MAX_THREADS];
 
 /*
  * The whole path: cache -> bounds -> transform -> chunk binning -> per chunk voxelize (+downscale) -> pack.
@@ -858,8 +870,11 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
             double t_merge = 0.0;
 #pragma omp parallel num_threads(g_threads)
             {
-                voxelizer *vz = voxelizer_new();
-                outvec lov = {0, 0, 0};
+                const int tid = omp_get_thread_num();
+                if (!g_vz_cache[tid]) g_vz_cache[tid] = voxelizer_new();
+                voxelizer *vz = g_vz_cache[tid];
+                outvec lov = g_out_cache[tid];
+                lov.n = 0;
                 memset(&t_stats, 0, sizeof(t_stats));
 #pragma omp for schedule(dynamic, 1)
                 for (long wi = 0; wi < (long) n_work; ++wi) {
@@ -871,14 +886,14 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                 }
                 /* every thread keeps its own output; the lists are joined below by parallel copies (the sink of the
                  * reference takes each chunk's voxels under a mutex, obj2voxel.cpp:298-303: the order is unspecified) */
-                per_thread[omp_get_thread_num()] = lov;
+                per_thread[tid] = lov;
+                g_out_cache[tid] = lov;
 #pragma omp critical
                 {
                     uint64_t *dst = (uint64_t *) &g_stats;
                     const uint64_t *src = (const uint64_t *) &t_stats;
                     for (size_t k = 0; k < sizeof(g_stats) / sizeof(uint64_t); ++k) dst[k] += src[k];
                 }
-                voxelizer_free(vz);
 #pragma omp barrier
 #pragma omp single
                 {
@@ -897,8 +912,6 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                         if (per_thread[k].n) memcpy(ov.d + before * 4, per_thread[k].d, sizeof(uint32_t) * 4 * per_thread[k].n);
                     }
                 }
-#pragma omp barrier
-                free(lov.d);
             }
             g_phase_seconds[1] = t_merge - t_vox;
             g_phase_seconds[2] = omp_get_wtime() - t_merge;
@@ -914,6 +927,18 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
 }
 
 void o2v_oracle_free(uint32_t *p) { free(p); }
+
+/* releases the per-thread state the harness keeps between calls */
+void o2v_oracle_release(void)
+{
+    for (int k = 0; k < O2V_MAX_THREADS; ++k) {
+        if (g_vz_cache[k]) voxelizer_free(g_vz_cache[k]);
+        g_vz_cache[k] = NULL;
+        free(g_out_cache[k].d);
+        g_out_cache[k].d = NULL;
+        g_out_cache[k].n = g_out_cache[k].cap = 0;
+    }
+}
 
 /* wall seconds of the last o2v_oracle_voxelize call: [0] copy + bounds + transform + chunk binning, [1] the chunk loop
  * (the reference's algorithm), [2] joining the threads' output lists */

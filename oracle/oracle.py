@@ -94,6 +94,11 @@ def set_threads(n):
     lib().o2v_oracle_set_threads(int(n))
 
 
+def release():
+    """Frees the per-thread state (voxelizers, output lists) the harness keeps between calls."""
+    lib().o2v_oracle_release()
+
+
 def phase_seconds():
     """Wall seconds of the last voxelize(): (prelude: copy + bounds + transform + chunk binning, the chunk loop = the
     reference's algorithm, joining the threads' output lists)."""

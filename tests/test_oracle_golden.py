@@ -75,3 +75,32 @@ def test_baseline_config1_spot_64_max_cpu_path(oracle):
         oracle.set_threads(1)
     assert np.array_equal(one, four)
     assert len(np.unique(one[:, :3], axis=0)) == len(one) > 15000
+
+
+def test_per_thread_state_survives_between_calls(oracle):
+    """The harness keeps every thread's voxelizer and output list between calls (oracle/o2v_oracle.c: g_vz_cache): other
+    meshes, strategies, supersampling and thread counts in between must not change a result, nor must releasing the state."""
+    from obj2voxel_amd import meshes
+    import numpy as np
+    a = meshes.uv_sphere(24)
+    b, buv = meshes.uv_sphere(9, with_uv=True)
+    tex = [(meshes.checker_texture(32, 4), 1)]
+    bkw = dict(uvs=buv, types=np.full(len(b), 3, np.uint32), texids=np.zeros(len(b), np.int32), textures=tex)
+
+    def run_a(threads):
+        oracle.set_threads(threads)
+        return meshes.sorted_voxels(oracle.voxelize(a, 96, strategy=1, supersampling=2))
+
+    oracle.release()
+    want = run_a(1)
+    try:
+        oracle.set_threads(5)
+        oracle.voxelize(b, 128, strategy=1, **bkw)              # textured, uv stamps in use
+        assert np.array_equal(run_a(5), want)
+        oracle.set_threads(3)
+        oracle.voxelize(meshes.unit_cube(), 64, strategy=0)     # axis-aligned, MAX
+        assert np.array_equal(run_a(8), want)
+        oracle.release()
+        assert np.array_equal(run_a(2), want)
+    finally:
+        oracle.set_threads(1)

@@ -8,8 +8,6 @@
 #include <cstdint>
 #include <vector>
 #include <string>
-#include <chrono>
-static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
@@ -177,18 +175,14 @@ int main()
         for (int w : {1, 4}) {
             // one workgroup of 4 * w wavefronts per CU: w per SIMD
             const dim3 grid(cus), block(64 * 4 * w);
-            double t0 = now();
             hipLaunchKernelGGL(c.fn, grid, block, 0, 0, out, 10);
             hipDeviceSynchronize();
-            double t1 = now();
             hipEventRecord(e0);
             hipLaunchKernelGGL(c.fn, grid, block, 0, 0, out, iters);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            (void) t0;
-            (void) t1;
             const double cyc = ms * 1e-3 * ghz * 1e9 / ((double) iters * c.per_rep * w);
             printf("%s\"w%d\": %.2f", f2 ? "" : ", ", w, cyc);
             f2 = false;

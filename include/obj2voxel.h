@@ -61,6 +61,10 @@ static const obj2voxel_error_t OBJ2VOXEL_ERR_IO_ERROR_ON_OPEN_INPUT_FILE = 4;
 static const obj2voxel_error_t OBJ2VOXEL_ERR_IO_ERROR_ON_OPEN_OUTPUT_FILE = 5;
 static const obj2voxel_error_t OBJ2VOXEL_ERR_IO_ERROR_DURING_VOXEL_WRITE = 6;
 static const obj2voxel_error_t OBJ2VOXEL_ERR_DOUBLE_VOXELIZATION = 7; /* instances are single-use */
+/* EXTENSION of this build (not in the reference, whose codes end at 7): no usable GPU, a HIP failure, out of device memory,
+ * or a limit of the dense-grid path (sample resolution above 65 535, ...).  The reason is logged at ERROR level.  There is no
+ * CPU voxelization path to fall back to. */
+static const obj2voxel_error_t OBJ2VOXEL_ERR_DEVICE = 8;
 
 /* ---- instance (reference :89-95) ----------------------------------------------------------------------- */
 

@@ -22,7 +22,6 @@
 #include <vector>
 
 // Extension to the reference's error codes: the GPU pipeline could not run (no device, HIP failure, device OOM).
-static const obj2voxel_error_t OBJ2VOXEL_ERR_DEVICE = 8;
 
 using namespace o2v;
 

@@ -30,6 +30,8 @@ void usage()
               "  -i FMT / -o FMT     explicit input (obj|stl) / output (ply|vl32|xyzrgb) format\n"
               "  -t TEXTURE          fallback texture (png) for faces with uv coordinates but no material\n"
               "  -v, --verbose       debug logging\n"
+              "  -V, --version       version and build information\n"
+              "  --80                accepted for compatibility (the reference prints its help 80 columns wide)\n"
               "  -h, --help          this text");
 }
 
@@ -85,6 +87,15 @@ int main(int argc, char **argv)
         else if (a == "-o") out_format = value("-o");
         else if (a == "-t") texture_file = value("-t");
         else if (a == "-v" || a == "--verbose") verbose = true;
+        else if (a == "-V" || a == "--version") {
+            // the reference prints its header, version and compiler builtins (src/main.cpp:320-340); here: which device path
+            std::puts("===== obj2voxel-amd =====");
+            std::puts("Version:  1.3.5-dev (C API of obj2voxel 1.3.5-dev)");
+            std::puts("Device:   HIP, gfx950 (MI355X); no CPU voxelization path");
+            return 0;
+        }
+        else if (a == "--80") {
+        }
         else if (!a.empty() && a[0] == '-') {
             std::fprintf(stderr, "unknown option %s\n", a.c_str());
             usage();

@@ -137,6 +137,9 @@ __device__ __forceinline__ BlockSlots reserve_slots(const Emit &e, Counters *c, 
                                                      (unsigned long long) tot_leaf | ((unsigned long long) tot_tile << 32));
             s_base[0] = (uint32_t) old;
             s_base[1] = (uint32_t) (old >> 32);
+            // (the pair is one 64-bit word: a leaf count that carried out of its 32 bits would corrupt the tile count - the
+            // counters keep counting past their capacities - so the wrap is reported instead of passing for a small count)
+            if ((uint32_t) old + tot_leaf < (uint32_t) old || (uint32_t) (old >> 32) + tot_tile < (uint32_t) (old >> 32)) atomicOr(&c->err_flags, kErrCounterWrap);
         }
         if (tot_leaf && node_round == 0) atomicAdd(&c->n_root_leaves, tot_leaf);
         s_base[2] = tot_big ? atomicAdd(&c->n_big, tot_big) : 0u;

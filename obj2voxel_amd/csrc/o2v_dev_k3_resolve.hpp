@@ -217,14 +217,18 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const Occ &o, cons
         for (uint32_t j = 0; j < 4; ++j)
             mf[j] = mat_fetch(m, (last[g0 + j] ? hi[g0 + j] : hi[0]) & 0x1fffffffu);  // (a valid triangle: the loads are unconditional)
         uint8_t q[4][3] = {};
-        if (kUv && m.n_textures) {
+        // (without a uv array - 16-byte records - a textured triangle samples its texture at uv = (0, 0), as colorAt_f does with
+        // the default-initialised t of such a triangle and as the other tiers' color_at does; the descriptor cache is only
+        // filled by the uv variants)
+        if (m.n_textures) {
             const uint8_t *qa[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t id = mf[j].texid < m.n_textures ? mf[j].texid : 0u;
-                const DevTexture tx = id < kTexCache ? s_tex[id] : m.textures[id];
+                const DevTexture tx = (kUv && id < kTexCache) ? s_tex[id] : m.textures[id];
                 // (a slot that is not a textured group reads three bytes of texture 0's first texel: any valid address)
-                qa[j] = (last[g0 + j] && mf[j].type == kTriTextured) ? texel_address(tx, u[g0 + j], v[g0 + j]) : s_tex[0].pixels;
+                qa[j] = (last[g0 + j] && mf[j].type == kTriTextured) ? texel_address(tx, u[g0 + j], v[g0 + j])
+                                                                     : (kUv ? s_tex[0].pixels : m.textures[0].pixels);
             }
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
@@ -237,7 +241,7 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const Occ &o, cons
         for (uint32_t j = 0; j < 4; ++j) {
             if (last[g0 + j]) {
                 float cr, cg, cb;
-                mat_color(mf[j], kUv && m.n_textures != 0u, q[j][0], q[j][1], q[j][2], cr, cg, cb);
+                mat_color(mf[j], m.n_textures != 0u, q[j][0], q[j][1], q[j][2], cr, cg, cb);
                 f.add(p.blend, hi[g0 + j], WCol{w[g0 + j], cr, cg, cb});
             }
         }

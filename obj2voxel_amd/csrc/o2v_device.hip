@@ -112,7 +112,10 @@ struct o2v_hip_ctx {
     Tile *d_tiles = nullptr;
     BigLeaf *d_big = nullptr;
     Node *d_nodes[2] = {nullptr, nullptr};
-    uint2 *d_jobq = nullptr;  // k_voxelize's job queues: VoxShape::queue records per workgroup
+    uint2 *d_jobq = nullptr;  // k_candidates' staging queues: kCandQueue records per workgroup
+    uint32_t *d_job_xy = nullptr, *d_job_zf = nullptr, *d_job_leaf = nullptr;  // the job list between k_candidates and k_voxelize: cap_jobs dwords each
+    uint32_t cap_jobs = 0;
+    uint32_t clip_pad_lds[2] = {0, 0};  // dynamic LDS that pads a k_voxelize<false / true> workgroup to its share of a CU's LDS
     HitRec *d_pool = nullptr;
     SortedRec *d_sorted = nullptr;  // cap_hits records (read through SortedView: 24 or 16 bytes per record)
     uint32_t sorted_stride = 6;
@@ -264,6 +267,28 @@ float ord2f_host(uint32_t o)
     return f;
 }
 
+// Which runs take the occupancy-only mode (Params::occupancy_only) and the direct MAX path: decided in one place, for the
+// run itself (o2v_hip_voxelize) and for the memory estimate of o2v_hip_max_slab_layers (1 byte per cell against 4 + 8).
+struct GridModes {
+    bool use_uv, exact_clip, occupancy_only, direct_max;
+};
+GridModes grid_modes(const o2v_hip_ctx *ctx, const o2v_hip_params *params)
+{
+    GridModes g;
+    g.use_uv = ctx->d_uvs && ctx->any_textured;
+    const char *exact = std::getenv("O2V_EXACT_CLIP");
+    g.exact_clip = (params->flags & O2V_HIP_FLAG_EXACT_CLIP) || (exact && exact[0] == '1');
+    const char *off = std::getenv("O2V_NO_DIRECT_MAX");
+    const bool no_direct = off && off[0] == '1';
+    // occupancy-only mode: no triangle has a material, so the result is the set of hit voxels, all white, with either
+    // strategy.  Not in exact mode: the fast-vs-exact comparison covers this shortcut too.
+    const char *no_occ = std::getenv("O2V_NO_OCCUPANCY_ONLY");
+    g.occupancy_only = !ctx->d_types && !g.use_uv && !g.exact_clip && !no_direct && !(no_occ && no_occ[0] == '1');
+    // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
+    g.direct_max = (params->strategy == 0u || g.occupancy_only) && !no_direct;
+    return g;
+}
+
 // One pass of the pipeline with the current capacities.  Fills h_ctr; the caller checks for overflow.
 int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
 {
@@ -313,16 +338,21 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
 
     {
-        // persistent workgroups: four wavefronts per SIMD, in workgroups of VoxShape<UV>::block threads
+        // candidates -> job list (persistent 256-thread workgroups), then the clip on persistent single-wavefront workgroups
+        const JobList jobs{ctx->d_job_xy, ctx->d_job_zf, ctx->d_job_leaf};
+        O2V_LAUNCH("k_candidates", s, k_candidates, dim3((uint32_t) ctx->num_cus * (uint32_t) O2V_CAND_WGS), dim3(kCandBlock), 0, s, ctx->d_leaves,
+                           ctx->d_tiles, ctx->d_ctr, ctx->d_jobq, jobs, use_uv ? 1u : 0u, p);
+        // Exactly ClipShape::waves wavefronts per SIMD on every CU: the kernel's registers and static LDS would let the
+        // dispatcher pack one or two more single-wavefront workgroups onto the CUs it fills first - with a static deal of the
+        // job list that leaves other CUs short and the crowded ones slow - so dynamic LDS pads every workgroup to its share
+        // of the CU's 160 KiB.
         if (use_uv) {
-            const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES_UV * (kBlock / VoxShape<true>::block);
-            O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+            O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3((uint32_t) ctx->num_cus * 4u * ClipShape<true>::waves), dim3(64), ctx->clip_pad_lds[1], s,
+                               ctx->d_leaves, jobs, ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
         }
         else {
-            const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
-            O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+            O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3((uint32_t) ctx->num_cus * 4u * ClipShape<false>::waves), dim3(64), ctx->clip_pad_lds[0], s,
+                               ctx->d_leaves, jobs, ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
         }
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
@@ -565,6 +595,16 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
+    {
+        // (see run_pass: one workgroup of the clip kernel = 1 / (4 x waves) of the CU's 160 KiB of LDS)
+        const void *fn[2] = {reinterpret_cast<const void *>(&k_voxelize<false>), reinterpret_cast<const void *>(&k_voxelize<true>)};
+        const uint32_t waves[2] = {ClipShape<false>::waves, ClipShape<true>::waves};
+        for (int v = 0; v < 2; ++v) {
+            hipFuncAttributes fa{};
+            const uint32_t share = (160u * 1024u) / (4u * waves[v]);
+            if (hipFuncGetAttributes(&fa, fn[v]) == hipSuccess && fa.sharedSizeBytes < share) ctx->clip_pad_lds[v] = (share - (uint32_t) fa.sharedSizeBytes) & ~255u;
+        }
+    }
     // k_resolve_big sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_big), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int) (kBigList * 12u));
@@ -579,7 +619,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
-                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq,
+                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq, ctx->d_job_xy, ctx->d_job_zf, ctx->d_job_leaf,
                     ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
     for (void *q : ptrs)
@@ -848,13 +888,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
     for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];
     p.has_uv = ctx->d_uvs ? 1u : 0u;
-    {
-        const char *exact = std::getenv("O2V_EXACT_CLIP");
-        p.exact_clip = ((params->flags & O2V_HIP_FLAG_EXACT_CLIP) || (exact && exact[0] == '1')) ? 1u : 0u;
-        ctx->ktimes_on = (params->flags & O2V_HIP_FLAG_KERNEL_TIMES) != 0;
-        ctx->kernel_times.clear();
-    }
-    const bool use_uv = ctx->d_uvs && ctx->any_textured;
+    const GridModes modes = grid_modes(ctx, params);
+    p.exact_clip = modes.exact_clip ? 1u : 0u;
+    ctx->ktimes_on = (params->flags & O2V_HIP_FLAG_KERNEL_TIMES) != 0;
+    ctx->kernel_times.clear();
+    const bool use_uv = modes.use_uv;
     ctx->sorted_stride = use_uv ? 6u : 4u;
 
     // Dense grids for the slab (bricked, see cell_index), each with one dirty flag per brick; allocated zeroed, kept clean by
@@ -866,17 +904,10 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     ctx->stats.grid_cells = cells;
     ctx->stats.grid_bytes = 0;
     const uint64_t brick_cap_want = (n_bricks + 15u) & ~15ull;
-    {
-        const char *off = std::getenv("O2V_NO_DIRECT_MAX");
-        // occupancy-only mode (Params::occupancy_only): no triangle has a material, so the result is the set of hit voxels,
-        // all white, with either strategy.  Not in exact mode: the fast-vs-exact comparison covers this shortcut too.
-        const char *no_occ = std::getenv("O2V_NO_OCCUPANCY_ONLY");
-        p.occupancy_only = (!ctx->d_types && !use_uv && !p.exact_clip && !(off && off[0] == '1') && !(no_occ && no_occ[0] == '1')) ? 1u : 0u;
-        // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
-        p.direct_max = ((params->strategy == 0u || p.occupancy_only) && !(off && off[0] == '1')) ? 1u : 0u;
-        p.pick_max = (p.direct_max && use_uv) ? 1u : 0u;  // textured: the winner's colour is picked afterwards (k_pick)
-        p.mat = Materials{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
-    }
+    p.occupancy_only = modes.occupancy_only ? 1u : 0u;
+    p.direct_max = modes.direct_max ? 1u : 0u;
+    p.pick_max = (p.direct_max && use_uv) ? 1u : 0u;  // textured: the winner's colour is picked afterwards (k_pick)
+    p.mat = Materials{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
     if (p.direct_max) {
         // the max grid: 8 bytes per cell, or - occupancy only - the same buffer used as 1 byte per cell
         const uint64_t want_bytes = cells * (p.occupancy_only ? 1ull : sizeof(unsigned long long));
@@ -949,7 +980,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
     if (!ctx->d_jobq)
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) (O2V_K2_WAVES > O2V_K2_WAVES_UV ? O2V_K2_WAVES : O2V_K2_WAVES_UV) * (kBlock / 64u) * (64u * 64u) * sizeof(uint2)));  // = workgroups x VoxShape::queue for every shape
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) O2V_CAND_WGS * kCandQueue * sizeof(uint2)));  // = k_candidates' workgroups x kCandQueue
 
     // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
     uint64_t want_leaves = std::max<uint64_t>(ctx->cap_leaves, ctx->n_tris + ctx->n_tris / 4 + (1u << 16));
@@ -957,6 +988,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     uint64_t want_big = std::max<uint64_t>(ctx->cap_big, 1u << 16);
     uint64_t want_nodes = std::max<uint64_t>(ctx->cap_nodes, 1u << 18);
     uint64_t want_hits = std::max<uint64_t>(ctx->cap_hits, std::min<uint64_t>(16 * ctx->n_tris + (4u << 20), 1ull << 31));
+    // (voxel jobs: a few per cent more than hits - most candidates that pass the plane cull are hit; far fewer in occupancy-only mode)
+    uint64_t want_jobs = std::max<uint64_t>(ctx->cap_jobs, std::min<uint64_t>(16 * ctx->n_tris + (4u << 20), 1ull << 31));
     if (const char *tiny = std::getenv("O2V_TEST_TINY_BUFFERS"); tiny && tiny[0] == '1') {
         // test hook: start with minimal buffers so that every overflow -> grow -> re-run path is exercised
         want_leaves = std::max<uint64_t>(ctx->cap_leaves, 64);
@@ -964,6 +997,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         want_big = std::max<uint64_t>(ctx->cap_big, 4);
         want_nodes = std::max<uint64_t>(ctx->cap_nodes, 16);
         want_hits = std::max<uint64_t>(ctx->cap_hits, 512);
+        want_jobs = std::max<uint64_t>(ctx->cap_jobs, 512);
     }
     uint64_t want_scratch = ctx->cap_scratch;
     uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
@@ -1019,6 +1053,13 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             if ((rc = grow(ctx, ctx->d_sorted, cap_s, want_hits))) return rc;
             ctx->cap_hits = cap_p;
         }
+        {
+            uint32_t cap_a = ctx->cap_jobs, cap_b = ctx->cap_jobs, cap_c = ctx->cap_jobs;
+            if ((rc = grow(ctx, ctx->d_job_xy, cap_a, want_jobs))) return rc;
+            if ((rc = grow(ctx, ctx->d_job_zf, cap_b, want_jobs))) return rc;
+            if ((rc = grow(ctx, ctx->d_job_leaf, cap_c, want_jobs))) return rc;
+            ctx->cap_jobs = cap_a;
+        }
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
@@ -1045,6 +1086,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         p.cap_nodes = ctx->cap_nodes;
         p.cap_hits = ctx->cap_hits;
         p.cap_vox = ctx->cap_vox;
+        p.cap_jobs = ctx->cap_jobs;
 
         if ((rc = run_pass(ctx, p, use_uv, n_rounds))) return rc;
         const Counters &h = *ctx->h_ctr;
@@ -1055,6 +1097,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->err = (h.err_flags & kErrLeafTooLarge) ? "a leaf's voxel AABB has 2^32 or more candidate voxels"
                        : (h.err_flags & kErrDepth)      ? "subdivision deeper than 15 levels"
                        : (h.err_flags & kErrDirtyList)  ? "more than 2^27 bricks of the slab hold voxels; use more z-slabs"
+                       : (h.err_flags & kErrCounterWrap) ? "2^32 or more leaves or tiles in one slab; use more z-slabs"
                                                         : "a voxel received 2^24 or more hits";
             return O2V_HIP_ERR_LIMIT;
         }
@@ -1072,6 +1115,10 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(h.n_big, ctx->cap_big, want_big);
         need(max_nodes, ctx->cap_nodes, want_nodes);
         need(h.n_hits_reserved, ctx->cap_hits, want_hits);
+        if (h.n_jobs > ctx->cap_jobs) {
+            want_jobs = h.n_jobs + h.n_jobs / 8 + 1024;
+            again = true;
+        }
         need(h.n_vox, ctx->cap_vox, want_vox);
         if (p.direct_max) need(h.n_out, ctx->cap_vox, want_vox);
         if (n_rounds < kMaxRounds && h.n_nodes[n_rounds] != 0) {
@@ -1314,7 +1361,6 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
         }
         return O2V_HIP_OK;
     }
-    if (!plan_params_ok(ctx, params, world)) return O2V_HIP_ERR_BAD_ARGUMENT;
     // Everything that can fail on one rank alone - the device, the allocations of the planning passes - happens before the
     // first collective, and the ranks then agree on going ahead (one 4-byte max-reduce): a rank that returned early would
     // leave the others waiting for it in RCCL.  The only word that has to exist for that is allocated first.
@@ -1357,17 +1403,25 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
             if (!ctx->d_block_count) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_block_count), sizeof(uint32_t)));
             return O2V_HIP_OK;
         };
-        rc_prepare = prepare();
+        // (bad parameters are a failure of this rank like any other: reported through the status word, so that the other
+        // ranks do not wait in the all-reduce for a rank that has already returned)
+        const bool params_ok = plan_params_ok(ctx, params, world);
+        rc_prepare = params_ok ? prepare() : O2V_HIP_ERR_BAD_ARGUMENT;
         if (const char *fail = std::getenv("O2V_TEST_FAIL_RANK"); fail && std::atoi(fail) == (int) rank && rc_prepare == O2V_HIP_OK) {
             ctx->err = "O2V_TEST_FAIL_RANK: simulated failure of this rank before the collectives";  // test hook
             rc_prepare = O2V_HIP_ERR_OUT_OF_MEMORY;
         }
-        const std::string prepare_err = ctx->err;
         hipStream_t s0 = ctx->stream;
         *ctx->h_status = rc_prepare ? 1u : 0u;
-        O2V_CHECK(hipMemcpyAsync(ctx->d_status, ctx->h_status, sizeof(uint32_t), hipMemcpyHostToDevice, s0));
-        const bool time_it = ctx->ev_coll[0] && ctx->ev_coll[1];
-        if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s0));
+        // (a HIP error here must not skip the all-reduce either: it is noted and returned once every rank has been through it)
+        hipError_t e_local = hipMemcpyAsync(ctx->d_status, ctx->h_status, sizeof(uint32_t), hipMemcpyHostToDevice, s0);
+        bool time_it = ctx->ev_coll[0] && ctx->ev_coll[1];
+        if (time_it && hipEventRecord(ctx->ev_coll[0], s0) != hipSuccess) time_it = false;
+        if (e_local != hipSuccess && !rc_prepare) {
+            ctx->err = std::string("hipMemcpyAsync(status word): ") + hipGetErrorString(e_local);
+            rc_prepare = O2V_HIP_ERR_HIP;
+        }
+        const std::string prepare_err = ctx->err;
         if (comm->allreduce_max_u32(ctx->d_status, 1, s0)) {
             ctx->err = std::string("collective failed: ") + comm->err;
             return O2V_HIP_ERR_HIP;
@@ -1455,8 +1509,9 @@ int o2v_hip_max_slab_layers(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint
     const uint64_t per_layer_bricks = ((G + kBrickX - 1) / kBrickX) * ((G + kBrickY - 1) / kBrickY);
     // per brick: occupancy only (no triangle of the uploaded mesh has a material) one byte per cell; else the 32-bit counter
     // grid and, for the MAX strategy, the 64-bit grid; each with a dirty flag and a dirty-list entry
-    const bool occupancy_only = !ctx->d_types && !(ctx->d_uvs && ctx->any_textured);
-    const bool max_grid = params->strategy == 0u;
+    const GridModes modes = grid_modes(ctx, params);  // (the same decision o2v_hip_voxelize takes, flags and environment included)
+    const bool occupancy_only = modes.occupancy_only;
+    const bool max_grid = modes.direct_max && !occupancy_only;
     const uint64_t per_brick = occupancy_only ? kBrickCells * 1ull + 1 + 4
                                               : kBrickCells * 4ull + 1 + 4 + (max_grid ? kBrickCells * 8ull + 1 + 4 : 0ull);
     // what the context already holds of these grids is reusable

@@ -193,3 +193,75 @@ def stress_soup(kind, T, S, seed=0, z_range=None):
 def stress_bounds(S):
     """User bounds that make the mesh transform x -> x + 0.5 (up to rounding) on an S^3 sample grid."""
     return [-0.25] * 3 + [S - 0.75] * 3
+
+
+def scan_like(target=870_000):
+    """A deterministic "scanned object": an icosphere refined adaptively (five refinement levels side by side: triangle areas
+    spread over more than 100 : 1), its surface displaced radially by a few octaves of smooth pseudo-noise (no RNG: products
+    of sines with incommensurate frequencies), every twentieth triangle collapsed into a sliver along one of its edges (5 %
+    of the list, aspect ratios around 50 : 1; the holes they leave are what scans have too).  About `target` triangles in
+    submission order of the refinement (spatially coherent, as a scanner's strips are).  float64 construction, rounded once
+    to float32: reproducible bit for bit.  Returns verts [T, 9]."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    V = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    V /= np.linalg.norm(V, axis=1, keepdims=True)
+    F = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                  [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7],
+                  [9, 8, 1]])
+    tris = V[F]  # [20, 3, 3]
+
+    def split(tr):
+        a, b, c = tr[:, 0], tr[:, 1], tr[:, 2]
+        ab, bc, ca = a + b, b + c, c + a
+        ab /= np.linalg.norm(ab, axis=1, keepdims=True)
+        bc /= np.linalg.norm(bc, axis=1, keepdims=True)
+        ca /= np.linalg.norm(ca, axis=1, keepdims=True)
+        # children in a fixed order, kept next to each other (spatial coherence of the list)
+        return np.stack([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)], 1).reshape(-1, 3, 3)
+
+    base_levels = 5
+    for _ in range(base_levels):
+        tris = split(tris)  # 20 * 4^5 = 20 480
+    # extra refinement 0..4 per base triangle from a smooth field of its centroid; the thresholds put ~ 15 / 25 / 30 / 20 / 10 %
+    # of the base triangles on the levels 0..4, which gives about 870 k triangles
+    cen = tris.mean(axis=1)
+    field = (np.sin(3.1 * cen[:, 0] + 0.4) * np.cos(2.3 * cen[:, 1] - 1.1) + 0.6 * np.sin(4.7 * cen[:, 2] + 2.0 * cen[:, 0]) +
+             0.35 * np.cos(7.9 * cen[:, 1] + 1.7 * cen[:, 2]))
+    qs = np.quantile(field, [0.15, 0.40, 0.70, 0.90])
+    level = np.searchsorted(qs, field)  # 0..4
+    # scale the split so that the total is close to `target`
+    total = int((4.0 ** level).sum())
+    if total > target * 1.15 or total < target * 0.85:
+        # (other targets: shift every level by the same amount where possible)
+        shift = int(np.round(np.log(target / total) / np.log(4.0)))
+        level = np.clip(level + shift, 0, 6)
+    # refine level by level, keeping each base triangle's descendants contiguous: process base triangles in order, in
+    # groups of equal level (stable: concatenate per base index afterwards)
+    order_keys, pieces = [], []
+    for lv in range(int(level.max()) + 1):
+        idx = np.flatnonzero(level == lv)
+        if len(idx) == 0:
+            continue
+        tr = tris[idx]
+        for _ in range(lv):
+            tr = split(tr)
+        n_per = 4 ** lv
+        pieces.append(tr)
+        order_keys.append(np.repeat(idx, n_per).astype(np.int64) * 4096 + np.tile(np.arange(n_per), len(idx)))
+    tr = np.concatenate(pieces, axis=0)
+    tr = tr[np.argsort(np.concatenate(order_keys), kind="stable")]
+    # radial displacement: smooth pseudo-noise, four octaves
+    def noise(p):
+        x, y, z = p[..., 0], p[..., 1], p[..., 2]
+        n = 0.060 * np.sin(2.1 * x + 1.3) * np.sin(1.7 * y - 0.6) * np.cos(2.9 * z + 0.2)
+        n += 0.030 * np.sin(5.3 * x - 2.2 * z) * np.cos(4.1 * y + 0.9)
+        n += 0.012 * np.sin(11.7 * y + 3.1 * x) * np.sin(9.3 * z - 1.4)
+        n += 0.004 * np.cos(23.9 * x + 17.1 * y - 19.7 * z)
+        return n
+    tr = tr * (1.0 + noise(tr))[..., None]
+    # slivers: every twentieth triangle is collapsed onto its first edge (c -> 2 % of the way from the edge's midpoint)
+    sl = np.arange(7, len(tr), 20)
+    mid = 0.5 * (tr[sl, 0] + tr[sl, 1])
+    tr[sl, 2] = mid + 0.02 * (tr[sl, 2] - mid)
+    return tr.astype(np.float32).reshape(-1, 9)

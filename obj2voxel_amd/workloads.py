@@ -24,6 +24,12 @@ def _coloured(nv):
     return make
 
 
+def _scan():
+    v = meshes.scan_like()
+    T = len(v)
+    return v, dict(types=np.full(T, 2, np.uint32), colors=meshes.triangle_colors(T)), None
+
+
 def _textured(nv):
     def make():
         v, uv = meshes.uv_sphere(nv, with_uv=True)
@@ -47,6 +53,8 @@ WORKLOADS = {
     "config2_colored_max": (_coloured(467), 1024, dict(strategy=0), "configs[2] mesh with per-triangle colours, MAX: direct path, colour by winner"),
     "config2_blend": (_coloured(467), 1024, dict(strategy=1), "configs[2] mesh with per-triangle colours, BLEND: pool -> counting sort -> ordered replay"),
     "config2_textured_max": (_textured(467), 1024, dict(strategy=0), "configs[2] mesh textured, MAX: k_voxelize<true>, direct path with pick records"),
+    "scan_colored_max": (_scan, 1024, dict(strategy=0), "irregular mesh: adaptively refined, noise-displaced icosphere (908 288 tris, areas spread 380 : 1, 5 % slivers) @1024^3, coloured, MAX"),
+    "scan_blend": (_scan, 1024, dict(strategy=1), "the same irregular mesh, coloured, BLEND"),
     "config1": (_textured(39), 512, dict(strategy=1), "BASELINE configs[1] stand-in: uv-sphere nv=39 (5 928 tris) @512^3, textured, BLEND"),
     "config3": (_sponza, 2048, dict(strategy=1, supersampling=2), "BASELINE configs[3] stand-in: box room + sphere (262 092 textured tris) @2048^3 x2 supersampling, BLEND"),
     "config3_max": (_sponza, 2048, dict(strategy=0, supersampling=2), "configs[3] stand-in with MAX"),
@@ -56,7 +64,7 @@ WORKLOADS = {
 }
 
 # the routes bench.py times after its headline (N = 1), in this order
-BENCH_ROUTES = ("config2_colored_max", "config2_blend", "config2_textured_max", "config1", "config3")
+BENCH_ROUTES = ("config2_colored_max", "config2_blend", "config2_textured_max", "scan_colored_max", "config1", "config3")
 
 # real assets: file stem under $O2V_ASSETS -> (BASELINE configuration it belongs to, resolution, voxelize keywords)
 ASSETS = {

@@ -829,20 +829,23 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
                             for (uint32_t x = t->chunk_min[0]; x <= t->chunk_max[0] && x < chunks_per_axis; ++x) {
                                 size_t c = ((size_t) z * chunks_per_axis + y) * chunks_per_axis + x;
                                 if (pass == 0) row[c]++;
-                                else chunk_items[row[c]++] = (uint32_t) i;
+                                else chunk_items[chunk_start[c] + row[c]++] = (uint32_t) i;
                             }
                 }
             }
             if (pass == 0) {
-                /* counts -> places: chunk by chunk, range by range (the 32-bit places bound a chunk list at 2^32 entries) */
+                /* counts -> places: chunk by chunk, range by range.  A place is relative to its chunk's start (32 bits bound one
+                 * chunk's list at 2^32 entries; the starts, and so the total, are 64-bit) */
                 uint64_t acc = 0;
                 for (size_t c = 0; c < nchunks; ++c) {
                     chunk_start[c] = acc;
+                    uint64_t in_chunk = 0;
                     for (int r = 0; r < n_ranges; ++r) {
                         const uint32_t n = cnt[(size_t) r * nchunks + c];
-                        cnt[(size_t) r * nchunks + c] = (uint32_t) acc;
-                        acc += n;
+                        cnt[(size_t) r * nchunks + c] = (uint32_t) in_chunk;
+                        in_chunk += n;
                     }
+                    acc += in_chunk;
                 }
                 chunk_start[nchunks] = acc;
                 chunk_items = (uint32_t *) malloc(sizeof(uint32_t) * (acc ? acc : 1));

@@ -84,6 +84,23 @@ def test_config2_dragon_standin_1024_coloured_blend(dv, all_cores):
     _equal(got, all_cores.voxelize(v, 1024, strategy=1, **kw))
 
 
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_irregular_scan_like_mesh_1024_coloured(dv, all_cores, strategy):
+    """The irregular route of the bench line (workloads `scan_colored_max` / `scan_blend`): an adaptively refined,
+    noise-displaced icosphere - 908 288 coloured triangles whose areas spread 380 : 1, 5 % of them slivers - at 1024^3,
+    full size against the oracle.  Every other timed mesh is uniformly tessellated; this one mixes leaves of one voxel with
+    leaves of dozens and subdivided triangles with whole ones in the same wavefront."""
+    from obj2voxel_amd import hip
+    v = meshes.scan_like()
+    T = len(v)
+    assert T == 908_288
+    kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T))
+    dv.set_triangles(v, **kw)
+    got = dv.voxelize(1024, strategy=strategy)
+    _equal(got, all_cores.voxelize(v, 1024, strategy=strategy, **kw))
+    assert len(got) > 3_000_000
+
+
 def _sponza_standin():
     from obj2voxel_amd import hip
     room = meshes.box_room(16)

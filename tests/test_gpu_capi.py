@@ -139,6 +139,34 @@ def test_log_callback_receives_messages():
     assert any(level == capi.LOG_DEBUG for level, _ in seen)
 
 
+@pytest.mark.parametrize("res,ss", [(65536, 1), (40000, 2)])
+def test_sample_resolution_above_65535_is_refused_with_a_logged_reason(res, ss):
+    """The reference takes any uint32 resolution (include/obj2voxel.h:130-138; its VoxelMap is sparse); the dense-grid path
+    refuses resolution x supersampling > 65 535 with OBJ2VOXEL_ERR_DEVICE (8, declared in include/obj2voxel.h as an extension)
+    and says why at ERROR level."""
+    from obj2voxel_amd import capi
+    a = capi.api()
+    seen = []
+    cb = capi.LOG_CB(lambda _d, msg, level: (seen.append((level, msg.decode())), True)[1])
+    a.obj2voxel_set_log_callback.argtypes = [capi.LOG_CB, C.c_void_p]
+    a.obj2voxel_set_log_callback(cb, None)
+    a.obj2voxel_set_log_level(capi.LOG_ERROR)
+    try:
+        inst, inp = _instance(a, meshes.unit_cube())
+        out = capi.CountingOutput()
+        a.obj2voxel_set_output_callback(inst, out.callback, None)
+        a.obj2voxel_set_resolution(inst, res)
+        a.obj2voxel_set_supersampling(inst, ss)
+        assert a.obj2voxel_voxelize(inst) == capi.ERR_DEVICE == 8
+        a.obj2voxel_free(inst)
+    finally:
+        a.obj2voxel_set_log_callback.argtypes = [C.c_void_p, C.c_void_p]
+        a.obj2voxel_set_log_callback(None, None)
+        a.obj2voxel_set_log_level(capi.LOG_INFO)
+    assert out.voxel_count == 0
+    assert any(level == capi.LOG_ERROR and "65536" in m for level, m in seen), seen
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_argb_texture_and_uv_mode_through_the_api(oracle, mode):
     """4-channel textures are ARGB (include/obj2voxel.h:317-320); obj2voxel_teture_set_uv_mode picks clamp / wrap."""

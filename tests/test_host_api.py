@@ -212,3 +212,28 @@ def test_gpu_path_fails_loudly_without_a_device(a):
     a.obj2voxel_free(inst)
     with pytest.raises(hip.DeviceError):
         hip.DeviceVoxelizer(0)
+
+
+def test_header_declares_the_error_codes_the_library_returns():
+    """The reference's codes 0..7 (include/obj2voxel.h:63-79) plus this build's extension OBJ2VOXEL_ERR_DEVICE = 8: a
+    caller compiled against the header can name every code obj2voxel_voxelize() returns."""
+    from obj2voxel_amd import capi
+    text = open(os.path.join(ROOT, "include", "obj2voxel.h")).read()
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"obj2voxel_error_t (OBJ2VOXEL_ERR_[A-Z_]+) = (\d+);", text)}
+    assert sorted(codes.values()) == list(range(9))
+    assert codes["OBJ2VOXEL_ERR_DEVICE"] == capi.ERR_DEVICE == 8
+    assert codes["OBJ2VOXEL_ERR_DOUBLE_VOXELIZATION"] == capi.ERR_DOUBLE_VOXELIZATION == 7
+
+
+def test_cli_version_and_help_need_no_device():
+    """-V / --version (reference src/main.cpp:296-298,320-340), --80 and -h of the command line front end."""
+    import subprocess
+    import obj2voxel_amd
+    cli = os.path.join(os.path.dirname(obj2voxel_amd.LIB_PATH), "obj2voxel-amd")
+    if not os.path.exists(cli):
+        obj2voxel_amd.build()
+    for flag in ("-V", "--version"):
+        r = subprocess.run([cli, flag], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "Version:" in r.stdout and "1.3.5" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([cli, "--80", "-h"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "--version" in r.stdout

@@ -13,22 +13,17 @@ constexpr uint32_t kMaxRounds = 16;       // subdivision depth limit (order key 
 constexpr uint32_t kHitChunk = 256;       // hit-pool slots a wavefront reserves per global atomic
 constexpr uint32_t kInlineTiles = 4;      // leaves with more tiles are expanded by k_expand_big
 
-struct __attribute__((aligned(16))) Leaf {  // 96 B; the first 48 (64 with uv: + t[0..3]) bytes are what the clip kernel prefetches per job
+struct __attribute__((aligned(16))) Leaf {  // 96 B
     float v[9];        // sample-space vertices
-    float area;        // area of the whole input triangle (voxelization.cpp:416)
+    float n[3];        // normalize(normal): plane of the distance cull
+    float t[6];        // uv per vertex
     uint32_t tri;      // input triangle index
     uint32_t pathkey;  // order key of this leaf among the leaves of `tri` (0 = unsplit triangle)
-    float t[6];        // uv per vertex
-    float n[3];        // normalize(normal): plane of the distance cull
     uint32_t bmin_xy;  // clamped AABB min: x | y << 16
     uint32_t bmin_z_dx;  // z | dx << 16
     uint32_t dy_dz;      // dy | dz << 16
+    float area;          // area of the whole input triangle (voxelization.cpp:416)
 };
-// dword offsets of the fields (k_candidates reads its staged copies by index)
-constexpr uint32_t kLfArea = 9, kLfTri = 10, kLfKey = 11, kLfT = 12, kLfN = 18, kLfBminXy = 21, kLfBminZDx = 22, kLfDyDz = 23;
-static_assert(offsetof(Leaf, area) == 4 * kLfArea && offsetof(Leaf, tri) == 4 * kLfTri && offsetof(Leaf, pathkey) == 4 * kLfKey &&
-              offsetof(Leaf, t) == 4 * kLfT && offsetof(Leaf, n) == 4 * kLfN && offsetof(Leaf, bmin_xy) == 4 * kLfBminXy &&
-              offsetof(Leaf, bmin_z_dx) == 4 * kLfBminZDx && offsetof(Leaf, dy_dz) == 4 * kLfDyDz, "Leaf layout");
 static_assert(sizeof(Leaf) == 96, "Leaf layout");
 
 struct __attribute__((aligned(16))) Node {  // 80 B: a sub-triangle that still has to be subdivided
@@ -123,7 +118,7 @@ struct Counters {
     unsigned long long n_direct;
     float xform[12];
     unsigned long long n_certain;   // occupancy-only mode: hits established without a voxel job (certain_prepare)
-    unsigned long long n_jobs;      // candidate voxels that passed k_candidates (= voxel jobs of k_voxelize); the job list's cursor
+    unsigned long long n_jobs;      // candidate voxels that passed phase 1 of k_voxelize (= voxel jobs of phase 2)
     unsigned long long dbg[16];  // event counts of an instrumented build (-DO2V_INSTRUMENT, tools/instrument.sh); else zero
 };
 
@@ -145,7 +140,6 @@ struct Params {
     uint32_t zo0;          // slab begin in output space
     uint32_t blend;
     uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
-    uint32_t cap_jobs;     // entries of the job list between k_candidates and k_voxelize
     uint32_t n_bricks;     // bricks of this slab
     uint32_t cap_dirty;    // entries of each dirty-brick list
     uint32_t bounds_known;
@@ -191,7 +185,7 @@ __device__ __forceinline__ bool direct_active(const Counters *c, const Params &p
 }
 __device__ __forceinline__ bool pass_overflowed(const Counters *c, const Params &p)
 {
-    return c->n_hits_reserved > p.cap_hits || c->n_sorted > p.cap_hits || c->n_vox > p.cap_vox || c->n_jobs > (unsigned long long) p.cap_jobs;
+    return c->n_hits_reserved > p.cap_hits || c->n_sorted > p.cap_hits || c->n_vox > p.cap_vox;
 }
 
 __device__ __forceinline__ uint32_t f2ord(float f)

@@ -1,4 +1,4 @@
-// o2v_dev_k2_voxelize.hpp -- K2: candidate test (k_candidates) and six-plane clip (k_voxelize<UV>).
+// o2v_dev_k2_voxelize.hpp -- K2: candidate test and six-plane clip (k_voxelize<UV>).
 //
 // Part of the device code of o2v_device.hip, which includes this file inside its anonymous namespace (one
 // translation unit: the stages share records and launch parameters).  Not a stand-alone header.
@@ -171,6 +171,58 @@ __device__ __forceinline__ void accumulate_piece(const Piece<UV> &pc, float area
         }
     }
     w = ws;
+}
+
+// Pending sibling pieces of the depth-first clip walk: a stack (last in, first out - the sibling pushed last belongs to
+// the deepest level and is next in depth-first order).  Under DISCARD a cut keeps <= 2 pieces, so at most one sibling per
+// level 1..5 is pending.  The first entries live in registers and are accessed with value selects on the stack pointer
+// (every access uses a compile-time slot, so they never leave the VGPR file): three without uv (deeper entries are 1 % of
+// the pushes on the bench mesh), two with uv, whose pieces are 15 floats (9 % of the pushes go deeper; measured faster on
+// configs[1] and configs[3] than a third slot and its spills).  Deeper entries go to a small per-lane overflow array
+// (scratch memory).
+#ifndef O2V_STACK_REGS
+#define O2V_STACK_REGS 3
+#endif
+#ifndef O2V_STACK_REGS_UV
+#define O2V_STACK_REGS_UV 2
+#endif
+template <bool UV>
+__device__ __forceinline__ constexpr uint32_t stack_regs() { return UV ? O2V_STACK_REGS_UV : O2V_STACK_REGS; }
+constexpr uint32_t kStackLevels = 5;
+template <bool UV>
+struct PieceStack {
+    Piece<UV> s0, s1, s2;
+};
+
+// Value-level selects (v_cndmask), not control flow: a branchy form gets folded by the compiler into a select of
+// addresses, which forces the stack into scratch memory.
+template <bool UV>
+__device__ __forceinline__ Piece<UV> sel_piece(bool take_x, const Piece<UV> &x, const Piece<UV> &y)
+{
+    const unsigned long long m = lane_mask(take_x);
+    Piece<UV> r;
+    r.a = vsel(m, x.a, y.a);
+    r.b = vsel(m, x.b, y.b);
+    r.c = vsel(m, x.c, y.c);
+    if (UV) {
+        r.ta = vsel(m, x.ta, y.ta);
+        r.tb = vsel(m, x.tb, y.tb);
+        r.tc = vsel(m, x.tc, y.tc);
+    }
+    return r;
+}
+template <bool UV>
+__device__ __forceinline__ void stack_store(PieceStack<UV> &st, uint32_t slot, const Piece<UV> &pc)
+{
+    st.s0 = sel_piece<UV>(slot == 0, pc, st.s0);
+    st.s1 = sel_piece<UV>(slot == 1, pc, st.s1);
+    if (stack_regs<UV>() > 2u) st.s2 = sel_piece<UV>(slot == 2, pc, st.s2);
+}
+template <bool UV>
+__device__ __forceinline__ Piece<UV> stack_load(const PieceStack<UV> &st, uint32_t slot)
+{
+    return stack_regs<UV>() > 2u ? sel_piece<UV>(slot == 0, st.s0, sel_piece<UV>(slot == 1, st.s1, st.s2))
+                                 : sel_piece<UV>(slot == 0, st.s0, st.s1);
 }
 
 // Conservative triangle / voxel overlap test (separating axes: the triangle's plane and the nine edge x axis
@@ -400,50 +452,70 @@ __device__ __forceinline__ CertainPrep certain_prepare(V3 v0, V3 v1, V3 v2, V3 n
     return c;
 }
 
-
-// ---- the two kernels of K2 ----------------------------------------------------------------------------------------------------
-// k_candidates  phase 1: the tiles' candidate rows (row_span), the reference's plane-distance cull, the certain hits of the
-//               occupancy-only mode; every surviving candidate becomes a 12-byte JOB RECORD in a global list.
-// k_voxelize    phase 2: the six-plane clip (computeTrianglesUvInVoxel) of every job, on persistent lanes that pull jobs from
-//               that list; hits go to the max grid / the hit pool as before.
-// Until round 3 both phases ran in one kernel, batch by batch, with the leaves of a batch in LDS.  That tied the clip loop
-// to the batches: a workgroup's lanes ran dry at the end of every batch (52 of 64 lanes busy per iteration on the bench mesh
-// with colours, 43 on configs[1]), every batch paid its staging and barriers (10 % of the kernel), and the leaf table left no
-// LDS for the clip loop's own state.  With the job list in between, the clip kernel has no batches, no barriers and no
-// phase 1: its lanes stay busy until the list is empty, and its LDS holds the stack of pending pieces (addressed by the stack
-// pointer: ds_write / ds_read instead of ~50 selects per iteration over register slots).
-
-// Job list: three dword arrays of Params::cap_jobs entries each (one allocation).
-//   xy    x | y << 16                                      (sample-space voxel position, all below 2^16)
-//   zf    z | plane mask << 16 | small << 22 | lean << 23   (planes of this voxel the leaf does not pass whole; see piece_masks)
-//   leaf  index into leaves[]
-// Counters::n_jobs is the list's cursor: it keeps counting past cap_jobs (the host then grows the list and repeats the pass).
-struct JobList {
-    uint32_t *xy, *zf, *leaf;
-};
-constexpr uint32_t kJobCfShift = 16, kJobSmallBit = 1u << 22, kJobLeanBit = 1u << 23;
-
 #ifndef O2V_FLUSH_AT
 #define O2V_FLUSH_AT 48
 #endif
 constexpr uint32_t kFlushAt = O2V_FLUSH_AT;             // parked hits per wavefront that trigger the append section
 constexpr uint32_t kLeafStride = 25;          // dwords per staged leaf in LDS (24 + 1 pad: spreads banks)
-// Launch shape of k_candidates: 256-thread workgroups (four wavefronts share a leaf table and a staging queue), persistent,
-// O2V_CAND_WGS per CU.  A workgroup stages at most one tile per thread and its staging queue holds 64 candidates per thread;
-// it takes its tiles from the cursor in batches, about O2V_CAND_BATCHES per workgroup.
-#ifndef O2V_CAND_WGS
-#define O2V_CAND_WGS 4
+// Launch shape of k_voxelize.  Without uv: 256-thread workgroups (four wavefronts share a leaf table and a job queue).  With
+// uv: one wavefront per workgroup with its own table and queue (no workgroup barriers; measured -8 % on configs[3], -5 % on
+// configs[1]; without uv the same change costs 4 %).  A workgroup stages at most one tile per thread and its queue holds
+// 64 candidates per thread; it takes its tiles from the cursor in batches - about `batches` per workgroup, `batches_large`
+// for large jobs (if a batch then still holds `finer_min` tiles): few large batches leave workgroups idle at the end of the
+// kernel, many small ones pay the per-batch staging, barriers and tails too often.
+#ifndef O2V_VOX_BLOCK
+#define O2V_VOX_BLOCK 256
 #endif
-#ifndef O2V_CAND_BATCHES
-#define O2V_CAND_BATCHES 4
+#ifndef O2V_VOX_BLOCK_UV
+#define O2V_VOX_BLOCK_UV 64
 #endif
 #ifndef O2V_HEAVY_PLANES
 #define O2V_HEAVY_PLANES 5
 #endif
-constexpr uint32_t kCandBlock = 256, kCandTiles = kCandBlock, kCandQueue = 64u * kCandBlock;
-constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;  // a job whose leaf straddles at least this many voxel planes goes to the front of its workgroup's part of the list
+template <bool UV>
+struct VoxShape {
+    static constexpr uint32_t block = UV ? O2V_VOX_BLOCK_UV : O2V_VOX_BLOCK;  // threads per workgroup
+    static constexpr uint32_t tiles = block;                                  // tiles staged at once (at most)
+    static constexpr uint32_t queue = 64u * block;  // job queue records (= candidate voxels at most) per sub-batch and workgroup
+#ifndef O2V_BATCHES
+#define O2V_BATCHES 4
+#define O2V_BATCHES_LARGE 6
+#endif
+#ifndef O2V_BATCHES_UV
+#define O2V_BATCHES_UV 2
+#define O2V_BATCHES_LARGE_UV 3
+#endif
+    static constexpr uint32_t batches = block >= 256u ? O2V_BATCHES : O2V_BATCHES_UV, batches_large = block >= 256u ? O2V_BATCHES_LARGE : O2V_BATCHES_LARGE_UV;
+    static constexpr uint32_t finer_min = 32u * block / 256u;
+};
+constexpr uint32_t kHeavyPlanes = O2V_HEAVY_PLANES;          // a job whose leaf straddles at least this many voxel planes is queued first
 
-// exclusive scan of one uint32 per thread over a workgroup of kVoxBlock threads; returns the total in `total`
+// K2.  Persistent workgroups pull batches of tiles.  Per batch:
+//   phase 1  the tiles' candidate rows: the separating-axis test solved for x per row (row_span), the rows' survivors
+//            flattened over the lanes, plane-distance cull (voxelization.cpp:451-458); survivors become 8-byte job
+//            records (position, tile slot, planes the leaf straddles) in the workgroup's queue in global memory, jobs
+//            that straddle many planes (the long ones) first
+//   phase 2  persistent lanes fetch their next job one ahead and run computeTrianglesUvInVoxel (voxelization.cpp:383-424) as a
+//            depth-first walk of the split tree: the reference clips level by level with two 64-entry buffers;
+//            visiting the first emitted piece first reproduces its buffer order, so the running mean of
+//            :414-420 accumulates in the identical sequence.  Under DISCARD every split keeps <= 2 pieces, so at
+//            most one sibling per level 1..5 is pending (register stack with a scratch overflow).  Every piece carries
+//            the set of planes it does not pass whole (piece_masks); per iteration a lane classifies its piece against
+//            the first of them and cuts it, and the kept pieces are judged at once from their bounding boxes: final
+//            (accumulated), beyond a later plane (dropped with its whole subtree), one plane left (without uv: settled
+//            from its classification, see single_plane), or to be cut again.  So lanes spend their iterations only on
+//            cuts whose pieces are needed (3.8 per voxel job on the bench mesh; 5.9 before the single-plane rule, 8.4
+//            events before the masks); lanes that run out of pieces pop the next survivor, so the wavefront stays full.
+// Register budget: 4 waves per SIMD for both variants (125 VGPRs without uv arithmetic; with it the allocator spills two
+// dozen cold values - measured faster than 3 waves without spills on the large textured workloads: configs[3] 31.5 ->
+// 30.1 ms).  5 waves without uv (96 VGPRs, 16 spilled) measured the same as 4.
+#ifndef O2V_K2_WAVES
+#define O2V_K2_WAVES 4
+#endif
+#ifndef O2V_K2_WAVES_UV
+#define O2V_K2_WAVES_UV 4
+#endif
+// exclusive scan of one uint32 per thread over k_voxelize's workgroup; returns the total in `total`
 template <uint32_t kVoxBlock>
 __device__ __forceinline__ uint32_t vox_exscan(uint32_t v, uint32_t *s_wave /*[kVoxBlock / 64]*/, uint32_t &total)
 {
@@ -468,45 +540,83 @@ __device__ __forceinline__ uint32_t vox_exscan(uint32_t v, uint32_t *s_wave /*[k
     return base + inc - v;
 }
 
-// K2, phase 1.  Persistent workgroups pull batches of tiles.  Per batch the tiles' leaves are staged in LDS; then
-//   the tiles' candidate rows: the separating-axis test solved for x per row (row_span), the rows' survivors flattened over
-//   the lanes, plane-distance cull (voxelization.cpp:451-458); in occupancy-only mode the certain-hit test marks most hit
-//   voxels at once; the other survivors become job records - first in the workgroup's staging queue (global memory, stays
-//   in L2), jobs that straddle many planes from the front, the others from the back - and, once their number is known, in
-//   the job list (one reservation per sub-batch and workgroup: atomics on one address serialise at ~88 per us).
-// `uv`: the mesh has textured triangles (the clip kernel then runs its uv variant, whose lean divisions need the leaf's area
-// and uv range checked: lean_ok).
-__global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles, Counters *c,
-                                                           uint2 *stage_all, JobList jobs, uint32_t uv, Params p)
+template <bool UV>
+__global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+                                                     Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
+                                                     uint2 *jobq_all, Params p)
 {
-    constexpr uint32_t kVoxBlock = kCandBlock, kVoxTiles = kCandTiles, kQueueCap = kCandQueue;
+    constexpr uint32_t kVoxBlock = VoxShape<UV>::block, kVoxTiles = VoxShape<UV>::tiles, kQueueCap = VoxShape<UV>::queue;
+    // (occupancy-only mode: most candidates are settled in phase 1, so a batch leaves few voxel jobs - half as many, larger
+    // batches keep phase 2's lanes busier: bench mesh 0.54 -> 0.50 ms)
+    const uint32_t kBatchesPerBlock = (!UV && p.occupancy_only) ? (VoxShape<UV>::batches + 1u) / 2u : VoxShape<UV>::batches;
+    const uint32_t kBatchesPerBlockLarge = (!UV && p.occupancy_only) ? (VoxShape<UV>::batches_large + 1u) / 2u : VoxShape<UV>::batches_large;
+    constexpr uint32_t kFinerBatchMinTiles = VoxShape<UV>::finer_min;
     __shared__ uint32_t s_leaf[kVoxTiles * kLeafStride];
     __shared__ uint32_t s_tleaf[kVoxTiles];
     __shared__ uint32_t s_tstart[kVoxTiles];
     __shared__ uint32_t s_tcount[kVoxTiles];
-    __shared__ uint32_t s_tprefix[kVoxTiles + 6];  // + total + padding for the four-entry window below
+    __shared__ uint32_t s_tprefix[kVoxTiles + 6];  // + total + padding for the four-entry window of phase 1
     __shared__ uint32_t s_scan[kVoxBlock / 64];
     __shared__ uint32_t s_tend;
-    __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-row chunk's first row
-    __shared__ float s_inv_dy[kVoxTiles];
+    __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-candidate chunk's first candidate
+    __shared__ float s_inv_dx[kVoxTiles], s_inv_dy[kVoxTiles];
+    __shared__ float s_margin[kVoxTiles];  // out_margin of the tile's leaf (piece_masks)
     __shared__ float s_satm[kVoxTiles];    // sat_margin of the tile's leaf (row_span)
     __shared__ uint32_t s_trow0[kVoxTiles];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
     __shared__ uint32_t s_rprefix[kVoxTiles + 6];  // rows before tile k (+ total + padding, as s_tprefix)
-    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_certain;
-    __shared__ unsigned long long s_list_base;
-    // staging queue of this workgroup: {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30 | lean << 31}
-    uint2 *stage = stage_all + (size_t) blockIdx.x * kQueueCap;
+    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct, s_certain;
+    // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
+    // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
+    // voxel (the long ones) are filed from the front, the others from the back, and the queue is served front to back:
+    // longest jobs first keeps the end of a sub-batch, when lanes run out of work, short.
+    uint2 *jobq = jobq_all + (size_t) blockIdx.x * kQueueCap;
+    __shared__ uint32_t s_next_x[kVoxBlock], s_next_y[kVoxBlock];  // every lane's prefetched next job record (take_job)
+    __shared__ uint8_t s_cls[64];    // classify_flags
+    __shared__ uint8_t s_kept[128];  // classify_kept: index | keep_lo << 6
 
     if (expand_overflowed(c, p)) return;
-    const bool occ_only = p.occupancy_only != 0u;
+    const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
+    // occupancy-only mode (Params::occupancy_only): a job is decided by its first surviving piece - splitTriangle only
+    // ever adds the leaf's area per surviving piece (voxelization.cpp:414-420), so the weight is non-zero from then on
+    const bool occ_only = !UV && p.occupancy_only != 0u;
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
-    // Batch size: about O2V_CAND_BATCHES batches per workgroup, between one tile per wavefront and what the LDS staging holds
-    // (a 96^3 job, a few thousand tiles, would otherwise keep 3 % of the machine busy).
-    uint32_t tiles_per_batch = (n_tiles + gridDim.x * O2V_CAND_BATCHES - 1u) / (gridDim.x * O2V_CAND_BATCHES);
-    tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch : (tiles_per_batch > kVoxTiles ? kVoxTiles : tiles_per_batch);
+    // Batch size: about kBatchesPerBlock batches per workgroup (VoxShape), between one tile per wavefront and what the LDS staging holds.  Few
+    // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
+    // of the machine busy); many small ones pay the per-batch staging and barriers too often.  Measured on seven
+    // workload shapes.
+    uint32_t tiles_per_batch = (n_tiles + gridDim.x * kBatchesPerBlock - 1u) / (gridDim.x * kBatchesPerBlock);
+    {
+        // large jobs: half as many tiles again per workgroup's share, as long as a batch still fills the workgroup's lanes
+        // twice over (shorter tail at the end of the kernel; measured -2 % on the bench mesh, -7 % on the low-poly sphere)
+        const uint32_t finer = (n_tiles + gridDim.x * kBatchesPerBlockLarge - 1u) / (gridDim.x * kBatchesPerBlockLarge);
+        if (finer >= kFinerBatchMinTiles) tiles_per_batch = finer;
+    }
+    tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
+                      : (tiles_per_batch > kVoxTiles ? kVoxTiles : tiles_per_batch);
     const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_certain = 0;
+    uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
+#ifdef O2V_INSTRUMENT
+    uint32_t dbgc[16] = {};
+    unsigned long long tmr[4] = {0, 0, 0, 0};  // cycles: staging + phase 1 | phase 2 loop | waiting at the barrier after phase 2 | whole kernel
+    unsigned long long t_mark = __builtin_readcyclecounter();
+    const unsigned long long t_kernel0 = t_mark;
+    auto lap = [&](int which) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        tmr[which] += now - t_mark;
+        t_mark = now;
+    };
+#define O2V_LAP(i) lap(i)
+#else
+#define O2V_LAP(i) do { } while (0)
+#endif
+    if (threadIdx.x == 0) {
+        s_hits = 0;
+        s_direct = 0;
+        s_certain = 0;
+    }
+    if (threadIdx.x < 64u) s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
+    for (uint32_t i = threadIdx.x; i < 128u; i += kVoxBlock) s_kept[i] = (uint8_t) classify_kept(i & 63u, i >= 64u);
 
     for (;;) {
         __syncthreads();
@@ -531,7 +641,7 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
         uint32_t my_count = 0, my_rows = 0;
         if (threadIdx.x < nt) {
             const uint32_t *lf = &s_leaf[threadIdx.x * kLeafStride];
-            const uint32_t dx = lf[kLfBminZDx] >> 16, dy = lf[kLfDyDz] & 0xffffu, dz = lf[kLfDyDz] >> 16;
+            const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
             const uint32_t rem = dx * dy * dz - s_tstart[threadIdx.x];
             my_count = rem < kTileSize ? rem : kTileSize;
             // bit 31: every coordinate of the leaf is finite and below kSmallCoord (see piece_masks)
@@ -541,33 +651,35 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
             // bit 30: the job's divisions may take the lean forms (accumulate_piece); without uv only the cut parameter is
             // divided, for which `small` is all that is needed
             bool lean_ok = is_small;
-            if (uv) {
-                const float a = __uint_as_float(lf[kLfArea]);
+            if (UV) {
+                const float a = __uint_as_float(lf[23]);
                 float uvmax = 0.f;
 #pragma unroll
-                for (int i = (int) kLfT; i < (int) kLfT + 6; ++i) uvmax = fmaxf(uvmax, abs_f(__uint_as_float(lf[i])));
+                for (int i = 12; i < 18; ++i) uvmax = fmaxf(uvmax, abs_f(__uint_as_float(lf[i])));
                 float uvsum = 0.f;
 #pragma unroll
-                for (int i = (int) kLfT; i < (int) kLfT + 6; ++i) uvsum += __uint_as_float(lf[i]);  // NaN if any uv is NaN (fmaxf ignores NaN operands)
+                for (int i = 12; i < 18; ++i) uvsum += __uint_as_float(lf[i]);  // NaN if any uv is NaN (fmaxf ignores NaN operands)
                 lean_ok = lean_ok && a >= kLeanAreaMin && a <= kLeanAreaMax && uvmax <= kLeanUv && uvsum == uvsum;
             }
             s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u) | (lean_ok ? 0x40000000u : 0u);
+            s_margin[threadIdx.x] = out_margin(m);
             s_satm[threadIdx.x] = sat_margin(m);
-            if (occ_only) {
+            if (!UV && occ_only) {
                 // the certain-hit test's per-leaf part goes where the staged leaf keeps its uv coordinates (unused without uv)
                 uint32_t *lw = &s_leaf[threadIdx.x * kLeafStride];
                 const CertainPrep cp = certain_prepare(V3{__uint_as_float(lw[0]), __uint_as_float(lw[1]), __uint_as_float(lw[2])},
                                                        V3{__uint_as_float(lw[3]), __uint_as_float(lw[4]), __uint_as_float(lw[5])},
                                                        V3{__uint_as_float(lw[6]), __uint_as_float(lw[7]), __uint_as_float(lw[8])},
-                                                       V3{__uint_as_float(lw[kLfN]), __uint_as_float(lw[kLfN + 1]), __uint_as_float(lw[kLfN + 2])}, m, is_small,
-                                                       __uint_as_float(lw[kLfArea]));
-                lw[kLfT] = __float_as_uint(cp.m00);
-                lw[kLfT + 1] = __float_as_uint(cp.m01);
-                lw[kLfT + 2] = __float_as_uint(cp.m10);
-                lw[kLfT + 3] = __float_as_uint(cp.m11);
-                lw[kLfT + 4] = __float_as_uint(cp.tau);
-                lw[kLfT + 5] = cp.axis;
+                                                       V3{__uint_as_float(lw[9]), __uint_as_float(lw[10]), __uint_as_float(lw[11])}, m, is_small,
+                                                       __uint_as_float(lw[23]));
+                lw[12] = __float_as_uint(cp.m00);
+                lw[13] = __float_as_uint(cp.m01);
+                lw[14] = __float_as_uint(cp.m10);
+                lw[15] = __float_as_uint(cp.m11);
+                lw[16] = __float_as_uint(cp.tau);
+                lw[17] = cp.axis;
             }
+            s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
             if (my_count) {
                 const uint32_t start = s_tstart[threadIdx.x];
@@ -605,10 +717,12 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
             if (threadIdx.x == 0) {
                 s_nheavy = 0;
                 s_nlight = 0;
+                s_next = 0;
             }
             __syncthreads();
             const uint32_t t_end = s_tend;
 
+            // ---- phase 1: the sub-batch's candidate rows flattened over the lanes ---------------------------
             // A tile's candidates are a run of the leaf's clamped AABB in x-fastest order, i.e. a few rows (fixed y, z) of it.
             // A lane takes one row, solves the separating-axis test for x (row_span) and so names the row's surviving
             // voxels without visiting the others; the survivors of the wavefront's 64 rows are then flattened over the
@@ -623,6 +737,7 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
                     for (uint32_t ch = (lo + 63u) / 64u; ch * 64u < hi; ++ch) s_chunk_tile[ch] = (uint8_t) threadIdx.x;
             }
             __syncthreads();
+            O2V_LAP(0);
             // Few long rows (large axis-aligned leaves): every wavefront looks at the same 64 rows and they share the
             // survivors, 64 at a time; otherwise each wavefront has its own rows.
             const bool shared_rows = s_tprefix[t_end] - base_cand > 32u * n_rows;
@@ -638,7 +753,7 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
                         while (s_rprefix[k + 1] <= gg) ++k;
                     const uint32_t i_row = gg - s_rprefix[k], last_row = s_rprefix[k + 1] - s_rprefix[k] - 1u;
                     const uint32_t *lf = &s_leaf[k * kLeafStride];
-                    const uint32_t dx = lf[kLfBminZDx] >> 16, dy = lf[kLfDyDz] & 0xffffu, dz = lf[kLfDyDz] >> 16;
+                    const uint32_t dx = lf[21] >> 16, dy = lf[22] & 0xffffu, dz = lf[22] >> 16;
                     const uint32_t row = s_trow0[k] + i_row;
                     if (row < (1u << 24)) {
                         // exact quotient from a float estimate (row < 2^24, divisor < 2^16): off by at most one
@@ -659,7 +774,7 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
                     x_first = xlo;
                     n_out = xhi - xlo + 1u;
                     if (s_tcount[k] >> 31) {
-                        const float ox = (float) (lf[kLfBminXy] & 0xffffu), oy = (float) (lf[kLfBminXy] >> 16), oz = (float) (lf[kLfBminZDx] & 0xffffu);
+                        const float ox = (float) (lf[20] & 0xffffu), oy = (float) (lf[20] >> 16), oz = (float) (lf[21] & 0xffffu);
                         const V3 p0{__uint_as_float(lf[0]) - ox, __uint_as_float(lf[1]) - oy, __uint_as_float(lf[2]) - oz};
                         const V3 p1{__uint_as_float(lf[3]) - ox, __uint_as_float(lf[4]) - oy, __uint_as_float(lf[5]) - oz};
                         const V3 p2{__uint_as_float(lf[6]) - ox, __uint_as_float(lf[7]) - oy, __uint_as_float(lf[8]) - oz};
@@ -704,22 +819,22 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
                     if (o < total) {
                         const uint32_t kk = r_xk >> 16, lx = (r_xk & 0xffffu) + (o - r_exc);
                         const uint32_t *lf = &s_leaf[kk * kLeafStride];
-                        const uint32_t qx = (lf[kLfBminXy] & 0xffffu) + lx, qy = (lf[kLfBminXy] >> 16) + (r_yz & 0xffffu), qz = (lf[kLfBminZDx] & 0xffffu) + (r_yz >> 16);
+                        const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + (r_yz & 0xffffu), qz = (lf[21] & 0xffffu) + (r_yz >> 16);
                         const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
                         const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
                         const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
-                        const V3 nrm{__uint_as_float(lf[kLfN]), __uint_as_float(lf[kLfN + 1]), __uint_as_float(lf[kLfN + 2])};
+                        const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
                         // plane distance cull, voxelization.cpp:451-458
                         const V3 rel = V3{(float) qx + 0.5f, (float) qy + 0.5f, (float) qz + 0.5f} - v0;
                         const float sd = dot(nrm, rel);
                         keep = !(abs_f(sd) > kPlaneDistanceLimit);
-                        if (occ_only && keep) {
+                        if (!UV && occ_only && keep) {
                             // certain hit (see certain_prepare): no voxel job, the voxel is marked here.  Tried are the columns
-                            // through kN lines across the voxel (every quantity of the test is linear in the offset along a
-                            // line); the lines stay inside the voxel by the margin D.
-                            const uint32_t axis = lf[kLfT + 5];
+                            // through a 5 x 5 lattice of points around the voxel centre (every quantity of the test is linear in
+                            // the offset); the lattice stays inside the voxel by the margin D.
+                            const uint32_t axis = lf[17];
                             const uint32_t iu = axis == 0u ? 1u : 0u, iw = axis == 2u ? 1u : 2u;
-                            const float tau = __uint_as_float(lf[kLfT + 4]);
+                            const float tau = __uint_as_float(lf[16]);
                             if (tau < 0.34f) {  // (else no point of the leaf is far enough from its edges)
                                 const float lim = 0.5f - (1.5f * s_satm[kk] + 1e-3f);  // 0.5 - D, D = certain_margin(m)
                                 // kN lines across the voxel (constant offset in the second lattice axis); along a line every
@@ -728,7 +843,7 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
                                 constexpr int kN = O2V_CERTAIN_N;
                                 const float half = 0.5f * (float) (kN - 1);
                                 const float step = fminf(O2V_CERTAIN_STEP, lim / fmaxf(half, 0.5f));
-                                const float m00 = __uint_as_float(lf[kLfT]), m01 = __uint_as_float(lf[kLfT + 1]), m10 = __uint_as_float(lf[kLfT + 2]), m11 = __uint_as_float(lf[kLfT + 3]);
+                                const float m00 = __uint_as_float(lf[12]), m01 = __uint_as_float(lf[13]), m10 = __uint_as_float(lf[14]), m11 = __uint_as_float(lf[15]);
                                 const float rnd = __builtin_amdgcn_rcpf(comp(nrm, axis));
                                 const float tu = comp(nrm, iu) * rnd, tw = comp(nrm, iw) * rnd * step;  // dt per unit of o / per line
                                 const float pu = comp(rel, iu), pw = comp(rel, iw) - half * step;       // the first line's centre
@@ -781,7 +896,7 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
                             heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
                         }
                     }
-                    if (occ_only) {
+                    if (!UV && occ_only) {
                         const unsigned long long mc = __ballot(certain);
                         if (mc && lane == 0) atomicAdd(&s_certain, (uint32_t) __popcll(mc));
                     }
@@ -797,509 +912,315 @@ __global__ __launch_bounds__(kCandBlock) void k_candidates(const Leaf *__restric
                         if (keep) {
                             const uint32_t at = heavy ? base_h + __builtin_amdgcn_mbcnt_hi((uint32_t) (mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mh, 0u))
                                                       : kQueueCap - 1u - (base_l + __builtin_amdgcn_mbcnt_hi((uint32_t) (ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ml, 0u)));
-                            stage[at] = rec;
+                            jobq[at] = rec;
                         }
                     }
                 }
             }
             __syncthreads();  // (workgroup scope: the records written above are visible to every wavefront of the workgroup)
-            // the sub-batch's survivors move to the job list: one reservation, heavy jobs first
             const uint32_t n_heavy = s_nheavy, n_surv = n_heavy + s_nlight;
-            if (threadIdx.x == 0 && n_surv) s_list_base = atomicAdd(&c->n_jobs, (unsigned long long) n_surv);
-            __syncthreads();
-            if (n_surv) {
-                const unsigned long long list_base = s_list_base;
-                for (uint32_t i = threadIdx.x; i < n_surv; i += kVoxBlock) {
-                    const uint2 rec = stage[i < n_heavy ? i : kQueueCap - 1u - (i - n_heavy)];
-                    const unsigned long long at = list_base + i;
-                    if (at < (unsigned long long) p.cap_jobs) {
-                        jobs.xy[at] = rec.x;
-                        jobs.zf[at] = (rec.y & 0xffffu) | (((rec.y >> 24) & 63u) << kJobCfShift) | (((rec.y >> 30) & 1u) ? kJobSmallBit : 0u) |
-                                      ((rec.y >> 31) ? kJobLeanBit : 0u);
-                        jobs.leaf[at] = s_tleaf[(rec.y >> 16) & 255u];
-                    }
-                }
-            }
-            t_begin = t_end;
-        }
-    }
-    __syncthreads();
-    // (a certain hit is a hit, a direct one, and a voxel job that did not have to run)
-    if (threadIdx.x == 0 && s_certain) {
-        atomicAdd(&c->n_hits, (unsigned long long) s_certain);
-        atomicAdd(&c->n_direct, (unsigned long long) s_certain);
-        atomicAdd(&c->n_certain, (unsigned long long) s_certain);
-    }
-}
+            if (threadIdx.x == 0 && n_surv) atomicAdd(&c->n_jobs, (unsigned long long) n_surv);
 
-// K2, phase 2.  One wavefront per workgroup, persistent; wavefront w of W walks the 64-job chunks w, w + W, ... of the job
-// list (a static deal: no atomics; the chunks of one wavefront are spread over the whole list, so the wavefronts' shares
-// cost the same to within a few per cent) and its lanes pull the jobs of that sequence one by one: a lane that finishes
-// a job takes the sequence's next one, so the wavefront stays full until its share is used up - once per launch.
-// Every lane holds its next job one ahead: the record is requested (LDS-DMA, see take_jobs) when the lane starts a job and
-// looked at when that job is done; the job's leaf (vertices, uv, area) is then loaded from the leaf array, which the
-// neighbouring jobs of the list share (L1 / L2 hits).
-// A job is computeTrianglesUvInVoxel (voxelization.cpp:383-424) as a depth-first walk of the split tree: the reference clips
-// level by level with two 64-entry buffers; visiting the first emitted piece first reproduces its buffer order, so the
-// running mean of :414-420 accumulates in the identical sequence.  Under DISCARD every split keeps <= 2 pieces, so at most
-// one sibling per level 1..5 is pending: the stack of pending pieces lives in LDS, one column per lane (dword k of slot s of
-// lane l at ((s * piece_dw + k) * 64 + l): every access is conflict-free and needs no select), the first ClipShape::lds_slots
-// levels there, deeper ones (1 % of the pushes without uv) in a small per-lane overflow array (scratch memory).  Every piece
-// carries the set of planes it does not pass whole (piece_masks); per iteration a lane classifies its piece against the first
-// of them and cuts it, and the kept pieces are judged at once from their bounding boxes: final (accumulated), beyond a later
-// plane (dropped with its whole subtree), one plane left (without uv: settled from its classification, see single_plane), or
-// to be cut again.  So lanes spend their iterations only on cuts whose pieces are needed.
-#ifndef O2V_K2_WAVES
-#define O2V_K2_WAVES 4
-#endif
-#ifndef O2V_K2_WAVES_UV
-#define O2V_K2_WAVES_UV 4
-#endif
-// Stack levels in LDS / in a register slot (the rest, up to kStackLevels, in scratch).  LDS per wavefront (160 KiB per CU, 16
-// wavefronts): without uv 2 x 2304 (stack) + 3072 (next leaf) + 768 (next record) + 192 (tables) = 8.4 KiB; with uv 3840 +
-// 4608 + 768 + 192 = 9.2 KiB.
-#ifndef O2V_STACK_LDS
-#define O2V_STACK_LDS 2
-#endif
-#ifndef O2V_STACK_LDS_UV
-#define O2V_STACK_LDS_UV 1
-#endif
-#ifndef O2V_STACK_REG
-#define O2V_STACK_REG 1
-#endif
-#ifndef O2V_STACK_REG_UV
-#define O2V_STACK_REG_UV 1
-#endif
-constexpr uint32_t kStackLevels = 5;
-template <bool UV>
-struct ClipShape {
-    static constexpr uint32_t piece_dw = UV ? 15u : 9u;                                // dwords of a piece
-    static constexpr uint32_t lds_slots = UV ? O2V_STACK_LDS_UV : O2V_STACK_LDS;       // stack levels kept in LDS
-    static constexpr uint32_t reg_slots = UV ? O2V_STACK_REG_UV : O2V_STACK_REG;       // the next level: a register slot (0 or 1)
-    static constexpr uint32_t waves = UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES;             // wavefronts per SIMD
-    static constexpr uint32_t leaf_granules = UV ? 4u : 3u;  // 16-byte pieces of a leaf prefetched per job: v, area, tri, key (, t[0..3])
-    static_assert(lds_slots >= 1u && reg_slots <= 1u && lds_slots + reg_slots <= kStackLevels, "stack levels");
-};
-
-template <bool UV>
-__device__ __forceinline__ void stack_write(float *col /* this lane's column of the slot */, const Piece<UV> &pc)
-{
-    col[0 * 64] = pc.a.x; col[1 * 64] = pc.a.y; col[2 * 64] = pc.a.z;
-    col[3 * 64] = pc.b.x; col[4 * 64] = pc.b.y; col[5 * 64] = pc.b.z;
-    col[6 * 64] = pc.c.x; col[7 * 64] = pc.c.y; col[8 * 64] = pc.c.z;
-    if (UV) {
-        col[9 * 64] = pc.ta.x; col[10 * 64] = pc.ta.y;
-        col[11 * 64] = pc.tb.x; col[12 * 64] = pc.tb.y;
-        col[13 * 64] = pc.tc.x; col[14 * 64] = pc.tc.y;
-    }
-}
-template <bool UV>
-__device__ __forceinline__ Piece<UV> stack_read(const float *col)
-{
-    Piece<UV> pc{};
-    pc.a = {col[0 * 64], col[1 * 64], col[2 * 64]};
-    pc.b = {col[3 * 64], col[4 * 64], col[5 * 64]};
-    pc.c = {col[6 * 64], col[7 * 64], col[8 * 64]};
-    if (UV) {
-        pc.ta = {col[9 * 64], col[10 * 64]};
-        pc.tb = {col[11 * 64], col[12 * 64]};
-        pc.tc = {col[13 * 64], col[14 * 64]};
-    }
-    return pc;
-}
-
-// LDS-DMA (global memory straight into LDS: lane l's 4 / 16 bytes land at lds_base + 4 l / 16 l; no destination register)
-__device__ __forceinline__ void lds_dma4(const void *src, void *lds_base_wave_uniform)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
-                                     (__attribute__((address_space(3))) void *) lds_base_wave_uniform, 4, 0, 0);
-}
-__device__ __forceinline__ void lds_dma16(const void *src, void *lds_base_wave_uniform)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
-                                     (__attribute__((address_space(3))) void *) lds_base_wave_uniform, 16, 0, 0);
-}
-
-template <bool UV>
-__global__ __launch_bounds__(64, ClipShape<UV>::waves) void k_voxelize(const Leaf *__restrict__ leaves, JobList jobs, Counters *c, uint32_t *grid,
-                                                                      uint8_t *brick_dirty, HitRec *pool, Params p)
-{
-    constexpr uint32_t kPieceDw = ClipShape<UV>::piece_dw, kLdsSlots = ClipShape<UV>::lds_slots, kRegSlots = ClipShape<UV>::reg_slots;
-    constexpr uint32_t kGranules = ClipShape<UV>::leaf_granules;
-    __shared__ float s_stack[kLdsSlots * kPieceDw * 64u];
-    __shared__ uint4 s_nleaf[kGranules * 64u];     // every lane's prefetched next leaf: granule g of lane l at [g * 64 + l]
-    __shared__ float s_nleaf_t45[UV ? 128 : 2];    // ... its t[4], t[5] (uv variant)
-    __shared__ uint32_t s_next_a[64], s_next_b[64], s_next_c[64];  // every lane's prefetched record after that (advance)
-    __shared__ uint8_t s_cls[64];    // classify_flags
-    __shared__ uint8_t s_kept[128];  // classify_kept: index | keep_lo << 6
-
-    if (expand_overflowed(c, p)) return;
-    const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
-    // occupancy-only mode (Params::occupancy_only): a job is decided by its first surviving piece - splitTriangle only
-    // ever adds the leaf's area per surviving piece (voxelization.cpp:414-420), so the weight is non-zero from then on
-    const bool occ_only = !UV && p.occupancy_only != 0u;
-    const unsigned long long n_listed = c->n_jobs;
-    const uint32_t n_list = n_listed < (unsigned long long) p.cap_jobs ? (uint32_t) n_listed : p.cap_jobs;
-    const uint32_t n_chunks = (n_list + 63u) / 64u;
-    const uint32_t lane = threadIdx.x;
-    uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
-    uint32_t n_hits_wave = 0, n_direct_wave = 0;      // wave-uniform
-#ifdef O2V_INSTRUMENT
-    uint32_t dbgc[16] = {};
-    unsigned long long tmr[4] = {0, 0, 0, 0};  // cycles: - | clip loop | - | whole kernel
-    const unsigned long long t_kernel0 = __builtin_readcyclecounter();
-#endif
-    s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
-    s_kept[threadIdx.x] = (uint8_t) classify_kept(threadIdx.x, false);
-    s_kept[threadIdx.x + 64u] = (uint8_t) classify_kept(threadIdx.x, true);
-    __syncthreads();
-    if (blockIdx.x < n_chunks) {
-        float *const my_col = &s_stack[lane];
-        Piece<UV> cur{}, sec{};
-        Piece<UV> rslot{};                                             // stack level kLdsSlots (if kRegSlots)
-        Piece<UV> overflow[kStackLevels - kLdsSlots - kRegSlots + 1u];  // deeper levels (+ 1: never of size zero)
-        uint32_t sp = 0;     // pending siblings of this lane's job
-        uint32_t cf = 0;     // planes the current piece does not pass whole (bit = level), see piece_masks
-        uint32_t pmask = 0;  // the same for the pending siblings: 6 bits per stack entry
-        bool active = false, has_job = false, small = false;
-        bool lean = false;   // this job's divisions may take the lean forms (lean_ok in k_candidates)
-        float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
-        float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
-        float margin = 0.f;                  // out_margin of the job's leaf
-        uint32_t pos_xy = 0, pos_z = 0, my_tri = 0, my_key = 0;  // voxel x | y << 16, z; the leaf's triangle and order key
-        // The job sequence of this wavefront: chunk `seq_chunk` of the list, `seq_used` of its 64 jobs handed out.
-        uint32_t seq_chunk = blockIdx.x, seq_used = 0;  // wave-uniform
-        // Every lane is two jobs ahead of the one it works on:
-        //   job N + 1  its record is in registers (nx_*), its leaf on the way into the lane's LDS slot s_nleaf
-        //   job N + 2  its record on the way into the lane's LDS slot s_next_*
-        // All of it is requested when the lane starts job N and looked at when that job is done, so neither the list (read
-        // once, from HBM) nor the leaves (L2 or HBM) are waited for.  The loads are LDS-DMA (global_load_lds: no destination
-        // register, so nothing the register allocator does can touch data in flight).  The wait before the slots are read is
-        // explicit: hipcc (ROCm 7.2) does track LDS-DMA for its own s_waitcnt placement, but across the loop's back edge it
-        // put the wait in front of the wrong LDS reads (seen in the compiled code: the slot was read first).
-        uint32_t nx_xy = 0, nx_zf = 0, nx_leaf = 0;
-        bool next_valid = false, next2_valid = false;
-        auto request_record = [&](bool who) {  // (called by the whole wavefront) the list's next jobs for the lanes in `who`
-            const unsigned long long m = __ballot(who);
-            if (!m) return;
-            uint32_t idx = seq_used + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-            uint32_t ch = seq_chunk;
-            if (idx >= 64u) {
-                idx -= 64u;
-                ch += gridDim.x;
-            }
-            if (who) {
-                // (ch < n_chunks <= 2^26: the product cannot wrap)
-                const uint32_t j = ch * 64u + idx;
-                next2_valid = ch < n_chunks && j < n_list;
-                if (next2_valid) {
-                    lds_dma4(jobs.xy + j, &s_next_a[0]);
-                    lds_dma4(jobs.zf + j, &s_next_b[0]);
-                    lds_dma4(jobs.leaf + j, &s_next_c[0]);
-                }
-            }
-            seq_used += (uint32_t) __popcll(m);
-            if (seq_used >= 64u) {
-                seq_used -= 64u;
-                // (saturating: a wavefront past the end of the list stays there)
-                seq_chunk = seq_chunk < n_chunks ? seq_chunk + gridDim.x : seq_chunk;
-            }
-        };
-        // (called by the whole wavefront; the DMA of the lanes in `who` has landed: s_waitcnt vmcnt(0) since it was issued)
-        auto advance = [&](bool who) {
-            if (!__ballot(who)) return;
-            if (who) {
-                next_valid = next2_valid;
+            O2V_LAP(2);
+            // ---- phase 2: persistent lanes ------------------------------------------------------------------
+            Piece<UV> cur{}, sec{};
+            PieceStack<UV> stack{};
+            Piece<UV> overflow[kStackLevels - stack_regs<UV>()];
+            uint32_t sp = 0, my_k = 0;  // sp: pending siblings of this lane's job; my_k: its tile slot
+            uint32_t cf = 0;     // planes the current piece does not pass whole (bit = level), see piece_masks
+            uint32_t pmask = 0;  // the same for the pending siblings: 6 bits per stack entry
+            bool active = false, has_job = false, small = false;
+            bool lean = false;   // this job's divisions may take the lean forms (lean_ok at staging)
+            float w = 0.f, u = 0.f, v = 0.f, area = 0.f;
+            float fx = 0.f, fy = 0.f, fz = 0.f;  // float(pos): the lower planes; upper planes are +1
+            float margin = 0.f;                  // out_margin of the job's leaf
+            uint32_t pos_xy = 0, pos_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
+            // Every lane holds its next job one ahead: the record is requested from the queue (an LDS ticket, then a load
+            // that L2 answers) when the lane starts a job and is only looked at when that job is done.  The load goes
+            // straight into the lane's LDS slot (global_load_lds: no destination register, so nothing the register
+            // allocator does can touch data in flight).  The wait before the slot is read is explicit: hipcc (ROCm 7.2) does
+            // track LDS-DMA for its own s_waitcnt placement, but across the loop's back edge it put the wait in front of
+            // the wrong LDS reads (seen in the compiled code: the slot was read first).  A stricter-than-needed vmcnt(0)
+            // costs nothing here: the lane's only other loads in flight are those of a rare stack overflow.
+            bool next_valid = false;
+            auto take_job = [&]() {
+                const uint32_t q = atomicAdd(&s_next, 1u);
+                next_valid = q < n_surv;
                 if (next_valid) {
-                    nx_xy = s_next_a[lane];
-                    nx_zf = s_next_b[lane];
-                    nx_leaf = s_next_c[lane];
+                    const uint2 *src = jobq + (q < n_heavy ? q : kQueueCap - 1u - (q - n_heavy));
+                    // (LDS address = the wave-uniform base + 4 x lane)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) &src->x,
+                                                     (__attribute__((address_space(3))) void *) &s_next_x[threadIdx.x & ~63u], 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) &src->y,
+                                                     (__attribute__((address_space(3))) void *) &s_next_y[threadIdx.x & ~63u], 4, 0, 0);
                 }
-            }
-            // (the slots - also the leaf slot the caller has just read - are free once their reads have returned)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (who && next_valid) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(leaves + nx_leaf);
-#pragma unroll
-                for (uint32_t g = 0; g < kGranules; ++g) lds_dma16(src + g, &s_nleaf[g * 64u]);
-                if (UV) {
-                    lds_dma4(reinterpret_cast<const float *>(src) + kLfT + 4, &s_nleaf_t45[0]);
-                    lds_dma4(reinterpret_cast<const float *>(src) + kLfT + 5, &s_nleaf_t45[UV ? 64 : 1]);
+            };
+            auto job_record = [&]() {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                return make_uint2(s_next_x[threadIdx.x], s_next_y[threadIdx.x]);
+            };
+            take_job();
+            // parked result of this lane's last finished hit
+            float d_w = 0.f, d_u = 0.f, d_v = 0.f;
+            uint32_t d_xy = 0, d_zk = 0;  // voxel x | y << 16, z | tile slot << 16 (all below 2^16)
+            bool d_valid = false;
+            auto flush_results = [&]() {
+                const unsigned long long all = __ballot(d_valid);
+                if (!all) return;
+                // Direct MAX path: a hit of an unsplit triangle (order key 0: its only leaf) is the triangle's whole weight in
+                // this (sub-)voxel, so it competes at once - one 64-bit atomic max on the cell, no hit record.  Hits of
+                // subdivided triangles still go through the pool (their leaves' weights must be added up in order first).
+                // (occupancy-only mode: any hit marks the voxel, also those of subdivided triangles)
+                const bool direct = d_valid && use_direct && (occ_only || s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u);
+                // with textures a direct hit still leaves a record behind: {cell, key, colour} for k_pick
+                const bool pooled = d_valid && (UV || !direct);
+                const unsigned long long mask = __ballot(pooled);
+                const uint32_t cnt = (uint32_t) __popcll(mask);
+                const uint32_t leader = mask ? (uint32_t) __ffsll((long long) mask) - 1u : 0u;
+                if (cnt && chunk_used + cnt > kHitChunk) {
+                    // abandon the rest of the chunk (marked as holes for the scatter pass) and reserve a new one
+                    const uint32_t hole = chunk_base + chunk_used + lane;
+                    if (chunk_used + lane < kHitChunk && hole < p.cap_hits) pool[hole].brick = kHoleBrick;
+                    if (chunk_used + 64u + lane < kHitChunk && hole + 64u < p.cap_hits) pool[hole + 64u].brick = kHoleBrick;
+                    if (chunk_used + 128u + lane < kHitChunk && hole + 128u < p.cap_hits) pool[hole + 128u].brick = kHoleBrick;
+                    if (chunk_used + 192u + lane < kHitChunk && hole + 192u < p.cap_hits) pool[hole + 192u].brick = kHoleBrick;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
+                    chunk_base = __shfl(base, (int) leader, 64);
+                    chunk_used = 0;
                 }
-            }
-            request_record(who);
-        };
-        request_record(true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        advance(true);
-        // parked result of this lane's last finished hit
-        float d_w = 0.f, d_u = 0.f, d_v = 0.f;
-        uint32_t d_xy = 0, d_z = 0, d_tri = 0, d_key = 0;  // voxel x | y << 16, z; triangle, order key of the leaf
-        bool d_valid = false;
-        auto flush_results = [&]() {
-            const unsigned long long all = __ballot(d_valid);
-            if (!all) return;
-            // Direct MAX path: a hit of an unsplit triangle (order key 0: its only leaf) is the triangle's whole weight in
-            // this (sub-)voxel, so it competes at once - one 64-bit atomic max on the cell, no hit record.  Hits of
-            // subdivided triangles still go through the pool (their leaves' weights must be added up in order first).
-            // (occupancy-only mode: any hit marks the voxel, also those of subdivided triangles)
-            const bool direct = d_valid && use_direct && (occ_only || d_key == 0u);
-            // with textures a direct hit still leaves a record behind: {cell, key, colour} for k_pick
-            const bool pooled = d_valid && (UV || !direct);
-            const unsigned long long mask = __ballot(pooled);
-            const uint32_t cnt = (uint32_t) __popcll(mask);
-            const uint32_t leader = mask ? (uint32_t) __ffsll((long long) mask) - 1u : 0u;
-            if (cnt && chunk_used + cnt > kHitChunk) {
-                // abandon the rest of the chunk (marked as holes for the scatter pass) and reserve a new one
-                const uint32_t hole = chunk_base + chunk_used + lane;
-                if (chunk_used + lane < kHitChunk && hole < p.cap_hits) pool[hole].brick = kHoleBrick;
-                if (chunk_used + 64u + lane < kHitChunk && hole + 64u < p.cap_hits) pool[hole + 64u].brick = kHoleBrick;
-                if (chunk_used + 128u + lane < kHitChunk && hole + 128u < p.cap_hits) pool[hole + 128u].brick = kHoleBrick;
-                if (chunk_used + 192u + lane < kHitChunk && hole + 192u < p.cap_hits) pool[hole + 192u].brick = kHoleBrick;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&c->n_hits_reserved, kHitChunk);
-                chunk_base = __shfl(base, (int) leader, 64);
-                chunk_used = 0;
-            }
-            const uint32_t mine = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-            chunk_used += cnt;
-            if (d_valid) {
-                const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_z;
-                const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
-                uint32_t brick;
-                const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
-                const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
-                const uint32_t keyhi = (sub << 29) | d_tri;
-                if (direct && occ_only) {
-                    // occupancy only: the voxel is hit, nothing else about it matters (plain stores; benign races: every
-                    // writer stores the same value)
-                    p.occgrid[cell] = 1;
-                    p.dirty_max[brick] = 1;
-                }
-                else if (direct) {
-                    atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
-                    p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
-                    if (UV && mine < p.cap_hits) {
-                        // the triangle is unsplit, so (d_u, d_v) already is its whole uv mean in this voxel; k_pick looks the
-                        // colour up (moveUvBufferIntoVoxels, voxelization.cpp:513-526) for the cell's winner only
-                        pool[mine] = HitRec{brick, ((uint32_t) cell & (kBrickCells - 1u)) << 24, keyhi, 0u, d_w, d_u, d_v, kPickRecord};
+                const uint32_t mine = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+                chunk_used += cnt;
+                if (d_valid) {
+                    const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
+                    const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
+                    const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
+                    uint32_t brick;
+                    const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                    const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
+                    const uint32_t keyhi = (sub << 29) | lf[18];
+                    if (direct && occ_only) {
+                        // occupancy only: the voxel is hit, nothing else about it matters (plain stores; benign races: every
+                        // writer stores the same value)
+                        p.occgrid[cell] = 1;
+                        p.dirty_max[brick] = 1;
+                    }
+                    else if (direct) {
+                        atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
+                        p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
+                        if (UV && mine < p.cap_hits) {
+                            // the triangle is unsplit, so (d_u, d_v) already is its whole uv mean in this voxel; k_pick looks the
+                            // colour up (moveUvBufferIntoVoxels, voxelization.cpp:513-526) for the cell's winner only
+                            pool[mine] = HitRec{brick, ((uint32_t) cell & (kBrickCells - 1u)) << 24, keyhi, 0u, d_w, d_u, d_v, kPickRecord};
+                        }
+                    }
+                    else if (mine < p.cap_hits) {
+                        // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
+                        // (handing the ranks out in k_scatter instead - no wait here - was measured: k_voxelize -2 %, k_scatter
+                        // +13 % on configs[3])
+                        const uint32_t rank = atomicAdd(&grid[cell], 1u);
+                        if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
+                        brick_dirty[brick] = 1;  // benign race: every writer stores the same value
+                        if (use_direct) p.dirty_max[brick] = 1;  // the resolve kernels will add this cell's result
+                        pool[mine] = HitRec{brick, (((uint32_t) cell & (kBrickCells - 1u)) << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w,
+                                            d_u, d_v, 0u};
                     }
                 }
-                else if (mine < p.cap_hits) {
-                    // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
-                    // (handing the ranks out in k_scatter instead - no wait here - was measured: k_voxelize -2 %, k_scatter
-                    // +13 % on configs[3])
-                    const uint32_t rank = atomicAdd(&grid[cell], 1u);
-                    if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
-                    brick_dirty[brick] = 1;  // benign race: every writer stores the same value
-                    if (use_direct) p.dirty_max[brick] = 1;  // the resolve kernels will add this cell's result
-                    pool[mine] = HitRec{brick, (((uint32_t) cell & (kBrickCells - 1u)) << 24) | (rank & (kMaxRank - 1u)), keyhi, d_key, d_w,
-                                        d_u, d_v, 0u};
+                if (lane == 0) atomicAdd(&s_hits, (uint32_t) __popcll(all));
+                if (use_direct) {
+                    const unsigned long long dmask = __ballot(direct);
+                    if (lane == 0 && dmask) atomicAdd(&s_direct, (uint32_t) __popcll(dmask));
                 }
-            }
-            n_hits_wave += (uint32_t) __popcll(all);
-            if (use_direct) n_direct_wave += (uint32_t) __popcll(__ballot(direct));
-            d_valid = false;
-        };
+                d_valid = false;
+            };
 #ifdef O2V_INSTRUMENT
 #define O2V_EV(i, cond) do { if (cond) dbgc[i] += 1u; } while (0)
 #else
 #define O2V_EV(i, cond) do { } while (0)
 #endif
-        bool leaving = false;
-        for (;;) {
-            O2V_EV(0, lane == 0);
-            {
-                // lanes whose job ended in a hit park it (w, u, v, position) in their result registers; if a lane's
-                // registers are still taken, everything parked is appended first
-                const bool fin_hit = has_job && !active && sp == 0;
-                const unsigned long long dv = __ballot(d_valid);
-                if (__ballot(fin_hit && d_valid) || (uint32_t) __popcll(dv) >= kFlushAt || (leaving && dv)) flush_results();
-                if (leaving) break;
-                if (fin_hit) {
-                    d_w = w; d_u = u; d_v = v;
-                    d_xy = pos_xy;
-                    d_z = pos_z;
-                    d_tri = my_tri;
-                    d_key = my_key;
-                    d_valid = true;
-                    has_job = false;
-                }
-            }
-            // pop a pending sibling (with the plane mask it was pushed with), or start the next job
-            bool started = false;
-            if (!active) {
-                if (sp) {
-                    sp -= 1u;
-                    cur = stack_read<UV>(my_col + __umul24(sp < kLdsSlots ? sp : kLdsSlots - 1u, kPieceDw * 64u));
-                    if (kRegSlots && sp == kLdsSlots) cur = rslot;
-                    if (kLdsSlots + kRegSlots < kStackLevels && sp >= kLdsSlots + kRegSlots) cur = overflow[sp - kLdsSlots - kRegSlots];
-                    const uint32_t sh = __umul24(sp, 6u);  // 6 bits per entry
-                    cf = (pmask >> sh) & 63u;
-                    pmask &= ~(63u << sh);
-                    active = true;
-                }
-                else if (next_valid) {
-                    // the next job's record and leaf were fetched while this lane worked on the last one (advance below)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const uint4 q0 = s_nleaf[lane], q1 = s_nleaf[64u + lane], q2 = s_nleaf[128u + lane];
-                    cur.a = {__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
-                    cur.b = {__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
-                    cur.c = {__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
-                    area = __uint_as_float(q2.y);
-                    my_tri = q2.z;
-                    my_key = q2.w;
-                    if (UV) {
-                        const uint4 q3 = s_nleaf[(kGranules - 1u) * 64u + lane];
-                        cur.ta = {__uint_as_float(q3.x), __uint_as_float(q3.y)};
-                        cur.tb = {__uint_as_float(q3.z), __uint_as_float(q3.w)};
-                        cur.tc = {s_nleaf_t45[UV ? lane : 0u], s_nleaf_t45[UV ? 64u + lane : 1u]};
-                    }
-                    pos_xy = nx_xy;
-                    pos_z = nx_zf & 0xffffu;
-                    fx = (float) (nx_xy & 0xffffu);
-                    fy = (float) (nx_xy >> 16);
-                    fz = (float) pos_z;
-                    cf = (nx_zf >> kJobCfShift) & 63u;
-                    small = (nx_zf & kJobSmallBit) != 0u;
-                    lean = (nx_zf & kJobLeanBit) != 0u;
-                    {
-                        // out_margin of the leaf (piece_masks; only used if the leaf is `small`, i.e. all coordinates finite)
-                        const float m = fmaxf(fmaxf(fmaxf(abs_f(cur.a.x), abs_f(cur.a.y)), fmaxf(abs_f(cur.a.z), abs_f(cur.b.x))),
-                                              fmaxf(fmaxf(fmaxf(abs_f(cur.b.y), abs_f(cur.b.z)), fmaxf(abs_f(cur.c.x), abs_f(cur.c.y))), abs_f(cur.c.z)));
-                        margin = out_margin(m);
-                    }
-                    w = 0.f;
-                    u = 0.f;
-                    v = 0.f;
-                    active = true;
-                    has_job = true;
-                    started = true;
-                }
-            }
-            advance(started);
-            // (wave-uniform: one job that needs the compiler's division sends the whole wavefront that way for the iteration)
-            const bool lean_all = __ballot(active && !lean) == 0ull;
-            O2V_EV(1, active);
-#ifdef O2V_INSTRUMENT
-            {
-                const uint32_t na = (uint32_t) __popcll(__ballot(active));
-                O2V_EV(4, lane == 0 && na <= 16u);
-                O2V_EV(6, lane == 0 && na <= 32u);
-            }
-#endif
-            if (active) {
-                // `cf` names the planes (bit = level: lo x, y, z, hi x, y, z) this piece does not pass whole; all others
-                // are the loSum == 0 / loSum == 3 case of splitTriangle (voxelization.cpp:194-205), which hands the
-                // triangle on unchanged, so they are skipped.
-                if (cf == 0u) {
-                    O2V_EV(2, true);
-                    accumulate_piece<UV>(cur, area, w, u, v, lean_all);  // inside all remaining planes
-                    active = false;
-                    if (occ_only) {
-                        sp = 0;
-                        pmask = 0;
+            bool leaving = false;
+            for (;;) {
+                O2V_EV(0, lane == 0);
+                {
+                    // lanes whose job ended in a hit park it (w, u, v, position) in their result registers; if a lane's
+                    // registers are still taken, everything parked is appended first
+                    const bool fin_hit = has_job && !active && sp == 0;
+                    const unsigned long long dv = __ballot(d_valid);
+                    if (__ballot(fin_hit && d_valid) || (uint32_t) __popcll(dv) >= kFlushAt || (leaving && dv)) flush_results();
+                    if (leaving) break;
+                    if (fin_hit) {
+                        d_w = w; d_u = u; d_v = v;
+                        d_xy = pos_xy;
+                        d_zk = pos_zk;
+                        d_valid = true;
+                        has_job = false;
                     }
                 }
-                else {
-                    const uint32_t level = (uint32_t) __ffs((int) cf) - 1u;
-                    const bool keep_lo = level >= 3u;
-                    const uint32_t axis = keep_lo ? level - 3u : level;
-                    const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
-                    const uint32_t cls = s_cls[classify_index(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane)];
-                    if ((cls & kClsModeMask) == 0u) {
-                        // whole triangle to one side (one of the planar special cases, or a job whose masks are not
-                        // computed: see piece_masks)
-                        if (((cls & kClsSideLo) != 0) == keep_lo) {
-                            O2V_EV(3, true);
-                            cf &= cf - 1u;  // passed this plane; the next iteration goes on (or accumulates if none is left)
-                        }
-                        else {
-                            O2V_EV(5, true);
-                            active = false;  // discarded
-                        }
+                // pop a pending sibling (with the plane mask it was pushed with), or fetch the next survivor
+                if (!active) {
+                    if (sp) {
+                        sp -= 1u;
+                        cur = stack_load<UV>(stack, sp);
+                        if (sp >= stack_regs<UV>()) cur = overflow[sp - stack_regs<UV>()];
+                        const uint32_t sh = __umul24(sp, 6u);  // 6 bits per entry
+                        cf = (pmask >> sh) & 63u;
+                        pmask &= ~(63u << sh);
+                        active = true;
                     }
-                    else {
-                        O2V_EV(7, true);
-                        const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo, lean_all);
-                        // What becomes of the kept pieces is decided at once, from their bounding boxes against the
-                        // planes still ahead: a piece that passes them all is a final piece (accumulated now), one that
-                        // lies beyond one of them (by a margin, see piece_masks) can only be discarded there, taking all
-                        // its sub-pieces with it (dropped now), anything else goes on.  So a lane spends its iterations
-                        // on cuts only.
-                        const uint32_t later = 63u & ~((2u << level) - 1u);
-                        uint32_t c_fail, c_out, c_near, s_fail, s_out, s_near;
-                        piece_masks<UV>(cur, fx, fy, fz, small, margin, later, c_fail, c_out, c_near);
-                        piece_masks<UV>(sec, fx, fy, fz, small, margin, later, s_fail, s_out, s_near);
-                        const bool has_sec = n == 2u;
-                        bool c_done = c_fail == 0u, s_done = has_sec && s_fail == 0u;
-                        const bool c_drop = c_out != 0u, s_drop = has_sec && s_out != 0u;
-                        uint32_t c_kept = c_done ? 1u : 0u, s_kept_n = s_done ? 1u : 0u;  // (without uv) final pieces they stand for
-                        if (!UV) {
-                            // a kept piece with one plane left is settled here and now: see single_plane
-                            const bool c_single = !c_drop && single_plane(c_fail, c_near);
-                            const bool s_single = has_sec && !s_drop && single_plane(s_fail, s_near);
-                            O2V_EV(9, c_single);
-                            O2V_EV(11, s_single);
-                            if (c_single) {
-                                c_kept = single_plane_kept<UV>(cur, c_fail, fx, fy, fz, s_kept);
-                                c_done = true;
-                            }
-                            if (s_single) {
-                                s_kept_n = single_plane_kept<UV>(sec, s_fail, fx, fy, fz, s_kept);
-                                s_done = true;
-                            }
-                        }
-                        O2V_EV(8, c_done);
-                        O2V_EV(10, s_done);
-                        const bool c_over = c_done || c_drop;  // the first piece's subtree is finished
-                        // without uv only the number of pieces matters, so a final second piece is counted at once; with
-                        // uv it must wait for its turn if the first piece goes on (the running mean of
-                        // voxelization.cpp:414-420 depends on the order): it is pushed with an empty mask
-                        const bool s_acc_now = s_done && (!UV || c_over);
-                        // The second piece goes to the stack whenever it is not finished here - also when the first piece's
-                        // subtree is over and it is next in depth-first order: the pop at the top of the next iteration
-                        // brings it back (no select of fifteen floats, no extra iteration).
-                        const bool s_push = has_sec && !s_drop && !s_acc_now;
+                    else if (next_valid) {
+                        // the next job was fetched while this lane worked on the last one (take_job below)
+                        const uint2 rec = job_record();
+                        my_k = (rec.y >> 16) & 255u;
+                        const uint32_t *lf = &s_leaf[__umul24(my_k, kLeafStride)];
+                        pos_xy = rec.x;
+                        pos_zk = rec.y & 0x00ffffffu;  // z | tile slot << 16
+                        fx = (float) (rec.x & 0xffffu);
+                        fy = (float) (rec.x >> 16);
+                        fz = (float) (rec.y & 0xffffu);
+                        cf = (rec.y >> 24) & 63u;
+                        small = (rec.y >> 30) & 1u;
+                        lean = (rec.y >> 31) != 0u;
+                        cur.a = {__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                        cur.b = {__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                        cur.c = {__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
                         if (UV) {
-                            if (c_done) accumulate_piece<UV>(cur, area, w, u, v, lean_all);
-                            if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v, lean_all);
+                            cur.ta = {__uint_as_float(lf[12]), __uint_as_float(lf[13])};
+                            cur.tb = {__uint_as_float(lf[14]), __uint_as_float(lf[15])};
+                            cur.tc = {__uint_as_float(lf[16]), __uint_as_float(lf[17])};
                         }
-                        else {
-                            // w += area once per final piece (util.hpp:160-165 with equal addends: the order is immaterial)
-                            const uint32_t kept = c_kept + s_kept_n;
-                            w = kept >= 1u ? w + area : w;
-                            w = kept >= 2u ? w + area : w;
-                            w = kept >= 3u ? w + area : w;
-                            w = kept >= 4u ? w + area : w;
-                        }
-                        O2V_EV(12, s_push);
-                        if (s_push) {
-                            if (sp < kLdsSlots) stack_write<UV>(my_col + __umul24(sp, kPieceDw * 64u), sec);
-                            else if (kRegSlots && sp == kLdsSlots) rslot = sec;
-                            else overflow[sp - kLdsSlots - kRegSlots] = sec;
-                            pmask |= s_fail << __umul24(sp, 6u);
-                            sp += 1u;
-                        }
-                        cf = c_fail;
-                        active = !c_over;
-                        if (!UV && occ_only && (c_kept | s_kept_n) != 0u) {
-                            // a piece survived: the voxel is hit, the rest of the job cannot change that
-                            active = false;
+                        area = __uint_as_float(lf[23]);
+                        margin = s_margin[my_k];
+                        w = 0.f;
+                        u = 0.f;
+                        v = 0.f;
+                        active = true;
+                        has_job = true;
+                        take_job();
+                    }
+                }
+                // (wave-uniform: one job that needs the compiler's division sends the whole wavefront that way for the iteration)
+                const bool lean_all = __ballot(active && !lean) == 0ull;
+                O2V_EV(1, active);
+#ifdef O2V_INSTRUMENT
+                {
+                    const uint32_t na = (uint32_t) __popcll(__ballot(active));
+                    O2V_EV(4, lane == 0 && na <= 16u);
+                    O2V_EV(6, lane == 0 && na <= 32u);
+                }
+#endif
+                if (active) {
+                    // `cf` names the planes (bit = level: lo x, y, z, hi x, y, z) this piece does not pass whole; all others
+                    // are the loSum == 0 / loSum == 3 case of splitTriangle (voxelization.cpp:194-205), which hands the
+                    // triangle on unchanged, so they are skipped.
+                    if (cf == 0u) {
+                        O2V_EV(2, true);
+                        accumulate_piece<UV>(cur, area, w, u, v, lean_all);  // inside all remaining planes
+                        active = false;
+                        if (occ_only) {
                             sp = 0;
                             pmask = 0;
                         }
                     }
+                    else {
+                        const uint32_t level = (uint32_t) __ffs((int) cf) - 1u;
+                        const bool keep_lo = level >= 3u;
+                        const uint32_t axis = keep_lo ? level - 3u : level;
+                        const float plane = (axis == 0 ? fx : (axis == 1 ? fy : fz)) + (keep_lo ? 1.0f : 0.0f);
+                        const uint32_t cls = s_cls[classify_index(comp(cur.a, axis), comp(cur.b, axis), comp(cur.c, axis), plane)];
+                        if ((cls & kClsModeMask) == 0u) {
+                            // whole triangle to one side (one of the planar special cases, or a job whose masks are not
+                            // computed: see piece_masks)
+                            if (((cls & kClsSideLo) != 0) == keep_lo) {
+                                O2V_EV(3, true);
+                                cf &= cf - 1u;  // passed this plane; the next iteration goes on (or accumulates if none is left)
+                            }
+                            else {
+                                O2V_EV(5, true);
+                                active = false;  // discarded
+                            }
+                        }
+                        else {
+                            O2V_EV(7, true);
+                            const uint32_t n = split_cut<UV>(cur, sec, cls, axis, plane, keep_lo, lean_all);
+                            // What becomes of the kept pieces is decided at once, from their bounding boxes against the
+                            // planes still ahead: a piece that passes them all is a final piece (accumulated now), one that
+                            // lies beyond one of them (by a margin, see piece_masks) can only be discarded there, taking all
+                            // its sub-pieces with it (dropped now), anything else goes on.  So a lane spends its iterations
+                            // on cuts only.
+                            const uint32_t later = 63u & ~((2u << level) - 1u);
+                            uint32_t c_fail, c_out, c_near, s_fail, s_out, s_near;
+                            piece_masks<UV>(cur, fx, fy, fz, small, margin, later, c_fail, c_out, c_near);
+                            piece_masks<UV>(sec, fx, fy, fz, small, margin, later, s_fail, s_out, s_near);
+                            const bool has_sec = n == 2u;
+                            bool c_done = c_fail == 0u, s_done = has_sec && s_fail == 0u;
+                            const bool c_drop = c_out != 0u, s_drop = has_sec && s_out != 0u;
+                            uint32_t c_kept = c_done ? 1u : 0u, s_kept_n = s_done ? 1u : 0u;  // (without uv) final pieces they stand for
+                            if (!UV) {
+                                // a kept piece with one plane left is settled here and now: see single_plane
+                                const bool c_single = !c_drop && single_plane(c_fail, c_near);
+                                const bool s_single = has_sec && !s_drop && single_plane(s_fail, s_near);
+                                O2V_EV(9, c_single);
+                                O2V_EV(11, s_single);
+                                if (c_single) {
+                                    c_kept = single_plane_kept<UV>(cur, c_fail, fx, fy, fz, s_kept);
+                                    c_done = true;
+                                }
+                                if (s_single) {
+                                    s_kept_n = single_plane_kept<UV>(sec, s_fail, fx, fy, fz, s_kept);
+                                    s_done = true;
+                                }
+                            }
+                            O2V_EV(8, c_done);
+                            O2V_EV(10, s_done);
+                            // (value selects, not control flow: see sel_piece)
+                            const bool c_over = c_done || c_drop;            // the first piece's subtree is finished
+                            const bool s_live = has_sec && !s_done && !s_drop;  // the second piece needs more cuts
+                            // without uv only the number of pieces matters, so a final second piece is counted at once; with
+                            // uv it must wait for its turn if the first piece goes on (the running mean of
+                            // voxelization.cpp:414-420 depends on the order): it is pushed with an empty mask
+                            const bool s_acc_now = s_done && (!UV || c_over);
+                            const bool s_push = has_sec && !s_drop && !c_over && !s_acc_now;
+                            const bool s_takes_over = c_over && s_live;  // next in depth-first order
+                            if (UV) {
+                                if (c_done) accumulate_piece<UV>(cur, area, w, u, v, lean_all);
+                                if (s_acc_now) accumulate_piece<UV>(sec, area, w, u, v, lean_all);
+                            }
+                            else {
+                                // w += area once per final piece (util.hpp:160-165 with equal addends: the order is immaterial)
+                                const uint32_t kept = c_kept + s_kept_n;
+                                w = kept >= 1u ? w + area : w;
+                                w = kept >= 2u ? w + area : w;
+                                w = kept >= 3u ? w + area : w;
+                                w = kept >= 4u ? w + area : w;
+                            }
+                            O2V_EV(12, s_push);
+                            stack_store<UV>(stack, s_push ? sp : 7u, sec);  // 7: no slot, nothing stored
+                            if (s_push && sp >= stack_regs<UV>()) overflow[sp - stack_regs<UV>()] = sec;
+                            pmask |= s_push ? s_fail << __umul24(sp, 6u) : 0u;
+                            sp += s_push ? 1u : 0u;
+                            cur = sel_piece<UV>(s_takes_over, sec, cur);
+                            cf = s_takes_over ? s_fail : c_fail;
+                            active = s_takes_over || !c_over;
+                            if (!UV && occ_only && (c_kept | s_kept_n) != 0u) {
+                                // a piece survived: the voxel is hit, the rest of the job cannot change that
+                                active = false;
+                                sp = 0;
+                                pmask = 0;
+                            }
+                        }
+                    }
                 }
+                // A job is finished when nothing of it is in flight.  `not eqExactly(uv.weight, 0.f)` -> insertWeighted
+                // (voxelization.cpp:466-468): the hit is appended to the pool and counted in its cell; the ordered
+                // combine happens in the resolve kernels.  A finished hit is parked in the lane's result registers; the
+                // append section (flush_results, at the top of the loop) runs when kFlushAt lanes hold one, when a lane
+                // needs its slot again or when the wavefront leaves - not in every iteration.
+                const bool finished = has_job && !active && sp == 0;
+                if (finished && w == 0.f) has_job = false;  // the voxel was not hit
+                leaving = !__ballot(active || sp != 0 || next_valid || has_job);
             }
-            // A job is finished when nothing of it is in flight.  `not eqExactly(uv.weight, 0.f)` -> insertWeighted
-            // (voxelization.cpp:466-468): the hit is appended to the pool and counted in its cell; the ordered
-            // combine happens in the resolve kernels.  A finished hit is parked in the lane's result registers; the
-            // append section (flush_results, at the top of the loop) runs when kFlushAt lanes hold one, when a lane
-            // needs its slot again or when the wavefront leaves - not in every iteration.
-            const bool finished = has_job && !active && sp == 0;
-            if (finished && w == 0.f) has_job = false;  // the voxel was not hit
-            leaving = !__ballot(active || sp != 0 || next_valid || has_job);
+            O2V_LAP(1);
+            t_begin = t_end;
         }
     }
     // the unused tail of this wavefront's last chunk holds no hits
@@ -1307,7 +1228,6 @@ __global__ __launch_bounds__(64, ClipShape<UV>::waves) void k_voxelize(const Lea
         if (chunk_used != kHitChunk && chunk_base + k < p.cap_hits) pool[chunk_base + k].brick = kHoleBrick;
 #ifdef O2V_INSTRUMENT
     tmr[3] = __builtin_readcyclecounter() - t_kernel0;
-    tmr[1] = tmr[3];
     for (uint32_t k = 0; k < 12; ++k) {
         uint32_t t = dbgc[k];
         for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
@@ -1316,6 +1236,9 @@ __global__ __launch_bounds__(64, ClipShape<UV>::waves) void k_voxelize(const Lea
     if (lane == 0)
         for (uint32_t k = 0; k < 4; ++k) atomicAdd(&c->dbg[12 + k], tmr[k]);  // summed over the wavefronts
 #endif
-    if (lane == 0 && n_hits_wave) atomicAdd(&c->n_hits, (unsigned long long) n_hits_wave);
-    if (lane == 0 && n_direct_wave) atomicAdd(&c->n_direct, (unsigned long long) n_direct_wave);
+    __syncthreads();
+    // (a certain hit is a hit, a direct one, and a voxel job that did not have to run)
+    if (threadIdx.x == 0 && (s_hits | s_certain)) atomicAdd(&c->n_hits, (unsigned long long) s_hits + s_certain);
+    if (threadIdx.x == 0 && (s_direct | s_certain)) atomicAdd(&c->n_direct, (unsigned long long) s_direct + s_certain);
+    if (threadIdx.x == 0 && s_certain) atomicAdd(&c->n_certain, (unsigned long long) s_certain);
 }

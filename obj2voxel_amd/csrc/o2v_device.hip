@@ -112,10 +112,7 @@ struct o2v_hip_ctx {
     Tile *d_tiles = nullptr;
     BigLeaf *d_big = nullptr;
     Node *d_nodes[2] = {nullptr, nullptr};
-    uint2 *d_jobq = nullptr;  // k_candidates' staging queues: kCandQueue records per workgroup
-    uint32_t *d_job_xy = nullptr, *d_job_zf = nullptr, *d_job_leaf = nullptr;  // the job list between k_candidates and k_voxelize: cap_jobs dwords each
-    uint32_t cap_jobs = 0;
-    uint32_t clip_pad_lds[2] = {0, 0};  // dynamic LDS that pads a k_voxelize<false / true> workgroup to its share of a CU's LDS
+    uint2 *d_jobq = nullptr;  // k_voxelize's job queues: VoxShape::queue records per workgroup
     HitRec *d_pool = nullptr;
     SortedRec *d_sorted = nullptr;  // cap_hits records (read through SortedView: 24 or 16 bytes per record)
     uint32_t sorted_stride = 6;
@@ -338,21 +335,16 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
 
     {
-        // candidates -> job list (persistent 256-thread workgroups), then the clip on persistent single-wavefront workgroups
-        const JobList jobs{ctx->d_job_xy, ctx->d_job_zf, ctx->d_job_leaf};
-        O2V_LAUNCH("k_candidates", s, k_candidates, dim3((uint32_t) ctx->num_cus * (uint32_t) O2V_CAND_WGS), dim3(kCandBlock), 0, s, ctx->d_leaves,
-                           ctx->d_tiles, ctx->d_ctr, ctx->d_jobq, jobs, use_uv ? 1u : 0u, p);
-        // Exactly ClipShape::waves wavefronts per SIMD on every CU: the kernel's registers and static LDS would let the
-        // dispatcher pack one or two more single-wavefront workgroups onto the CUs it fills first - with a static deal of the
-        // job list that leaves other CUs short and the crowded ones slow - so dynamic LDS pads every workgroup to its share
-        // of the CU's 160 KiB.
+        // persistent workgroups: four wavefronts per SIMD, in workgroups of VoxShape<UV>::block threads
         if (use_uv) {
-            O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3((uint32_t) ctx->num_cus * 4u * ClipShape<true>::waves), dim3(64), ctx->clip_pad_lds[1], s,
-                               ctx->d_leaves, jobs, ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
+            const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES_UV * (kBlock / VoxShape<true>::block);
+            O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         else {
-            O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3((uint32_t) ctx->num_cus * 4u * ClipShape<false>::waves), dim3(64), ctx->clip_pad_lds[0], s,
-                               ctx->d_leaves, jobs, ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, p);
+            const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
+            O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
     }
     O2V_CHECK(hipEventRecord(ctx->ev[3], s));
@@ -595,16 +587,6 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
-    {
-        // (see run_pass: one workgroup of the clip kernel = 1 / (4 x waves) of the CU's 160 KiB of LDS)
-        const void *fn[2] = {reinterpret_cast<const void *>(&k_voxelize<false>), reinterpret_cast<const void *>(&k_voxelize<true>)};
-        const uint32_t waves[2] = {ClipShape<false>::waves, ClipShape<true>::waves};
-        for (int v = 0; v < 2; ++v) {
-            hipFuncAttributes fa{};
-            const uint32_t share = (160u * 1024u) / (4u * waves[v]);
-            if (hipFuncGetAttributes(&fa, fn[v]) == hipSuccess && fa.sharedSizeBytes < share) ctx->clip_pad_lds[v] = (share - (uint32_t) fa.sharedSizeBytes) & ~255u;
-        }
-    }
     // k_resolve_big sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_big), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int) (kBigList * 12u));
@@ -619,7 +601,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
-                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq, ctx->d_job_xy, ctx->d_job_zf, ctx->d_job_leaf,
+                    ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq,
                     ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
     for (void *q : ptrs)
@@ -980,7 +962,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
     if (!ctx->d_jobq)
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) O2V_CAND_WGS * kCandQueue * sizeof(uint2)));  // = k_candidates' workgroups x kCandQueue
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) (O2V_K2_WAVES > O2V_K2_WAVES_UV ? O2V_K2_WAVES : O2V_K2_WAVES_UV) * (kBlock / 64u) * (64u * 64u) * sizeof(uint2)));  // = workgroups x VoxShape::queue for every shape
 
     // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
     uint64_t want_leaves = std::max<uint64_t>(ctx->cap_leaves, ctx->n_tris + ctx->n_tris / 4 + (1u << 16));
@@ -988,8 +970,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     uint64_t want_big = std::max<uint64_t>(ctx->cap_big, 1u << 16);
     uint64_t want_nodes = std::max<uint64_t>(ctx->cap_nodes, 1u << 18);
     uint64_t want_hits = std::max<uint64_t>(ctx->cap_hits, std::min<uint64_t>(16 * ctx->n_tris + (4u << 20), 1ull << 31));
-    // (voxel jobs: a few per cent more than hits - most candidates that pass the plane cull are hit; far fewer in occupancy-only mode)
-    uint64_t want_jobs = std::max<uint64_t>(ctx->cap_jobs, std::min<uint64_t>(16 * ctx->n_tris + (4u << 20), 1ull << 31));
     if (const char *tiny = std::getenv("O2V_TEST_TINY_BUFFERS"); tiny && tiny[0] == '1') {
         // test hook: start with minimal buffers so that every overflow -> grow -> re-run path is exercised
         want_leaves = std::max<uint64_t>(ctx->cap_leaves, 64);
@@ -997,7 +977,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         want_big = std::max<uint64_t>(ctx->cap_big, 4);
         want_nodes = std::max<uint64_t>(ctx->cap_nodes, 16);
         want_hits = std::max<uint64_t>(ctx->cap_hits, 512);
-        want_jobs = std::max<uint64_t>(ctx->cap_jobs, 512);
     }
     uint64_t want_scratch = ctx->cap_scratch;
     uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
@@ -1053,13 +1032,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             if ((rc = grow(ctx, ctx->d_sorted, cap_s, want_hits))) return rc;
             ctx->cap_hits = cap_p;
         }
-        {
-            uint32_t cap_a = ctx->cap_jobs, cap_b = ctx->cap_jobs, cap_c = ctx->cap_jobs;
-            if ((rc = grow(ctx, ctx->d_job_xy, cap_a, want_jobs))) return rc;
-            if ((rc = grow(ctx, ctx->d_job_zf, cap_b, want_jobs))) return rc;
-            if ((rc = grow(ctx, ctx->d_job_leaf, cap_c, want_jobs))) return rc;
-            ctx->cap_jobs = cap_a;
-        }
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
@@ -1086,7 +1058,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         p.cap_nodes = ctx->cap_nodes;
         p.cap_hits = ctx->cap_hits;
         p.cap_vox = ctx->cap_vox;
-        p.cap_jobs = ctx->cap_jobs;
 
         if ((rc = run_pass(ctx, p, use_uv, n_rounds))) return rc;
         const Counters &h = *ctx->h_ctr;
@@ -1115,10 +1086,6 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(h.n_big, ctx->cap_big, want_big);
         need(max_nodes, ctx->cap_nodes, want_nodes);
         need(h.n_hits_reserved, ctx->cap_hits, want_hits);
-        if (h.n_jobs > ctx->cap_jobs) {
-            want_jobs = h.n_jobs + h.n_jobs / 8 + 1024;
-            again = true;
-        }
         need(h.n_vox, ctx->cap_vox, want_vox);
         if (p.direct_max) need(h.n_out, ctx->cap_vox, want_vox);
         if (n_rounds < kMaxRounds && h.n_nodes[n_rounds] != 0) {

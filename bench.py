@@ -52,6 +52,32 @@ def load_profile():
         return None
 
 
+ISA_HIST = os.path.join(ROOT, "profiles", "current_isa.json")   # tools/isa_hist.py --json: instruction histogram of the clip loop x measured issue costs
+
+
+def mix_ceiling(kernel):
+    """The mix-weighted issue ceiling of k_voxelize<...>: its clip loop's instruction histogram (from the compiled gfx950 code,
+    tools/isa_hist.py) priced with the measured SIMD cycles per instruction of each opcode class (profiles/*/valu_rates.json)
+    gives the cycles an average VALU instruction of THIS kernel costs; SIMDs x clock / that is the rate at which the kernel's
+    own mix can issue at best.  None if the histogram is missing or was made from other device sources."""
+    try:
+        h = json.load(open(ISA_HIST))
+        e = h.get(kernel)
+        if not e or not e.get("mix_cycles_per_valu"):
+            return None
+        try:
+            from obj2voxel_amd import hip
+            running = hip.build_id()
+        except Exception:
+            running = None
+        m = float(e["mix_cycles_per_valu"])
+        return {"mix_cycles_per_valu_instruction": round(m, 3), "ceiling_ginstr": round(N_SIMDS * CLOCK_GHZ / m, 1),
+                "stale": bool(running is not None and h.get("build_id") != running),
+                "source": "profiles/current_isa.json (tools/isa_hist.py: clip loop histogram x " + str(h.get("rates_file")) + ")"}
+    except (OSError, ValueError):
+        return None
+
+
 def profile_for(prof, workload, stats=None):
     """(kernels, stale) of the committed PMC summary for a named workload: `kernels` is None if the summary does not hold
     the workload or was measured on another mesh; stale = the summary was recorded with a library built from other device
@@ -329,6 +355,13 @@ def kernel_view(name, ms, launches, alg_bytes, prof_kernels, stale):
             row["valu_frac"] = round(row["valu_instructions"] / (ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4)
             if sq.get("SQ_THREAD_CYCLES_VALU"):
                 row["active_lane_fraction"] = round(sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_INSTS_VALU"] / 64.0, 3)
+            mc = mix_ceiling(name)
+            if mc:
+                # against the rate the kernel's own instruction mix can issue at (see mix_ceiling), not the 2-cycle peak
+                row["valu_frac_of_mix_ceiling"] = round(row["valu_instructions"] / (ms * 1e-3) / 1e9 / mc["ceiling_ginstr"], 4)
+                row["mix_cycles_per_valu_instruction"] = mc["mix_cycles_per_valu_instruction"]
+                if mc["stale"]:
+                    row["mix_stale"] = True
         row["counters"] = "profiles/current.json"
         if stale:
             row["stale"] = True   # recorded with a library built from other device sources: not this kernel's counters
@@ -451,6 +484,17 @@ def report(args, n, run, dv, comm):
                     # so a figure near 4 means the VALU pipes are full for the instructions this kernel is made of.
                     "simd_cycles_per_valu_instruction": round(dom["ms"] * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMDS / sq["SQ_INSTS_VALU"], 2),
                     "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU: " + (prof or {}).get("source", "profiles/current.json")}
+        mc = mix_ceiling(dom_kernel)
+        if mc:
+            # `frac` is the distance to a kernel made of 2-cycle instructions only; this one is the distance to the best the
+            # kernel's own mix of 2- and 4-cycle instructions can do: both recomputable from profiles/ alone
+            # (valu_instructions_per_launch / kernel_ms against peak and against mix_ceiling)
+            roofline["mix_cycles_per_valu_instruction"] = mc["mix_cycles_per_valu_instruction"]
+            roofline["mix_ceiling"] = mc["ceiling_ginstr"]
+            roofline["frac_of_mix_ceiling"] = round(ginstr / mc["ceiling_ginstr"], 4)
+            roofline["mix_source"] = mc["source"]
+            if mc["stale"]:
+                roofline["mix_stale"] = True
         if stale:
             # the summary was recorded with a library built from other device sources (o2v_hip_build_id differs): the count is
             # another kernel's - kept for orientation, labelled, to be re-measured (tools/profile_all.sh)

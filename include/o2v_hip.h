@@ -279,6 +279,10 @@ void o2v_hip_cuts_from_histogram(const uint64_t *hist, uint32_t n_bins, uint32_t
                                  uint32_t n_slabs, uint32_t *out_z);
 int o2v_hip_comm_callbacks_selftest(const o2v_hip_comm_callbacks *callbacks, int rank, int world);
 int o2v_hip_group_exchange_selftest(uint32_t n_threads);
+/* The RCCL code path of an n-rank in-process group (unique id, ncclCommInitRank on one thread per rank, all five collectives,
+ * teardown) on host memory, without selecting a device: only meaningful with a librccl that works on host memory (the tests'
+ * stand-in, loaded through O2V_RCCL_LIB).  0 = everything behaved as specified. */
+int o2v_hip_group_rccl_selftest(uint32_t n_ranks);
 
 /* A triangle file (OBJ with MTL + PNG textures, binary STL; `type` = extension or NULL to take the path's) read by the
  * library's own readers into the flat host arrays o2v_hip_set_triangles takes - what obj2voxel_voxelize() does with

@@ -85,7 +85,7 @@ struct RcclComm final : o2v_hip_comm {
     ~RcclComm() override
     {
         if (comm) {
-            (void) hipSetDevice(device);
+            if (device >= 0) (void) hipSetDevice(device);
             (void) api->CommDestroy(comm);
         }
     }
@@ -195,7 +195,8 @@ o2v_hip_comm *make_rccl_comm(const uint8_t id[O2V_HIP_COMM_ID_BYTES], int rank, 
         err = "librccl is not available";
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) {
+    // (device < 0: no device is selected - the host-only self-test of this code path, o2v_hip_group_rccl_selftest)
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) {
         err = "hipSetDevice failed";
         return nullptr;
     }

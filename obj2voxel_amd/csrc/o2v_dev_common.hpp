@@ -71,10 +71,12 @@ struct __attribute__((aligned(8))) SortedRec {  // 24 B: the same hit, placed co
 // The sorted array is read through a view: 6 dwords per record in general, 4 (keyhi, keylo, w, pad: one 16-byte access)
 // when the mesh has no textured triangle, because then u and v are never used and the scatter's cost scales with the
 // bytes it writes.
+constexpr uint32_t kOccInline = 0x80000000u;  // Occ::count: the cell's hits are in its brick's slab, not in the sorted array
+constexpr uint32_t kInlineHits = 8;  // hits per cell kept in the brick's slab (= kShortList: what k_resolve's lanes fold from registers)
 struct SortedView {
     const uint32_t *base;
     uint32_t stride;  // dwords per record: 6 or 4
-    __device__ __forceinline__ SortedRec load(uint32_t i) const
+    __device__ __forceinline__ SortedRec load(size_t i) const
     {
         if (stride == 4u) {
             const uint4 q = reinterpret_cast<const uint4 *>(base)[i];
@@ -86,8 +88,8 @@ struct SortedView {
 
 struct __attribute__((aligned(16))) Occ {  // 16 B: one occupied cell
     uint32_t cell_lo, cell_hi;  // brick * kBrickCells + cell in brick
-    uint32_t offset;            // first SortedRec of the cell
-    uint32_t count;             // number of hits
+    uint32_t offset;            // first SortedRec of the cell; for an inline cell: the number of its brick's slab
+    uint32_t count;             // number of hits; | kOccInline: the hits (at most kInlineHits) are in the brick's slab
 };
 
 struct DevTexture {
@@ -158,6 +160,13 @@ struct Params {
     // {cell, key, argb} record; k_pick later gives every cell whose winner it was that colour.
     uint32_t pick_max;
     Materials mat;
+    // Inline hit slabs (general route): every brick a leaf's clamped box touches is listed before
+    // k_voxelize (k_mark_bricks -> k_scan_flags) and owns a slab of kInlineHits x 64 hit records; brick_slab[brick] is its
+    // number.  A cell's first kInlineHits hits (by rank) go straight into its slab - record (slab * 64 + cell in brick) *
+    // kInlineHits + rank: a cell's hits lie side by side - and never see the pool or the scatter.
+    const uint32_t *brick_slab;
+    uint32_t *slabs;       // cap_slabs x kInlineHits x 64 records of slab_stride dwords
+    uint32_t cap_slabs, slab_stride;
     uint32_t *pick_extra;  // the same records for the winners of cells resolved by replay: 6 words each, cap_vox of them
     unsigned long long *maxgrid;
     uint8_t *occgrid;   // occupancy-only mode: the same buffer as one byte per cell (non-zero = the voxel is hit)
@@ -182,6 +191,12 @@ __device__ __forceinline__ bool expand_overflowed(const Counters *c, const Param
 __device__ __forceinline__ bool direct_active(const Counters *c, const Params &p)
 {
     return p.direct_max && (p.occupancy_only || c->n_nodes[0] <= c->n_root_leaves);
+}
+// A pass pools no hits at all if every triangle is voxelized whole and takes the direct MAX path (or the mesh has no
+// materials): then no brick needs a hit slab and the stages of the general route have nothing to do.
+__device__ __forceinline__ bool pools_no_hits(const Counters *c, const Params &p, uint32_t force_general)
+{
+    return p.occupancy_only || (direct_active(c, p) && c->n_nodes[0] == 0u && !force_general);
 }
 __device__ __forceinline__ bool pass_overflowed(const Counters *c, const Params &p)
 {

@@ -127,6 +127,10 @@ __global__ void k_setup(Counters *c, Params p)
 // spreads that estimate over the triangle's z layers into <= 2048 bins (fixed point, integer atomics: the result
 // does not depend on the order of the adds, so every rank derives the same cuts).
 constexpr uint32_t kPlanBins = 2048;
+#ifndef O2V_PLAN_LEAF_COST
+#define O2V_PLAN_LEAF_COST 4.0f
+#endif
+constexpr float kPlanLeafCost = O2V_PLAN_LEAF_COST;  // what a leaf costs beside its hits, in hits (see k_zhist)
 __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ verts, const Counters *__restrict__ c,
                                                    unsigned long long *hist, float2 *zrange, float *zrange_xform,
                                                    Params p, uint32_t bin_h, uint64_t tri_begin, uint64_t tri_end)
@@ -194,9 +198,19 @@ __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ vert
         }
         if (!live) continue;
         const V3 n = tri_normal(v0, v1, v2), e0 = v1 - v0, e1 = v2 - v1, e2 = v0 - v2;
+        // Predicted TIME, in hit equivalents: the hits (Steiner-type estimate above) plus what a leaf costs whatever it hits -
+        // its expansion, its tile, its candidate rows - measured on the eight slabs of configs[4] (equal hits, 5.3 M to 7.8 M
+        // leaves: +0.127 us per leaf, against 0.031 us per hit: kPlanLeafCost hits per leaf; profiles/r03/predict_scaling_8_config4.jsonl).
+        // A triangle whose voxel box has V >= 512 cells is subdivided (voxelization.cpp:349-379) into about (V / 512)^(2/3)
+        // leaves (every level quarters the triangle and divides its box by about eight).
+        const float bx = fmax2(v0.x, fmax2(v1.x, v2.x)) - fmin2(v0.x, fmin2(v1.x, v2.x)) + 1.0f;
+        const float by = fmax2(v0.y, fmax2(v1.y, v2.y)) - fmin2(v0.y, fmin2(v1.y, v2.y)) + 1.0f;
+        const float bz = fmax2(v0.z, fmax2(v1.z, v2.z)) - fmin2(v0.z, fmin2(v1.z, v2.z)) + 1.0f;
+        const float boxes = bx * by * bz * (1.0f / 512.0f);
+        const float leaves_est = boxes > 1.0f ? __builtin_exp2f(__builtin_log2f(boxes) * (2.0f / 3.0f)) : 1.0f;
         float est = (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) * 0.5f +
                     (abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z) + abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z) + abs_f(e2.x) +
-                     abs_f(e2.y) + abs_f(e2.z)) * 0.5f + 1.0f;
+                     abs_f(e2.y) + abs_f(e2.z)) * 0.5f + 1.0f + kPlanLeafCost * leaves_est;
         if (!(est < 1e12f)) est = 1e12f;  // also catches NaN
         const float zlo = fmin2(v0.z, fmin2(v1.z, v2.z)), zhi = fmax2(v0.z, fmax2(v1.z, v2.z));
         if (!(zhi >= 0.f) || !(zlo < (float) p.S)) continue;

@@ -487,3 +487,61 @@ __global__ __launch_bounds__(kBlock) void k_expand_big(const BigLeaf *__restrict
             if (bl.first_tile + k < p.cap_tiles) tiles[bl.first_tile + k] = Tile{bl.leaf, k * kTileSize};
     }
 }
+
+// Lists, before k_voxelize, the bricks of the output grid that can receive pooled hits: every brick the clamped box of a leaf
+// touches gets its flag set (the dirty-flag map; k_scan_flags then turns the flags into the brick list and gives every listed
+// brick its hit slab).  A superset of the bricks that do receive hits - a hit's voxel lies in its leaf's clamped box
+// (voxelization.cpp:440-444) - by about a third on tessellated surfaces.  One lane per leaf; a leaf whose box covers more than
+// 64 bricks (large axis-aligned triangles) is marked by its whole wavefront.  No work if the pass pools no hits (every
+// triangle whole and on the direct MAX path).
+__global__ __launch_bounds__(kBlock) void k_mark_bricks(const Leaf *__restrict__ leaves, const Counters *c, uint8_t *brick_flags, uint32_t force_general, Params p)
+{
+    if (expand_overflowed(c, p)) return;
+    if (pools_no_hits(c, p, force_general)) return;
+    const uint32_t n_leaves = c->n_leaves < p.cap_leaves ? c->n_leaves : p.cap_leaves;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = blockIdx.x * kBlock; i0 < n_leaves; i0 += gridDim.x * kBlock) {  // (uniform per wavefront)
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t b0[3] = {0, 0, 0}, nb[3] = {0, 0, 0};
+        if (i < n_leaves) {
+            const Leaf &l = leaves[i];
+            const uint32_t lo[3] = {l.bmin_xy & 0xffffu, l.bmin_xy >> 16, l.bmin_z_dx & 0xffffu};
+            const uint32_t d[3] = {l.bmin_z_dx >> 16, l.dy_dz & 0xffffu, l.dy_dz >> 16};
+            const uint32_t sh[3] = {kBrickXs, kBrickYs, kBrickZs};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (d[a] == 0u) continue;
+                // output cells [lo >> ss, (lo + d - 1) >> ss]; z relative to the slab
+                uint32_t c0 = lo[a] >> p.ss_shift, c1 = (lo[a] + d[a] - 1u) >> p.ss_shift;
+                if (a == 2) {
+                    c0 -= p.zo0;
+                    c1 -= p.zo0;
+                }
+                b0[a] = c0 >> sh[a];
+                nb[a] = (c1 >> sh[a]) - b0[a] + 1u;
+            }
+            if (!d[0] || !d[1] || !d[2]) nb[0] = nb[1] = nb[2] = 0u;
+        }
+        const uint32_t count = nb[0] * nb[1] * nb[2];  // (a box of < 2^16 cells per axis: < 2^14 bricks per axis; leaves that large are rare and aligned, one axis is thin)
+        const bool big = count > 64u || nb[0] > 0xffffu;
+        if (count && !big) {
+            for (uint32_t z = 0; z < nb[2]; ++z)
+                for (uint32_t y = 0; y < nb[1]; ++y) {
+                    const uint32_t row = ((b0[2] + z) * p.NBy + (b0[1] + y)) * p.NBx + b0[0];
+                    for (uint32_t x = 0; x < nb[0]; ++x) brick_flags[row + x] = 1;
+                }
+        }
+        unsigned long long mb = __ballot(big);
+        while (mb) {
+            const int src = __ffsll((long long) mb) - 1;
+            mb &= mb - 1ull;
+            const uint32_t x0 = __shfl(b0[0], src, 64), y0 = __shfl(b0[1], src, 64), z0 = __shfl(b0[2], src, 64);
+            const uint32_t nx = __shfl(nb[0], src, 64), ny = __shfl(nb[1], src, 64), nz = __shfl(nb[2], src, 64);
+            const uint64_t total = (uint64_t) nx * ny * nz;
+            for (uint64_t t = lane; t < total; t += 64u) {
+                const uint32_t x = (uint32_t) (t % nx), yz = (uint32_t) (t / nx), y = yz % ny, z = yz / ny;
+                brick_flags[((size_t) (z0 + z) * p.NBy + (y0 + y)) * p.NBx + (x0 + x)] = 1;
+            }
+        }
+    }
+}

@@ -972,8 +972,31 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 // subdivided triangles still go through the pool (their leaves' weights must be added up in order first).
                 // (occupancy-only mode: any hit marks the voxel, also those of subdivided triangles)
                 const bool direct = d_valid && use_direct && (occ_only || s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u);
+                // The cell's counter hands out the hit's rank.  The first kInlineHits hits of a cell (by rank) go straight into
+                // the slab of the cell's brick (Params::brick_slab: listed before this kernel by k_mark_bricks / k_scan_flags) -
+                // they never see the pool, the scatter or a second copy: the random writes of the counting sort happen here,
+                // under a kernel that is bound by instruction issue, not by memory; only the later hits of crowded cells are
+                // pooled (k_scan_bricks turns the counts into offsets, k_scatter places them behind the slab's eight).
+                // (handing the ranks out in k_scatter instead - no wait here - was measured: k_voxelize -2 %, k_scatter +13 % on
+                // configs[3])
+                uint32_t brick = 0, rank = 0, keyhi = 0, slab = 0;
+                uint64_t cell = 0;
+                const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
+                if (d_valid) {
+                    const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
+                    const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
+                    cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                    const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
+                    keyhi = (sub << 29) | lf[18];
+                    if (!direct) {
+                        slab = p.brick_slab[brick];
+                        rank = atomicAdd(&grid[cell], 1u);
+                        if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
+                    }
+                }
+                const bool inlined = d_valid && !direct && rank < kInlineHits && slab < p.cap_slabs;
                 // with textures a direct hit still leaves a record behind: {cell, key, colour} for k_pick
-                const bool pooled = d_valid && (UV || !direct);
+                const bool pooled = d_valid && !inlined && (UV || !direct);
                 const unsigned long long mask = __ballot(pooled);
                 const uint32_t cnt = (uint32_t) __popcll(mask);
                 const uint32_t leader = mask ? (uint32_t) __ffsll((long long) mask) - 1u : 0u;
@@ -992,13 +1015,6 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 const uint32_t mine = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
                 chunk_used += cnt;
                 if (d_valid) {
-                    const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
-                    const uint32_t *lf = &s_leaf[(d_zk >> 16) * kLeafStride];
-                    const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
-                    uint32_t brick;
-                    const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
-                    const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
-                    const uint32_t keyhi = (sub << 29) | lf[18];
                     if (direct && occ_only) {
                         // occupancy only: the voxel is hit, nothing else about it matters (plain stores; benign races: every
                         // writer stores the same value)
@@ -1014,16 +1030,17 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             pool[mine] = HitRec{brick, ((uint32_t) cell & (kBrickCells - 1u)) << 24, keyhi, 0u, d_w, d_u, d_v, kPickRecord};
                         }
                     }
-                    else if (mine < p.cap_hits) {
-                        // the cell's counter hands out this hit's rank; k_scan_bricks turns the counts into offsets
-                        // (handing the ranks out in k_scatter instead - no wait here - was measured: k_voxelize -2 %, k_scatter
-                        // +13 % on configs[3])
-                        const uint32_t rank = atomicAdd(&grid[cell], 1u);
-                        if (rank >= kMaxRank) atomicOr(&c->err_flags, kErrRank);
-                        brick_dirty[brick] = 1;  // benign race: every writer stores the same value
+                    else {
                         if (use_direct) p.dirty_max[brick] = 1;  // the resolve kernels will add this cell's result
-                        pool[mine] = HitRec{brick, (((uint32_t) cell & (kBrickCells - 1u)) << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w,
-                                            d_u, d_v, 0u};
+                        if (inlined) {
+                            const size_t at = ((size_t) slab * kBrickCells + ((uint32_t) cell & (kBrickCells - 1u))) * kInlineHits + rank;
+                            if (UV) reinterpret_cast<SortedRec *>(p.slabs)[at] = SortedRec{keyhi, lf[19], d_w, d_u, d_v, 0u};
+                            else reinterpret_cast<uint4 *>(p.slabs)[at] = make_uint4(keyhi, lf[19], __float_as_uint(d_w), 0u);
+                        }
+                        else if (mine < p.cap_hits) {
+                            pool[mine] = HitRec{brick, (((uint32_t) cell & (kBrickCells - 1u)) << 24) | (rank & (kMaxRank - 1u)), keyhi, lf[19], d_w,
+                                                d_u, d_v, 0u};
+                        }
                     }
                 }
                 if (lane == 0) atomicAdd(&s_hits, (uint32_t) __popcll(all));

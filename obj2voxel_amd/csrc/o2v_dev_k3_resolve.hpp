@@ -145,10 +145,15 @@ struct SortNet {
 // One cell with up to N hits, resolved by one lane out of its registers (compile-time indices only): the records are sorted
 // by a sorting network, reduced to their (sub-voxel, triangle) groups in one forward pass, coloured four groups at a time
 // and folded.  Returns the cell's ARGB; `f` holds the winner for the direct MAX path.
+// The cell's `count` hits are the records first, first + step, ... of `sorted` (step 1: the sorted array and the slabs both
+// keep a cell's hits side by side).
 template <uint32_t STRIDE, uint32_t N>
-__device__ __forceinline__ uint32_t resolve_cell_in_registers(const Occ &o, const SortedView &sorted, const Materials &m, const DevTexture *s_tex,
-                                                              const Params &p, GroupFold &f)
+__device__ __forceinline__ uint32_t resolve_cell_in_registers(const SortedView &sorted, size_t first, uint32_t step, uint32_t count, const Materials &m,
+                                                              const DevTexture *s_tex, const Params &p, GroupFold &f)
 {
+    struct {
+        uint32_t count;
+    } o{count};
     constexpr bool kUv = STRIDE == 6;  // 16-byte records carry no uv
     // All loads are issued before anything is consumed (independent round trips overlap); slots beyond the cell's count get
     // the greatest key and sort to the end.
@@ -157,7 +162,7 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const Occ &o, cons
     {
         SortedRec r[N];
 #pragma unroll
-        for (uint32_t k = 0; k < N; ++k) r[k] = sorted.load(o.offset + (k < o.count ? k : 0u));
+        for (uint32_t k = 0; k < N; ++k) r[k] = sorted.load(first + (size_t) ((k < o.count ? k : 0u) * step));
 #pragma unroll
         for (uint32_t k = 0; k < N; ++k) {
             key[k] = k < o.count ? (((uint64_t) r[k].keyhi << 32) | r[k].keylo) : ~0ull;
@@ -250,10 +255,9 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const Occ &o, cons
 }
 
 template <uint32_t STRIDE>
-__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn,
+__global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn, SortedView slabs_dyn,
                                                     const Counters *c, Materials m, uint4 *out, Params p)
 {
-    const SortedView sorted{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
     __shared__ DevTexture s_tex[kTexCache];  // the first textures' descriptors (the colour lookup reads them per group)
     if (pass_overflowed(c, p)) return;
     if (STRIDE == 6) {
@@ -263,9 +267,14 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
-        if (o.count > kShortList) continue;  // filed for another tier by k_scan_bricks
+        const uint32_t count = o.count & ~kOccInline;
+        if (count > kShortList) continue;  // filed for another tier by k_scan_bricks
+        // an inline cell's hits are in its brick's slab (Occ::offset names it), the others' in the sorted array
+        const bool inl = (o.count & kOccInline) != 0u;
+        const SortedView from{inl ? slabs_dyn.base : sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
+        const size_t first = inl ? ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) o.offset;
         GroupFold f;
-        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>(o, sorted, m, s_tex, p, f);
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>(from, first, 1u, count, m, s_tex, p, f);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_list16(const uint32_t *__res
         const uint32_t i = list[item];
         const Occ o = occ[i];
         GroupFold f;
-        const uint32_t argb = resolve_cell_in_registers<STRIDE, kLane16List>(o, sorted, m, s_tex, p, f);
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kLane16List>(sorted, (size_t) o.offset, 1u, o.count, m, s_tex, p, f);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }

@@ -10,8 +10,13 @@
 // not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.
 
 constexpr uint32_t kFlagLoads = 2;  // 16-byte loads of the flag map per thread and round
-__global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uint32_t *n_dirty, uint32_t *dirty_list, Counters *c, Params p)
+// `brick_slab` (optional): every listed brick learns its place in the list (= the number of its hit slab, Params::brick_slab);
+// this use of the kernel - ahead of k_voxelize, on the flags k_mark_bricks set - is skipped like k_mark_bricks itself when
+// the pass pools no hits.
+__global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uint32_t *n_dirty, uint32_t *dirty_list, Counters *c, uint32_t *brick_slab,
+                                                       uint32_t force_general, Params p)
 {
+    if (brick_slab && pools_no_hits(c, p, force_general)) return;
     // The workgroup collects dirty bricks in LDS over several rounds and reserves their place in the list with one global
     // atomic per few thousand of them (atomics on one address serialise at ~88 per us: one per round and workgroup was most
     // of this kernel's time).  Launched with two workgroups per CU.
@@ -27,7 +32,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uin
         if (threadIdx.x == 0) s_base = atomicAdd(n_dirty, n);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-            if (s_base + i < p.cap_dirty) dirty_list[s_base + i] = s_list[i];
+            if (s_base + i < p.cap_dirty) {
+                dirty_list[s_base + i] = s_list[i];
+                if (brick_slab) brick_slab[s_list[i]] = s_base + i;
+            }
         if (threadIdx.x == 0 && s_base + n > p.cap_dirty) atomicOr(&c->err_flags, kErrDirtyList);
         __syncthreads();
         if (threadIdx.x == 0) s_n = 0;
@@ -105,7 +113,11 @@ __device__ __forceinline__ uint32_t *class_counter(Counters *c, uint32_t k)
 // Writes the staged occupied cells of one workgroup to `occ`, giving every cell the offset of its hits in the sorted
 // record array: one reservation of (cells, hits) per flush, offsets by a block-level prefix sum over the counts.
 // The offset is also stored in the cell itself, where k_scatter reads it.
-__device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi, uint32_t *s_cnt,
+// Cells with at most kInlineHits hits whose brick has a slab keep them there (written by k_voxelize): their occ entry names
+// the slab (kOccInline) and they take no part in the counting sort.  The other cells get a range of the sorted array as
+// before; what a slab holds of them - their first kInlineHits hits - is copied there by k_promote, the rest arrives through
+// k_scatter (a brick beyond the slab budget has all its hits pooled).
+__device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi /* cell >> 32 | slab << 5 */, uint32_t *s_cnt,
                                            uint32_t *s_wave, uint32_t *s_base, uint32_t *s_cls /*[7], zero*/,
                                            uint32_t *s_cls_base /*[7]*/, uint32_t *grid, Counters *c, Occ *occ,
                                            const ResolveLists &lists, const Params &p)
@@ -114,7 +126,7 @@ __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, con
     const uint32_t per = (n + kBlock - 1) / kBlock;
     const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += s_cnt[i];
+    for (uint32_t i = lo; i < hi; ++i) sum += (s_cnt[i] > kInlineHits || (s_hi[i] >> 5) >= p.cap_slabs) ? s_cnt[i] : 0u;
     uint32_t total;
     uint32_t run = block_exscan(sum, s_wave, total);
     __syncthreads();
@@ -128,9 +140,15 @@ __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, con
     for (uint32_t i = lo; i < hi; ++i) {
         const uint32_t cnt = s_cnt[i];
         const bool listed = base_vox + i < p.cap_vox;
-        if (listed) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], run, cnt};
-        grid[((uint64_t) s_hi[i] << 32) | s_lo[i]] = run;
-        if (cnt > kShortList && listed) {
+        const uint32_t cell_hi = s_hi[i] & 31u, slab = s_hi[i] >> 5;
+        const bool has_slab = slab < p.cap_slabs;
+        if (cnt <= kInlineHits && has_slab) {
+            if (listed) occ[base_vox + i] = Occ{s_lo[i], cell_hi, slab, cnt | kOccInline};
+            continue;
+        }
+        if (listed) occ[base_vox + i] = Occ{s_lo[i], cell_hi, run, cnt};
+        grid[((uint64_t) cell_hi << 32) | s_lo[i]] = run;  // (k_scatter places the pooled hits at run + rank)
+        if (listed && cnt > kShortList) {
             // rank within its class among this flush's cells; the count is not needed again, the slot keeps the tag
             const uint32_t cls = resolve_class(cnt);
             s_cnt[i] = 0x80000000u | (cls << 24) | atomicAdd(&s_cls[cls], 1u);
@@ -165,13 +183,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t n_rounds = (n_dirty + kScanBricksPerRound - 1) / kScanBricksPerRound;
     for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
-        uint32_t brick[kScanBricksPerWave];
+        uint32_t brick[kScanBricksPerWave], slab[kScanBricksPerWave];
         uint4 h[kScanBricksPerWave];
 #pragma unroll
         for (uint32_t k = 0; k < kScanBricksPerWave; ++k) {
             // (a load covers kBricksPerLoad bricks: kLanesPerBrick lanes each)
             const uint32_t item = r * kScanBricksPerRound + (wave * kScanBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
             brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
+            slab[k] = item;  // (a brick's place in the list is the number of its hit slab)
         }
 #pragma unroll
         for (uint32_t k = 0; k < kScanBricksPerWave; ++k)
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
                     if (hv[e]) {
                         const uint64_t cell = (uint64_t) brick[k] * kBrickCells + (lane % kLanesPerBrick) * 4u + e;
                         s_lo[slot] = (uint32_t) cell;
-                        s_hi[slot] = (uint32_t) (cell >> 32);
+                        s_hi[slot] = (uint32_t) (cell >> 32) | (slab[k] << 5);  // (cell < 2^37, slab < 2^27)
                         s_cnt[slot] = hv[e];
                         ++slot;
                     }
@@ -220,6 +239,30 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
     }
     const uint32_t n = s_n;
     if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
+}
+
+// The cells with more than kInlineHits hits whose brick has a slab: their first kInlineHits hits (ranks 0 .. 7, written there
+// by k_voxelize) move to the head of the cell's range of the sorted array - eight lanes per cell, one record each - so that
+// the cooperative tiers find a cell's hits in one place.  The cells are the ones k_scan_bricks filed for those tiers.
+__global__ __launch_bounds__(kBlock) void k_promote(const Occ *__restrict__ occ, ResolveLists lists, const Counters *c, uint32_t *sorted, Params p)
+{
+    if (pass_overflowed(c, p)) return;
+    static_assert(kInlineHits == 8, "eight lanes per cell");
+    for (uint32_t cls = 0; cls < kResolveClasses; ++cls) {
+        const uint32_t *list = class_list(lists, cls);
+        const uint32_t n_raw = *class_counter(const_cast<Counters *>(c), cls);
+        const uint32_t n = n_raw < lists.cap ? n_raw : lists.cap;
+        for (uint64_t t = (uint64_t) blockIdx.x * kBlock + threadIdx.x; t < (uint64_t) n * kInlineHits; t += (uint64_t) gridDim.x * kBlock) {
+            const Occ o = occ[list[t / kInlineHits]];
+            const uint32_t k = (uint32_t) (t % kInlineHits);
+            const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+            const uint32_t slab = p.brick_slab[cell >> kBrickShift];
+            if (slab >= p.cap_slabs || (uint64_t) o.offset + k >= p.cap_hits) continue;  // (no slab: every hit of the cell was pooled)
+            const size_t from = ((size_t) slab * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits + k;
+            if (p.slab_stride == 4u) reinterpret_cast<uint4 *>(sorted)[o.offset + k] = reinterpret_cast<const uint4 *>(p.slabs)[from];
+            else reinterpret_cast<SortedRec *>(sorted)[o.offset + k] = reinterpret_cast<const SortedRec *>(p.slabs)[from];
+        }
+    }
 }
 
 #ifndef O2V_SCATTER_UNROLL

@@ -130,6 +130,10 @@ struct o2v_hip_ctx {
     uint64_t grid_cells = 0;      // allocated
     uint8_t *d_brick_dirty = nullptr;   // one flag per brick (padded to 16 bytes)
     uint32_t *d_dirty_list = nullptr;   // dirty brick ids of the current run
+    uint32_t *d_brick_slab = nullptr;   // per brick: its place in that list = the number of its hit slab (Params::brick_slab)
+    uint32_t *d_slabs = nullptr;        // cap_slabs x kInlineHits x 64 hit records (sorted_stride dwords each)
+    uint32_t cap_slabs = 0, slabs_stride = 0;
+    uint64_t want_slabs_next = 0;       // the brick list of the last pass (+ 1/8): what the slabs are grown to at the next call
     uint32_t cap_pick_extra = 0;
     PickRec *d_pick_extra = nullptr;  // textured MAX: {cell, key, argb} of the cells resolved by replay (6 words, cap_vox of them)
     unsigned long long *d_maxgrid = nullptr;  // direct MAX path: one 64-bit cell per output voxel (same bricked layout)
@@ -326,6 +330,16 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
     }
     O2V_LAUNCH("k_expand_big", s, k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
+    if (!p.occupancy_only) {
+        // The bricks that can receive pooled hits are listed before k_voxelize (every brick a leaf's clamped box touches: a
+        // superset of the bricks that do), and every listed brick gets a hit slab: the first kInlineHits hits of a cell go
+        // there directly.  Neither kernel has work if the pass pools no hits (decided on the device from K1's counters).
+        O2V_LAUNCH("k_mark_bricks", s, k_mark_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_ctr, ctx->d_brick_dirty,
+                           ctx->force_general ? 1u : 0u, p);
+        const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
+        O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
+                           dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, ctx->d_ctr, ctx->d_brick_slab, ctx->force_general ? 1u : 0u, p);
+    }
     O2V_CHECK(hipEventRecord(ctx->ev[2], s));
     if (p.direct_max) {
         // K1's counters go to the host on an auxiliary stream while k_voxelize runs (see below)
@@ -364,18 +378,18 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         if (run_emit) {
             const uint32_t groups = (p.n_bricks + 15u) / 16u;
             O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
-                               dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, ctx->d_ctr, p);
+                               dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, ctx->d_ctr, (uint32_t *) nullptr, 0u, p);
         }
     }
 
     if (run_general) {
-        const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
-        O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
-                           dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, ctx->d_ctr, p);
+        // (the brick list was made before k_voxelize: see k_mark_bricks)
         const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
                                  ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
         O2V_LAUNCH("k_scan_bricks", s, k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, lists, p);
+        O2V_LAUNCH("k_promote", s, k_promote, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_occ, lists, ctx->d_ctr,
+                           reinterpret_cast<uint32_t *>(ctx->d_sorted), p);
         O2V_LAUNCH("k_scatter", s, k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
         O2V_LAUNCH("k_reset_bricks", s, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
@@ -398,11 +412,13 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             O2V_CHECK(hipEventRecord(ctx->ev_fork, s));
             for (hipStream_t a : ctx->aux) O2V_CHECK(hipStreamWaitEvent(a, ctx->ev_fork, 0));
         }
+        // (cells with up to kInlineHits hits: straight from their bricks' slabs)
+        const SortedView slab_view{ctx->d_slabs, use_uv ? 6u : 4u};
         if (use_uv)
-            O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+            O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
                                ctx->d_out, p);
         else
-            O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, ctx->d_ctr, m,
+            O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
                                ctx->d_out, p);
         if (use_uv)
             O2V_LAUNCH("k_resolve_list16<6>", sw, k_resolve_list16<6>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
@@ -603,7 +619,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
                     ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq,
                     ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
-                    ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
+                    ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_brick_slab, ctx->d_slabs, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
     for (uint8_t *q : ctx->d_texpix)
@@ -952,6 +968,9 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->brick_cap = brick_cap_want;
             O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_brick_dirty), ctx->brick_cap));
             O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_dirty_list), std::min<uint64_t>(ctx->brick_cap, kDirtyListMax) * sizeof(uint32_t)));
+            if (ctx->d_brick_slab) O2V_CHECK(hipFree(ctx->d_brick_slab));
+            ctx->d_brick_slab = nullptr;
+            O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_brick_slab), ctx->brick_cap * sizeof(uint32_t)));
             ctx->grid_dirty = true;
         }
         if (ctx->grid_dirty) {
@@ -977,6 +996,28 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         want_big = std::max<uint64_t>(ctx->cap_big, 4);
         want_nodes = std::max<uint64_t>(ctx->cap_nodes, 16);
         want_hits = std::max<uint64_t>(ctx->cap_hits, 512);
+    }
+    // Hit slabs: one per listed brick (about 1.3 x the bricks that end up holding voxels on a tessellated surface).  They are a
+    // budget, not a requirement - a listed brick beyond cap_slabs pools all its hits - so a pass is never repeated for them:
+    // the capacity follows the last pass's list (ctx->want_slabs_next) up to a sixth of the device memory.
+    const uint32_t slab_stride = use_uv ? 6u : 4u;
+    if (ctx->slabs_stride != slab_stride) {
+        ctx->cap_slabs = 0;  // (the records' size changed: the allocation is counted in slabs of the new size)
+        if (ctx->d_slabs) O2V_CHECK(hipFree(ctx->d_slabs));
+        ctx->d_slabs = nullptr;
+        ctx->slabs_stride = slab_stride;
+    }
+    uint64_t want_slabs = 0;
+    if (!p.occupancy_only) {
+        size_t free_b = 0, total_b = 0;
+        O2V_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t slab_bytes = (uint64_t) kInlineHits * kBrickCells * slab_stride * sizeof(uint32_t);
+        const uint64_t budget = std::max<uint64_t>(total_b / 6 / slab_bytes, 1);
+        want_slabs = std::max<uint64_t>(ctx->want_slabs_next, ctx->n_tris / 2 + (1u << 14));
+        want_slabs = std::min<uint64_t>(std::min<uint64_t>(want_slabs, n_bricks), budget);
+        want_slabs = std::max<uint64_t>(want_slabs, ctx->cap_slabs);
+        if (const char *tiny = std::getenv("O2V_TEST_TINY_BUFFERS"); tiny && tiny[0] == '1') want_slabs = std::max<uint64_t>(ctx->cap_slabs, 4);
+        if (const char *no = std::getenv("O2V_NO_SLABS"); no && no[0] == '1') want_slabs = ctx->cap_slabs;  // (A/B: every hit pooled)
     }
     uint64_t want_scratch = ctx->cap_scratch;
     uint64_t want_vox = std::max<uint64_t>(ctx->cap_vox, std::min<uint64_t>(8 * ctx->n_tris + (2u << 20), 1ull << 31));
@@ -1032,6 +1073,16 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             if ((rc = grow(ctx, ctx->d_sorted, cap_s, want_hits))) return rc;
             ctx->cap_hits = cap_p;
         }
+        if (want_slabs > ctx->cap_slabs) {
+            if (ctx->d_slabs) O2V_CHECK(hipFree(ctx->d_slabs));
+            ctx->d_slabs = nullptr;
+            ctx->cap_slabs = 0;
+            if (hipMalloc(reinterpret_cast<void **>(&ctx->d_slabs), want_slabs * kInlineHits * kBrickCells * slab_stride * sizeof(uint32_t)) == hipSuccess)
+                ctx->cap_slabs = (uint32_t) std::min<uint64_t>(want_slabs, 0xfffffff0ull);
+            else
+                (void) hipGetLastError();  // (no slabs: every hit is pooled)
+            want_slabs = ctx->cap_slabs;
+        }
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
         if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
         if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
@@ -1058,6 +1109,10 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         p.cap_nodes = ctx->cap_nodes;
         p.cap_hits = ctx->cap_hits;
         p.cap_vox = ctx->cap_vox;
+        p.cap_slabs = ctx->cap_slabs;
+        p.slab_stride = slab_stride;
+        p.slabs = ctx->d_slabs;
+        p.brick_slab = ctx->d_brick_slab;
 
         if ((rc = run_pass(ctx, p, use_uv, n_rounds))) return rc;
         const Counters &h = *ctx->h_ctr;
@@ -1086,6 +1141,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(h.n_big, ctx->cap_big, want_big);
         need(max_nodes, ctx->cap_nodes, want_nodes);
         need(h.n_hits_reserved, ctx->cap_hits, want_hits);
+        need(h.n_sorted, ctx->cap_hits, want_hits);  // (the sorted array also holds what the slabs held of the crowded cells)
+        if (!p.occupancy_only) ctx->want_slabs_next = std::max<uint64_t>(ctx->want_slabs_next, (uint64_t) h.n_dirty + h.n_dirty / 8 + 64);
         need(h.n_vox, ctx->cap_vox, want_vox);
         if (p.direct_max) need(h.n_out, ctx->cap_vox, want_vox);
         if (n_rounds < kMaxRounds && h.n_nodes[n_rounds] != 0) {
@@ -1567,11 +1624,15 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
     O2V_CHECK(hipMemcpy(vox.data(), ctx->d_out, vox.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < ctx->n_vox; ++i) {
         if (vox[i].x != x || vox[i].y != y || vox[i].z != z) continue;
-        const uint32_t n = occ[i].count < max_records ? occ[i].count : max_records;
+        const bool inl = (occ[i].count & kOccInline) != 0u;  // (the hits are in the brick's slab)
+        const uint32_t cnt = occ[i].count & ~kOccInline;
+        const uint32_t n = cnt < max_records ? cnt : max_records;
         std::vector<uint32_t> raw((size_t) n * ctx->sorted_stride);
-        if (n)
-            O2V_CHECK(hipMemcpy(raw.data(), reinterpret_cast<const uint32_t *>(ctx->d_sorted) + (size_t) occ[i].offset * ctx->sorted_stride,
-                                raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const size_t first = inl ? ((size_t) occ[i].offset * kBrickCells + (occ[i].cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) occ[i].offset;
+        for (uint32_t k = 0; k < n; ++k)
+            O2V_CHECK(hipMemcpy(raw.data() + (size_t) k * ctx->sorted_stride,
+                                (inl ? ctx->d_slabs : reinterpret_cast<const uint32_t *>(ctx->d_sorted)) + (first + (size_t) k) * ctx->sorted_stride,
+                                ctx->sorted_stride * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t *r = &raw[(size_t) k * ctx->sorted_stride];
             uint32_t *o = out + k * 6;
@@ -1580,7 +1641,7 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
             o[2] = r[2];
             o[3] = ctx->sorted_stride == 6 ? r[3] : 0u;
             o[4] = ctx->sorted_stride == 6 ? r[4] : 0u;
-            o[5] = occ[i].offset + k;
+            o[5] = (uint32_t) (first + (size_t) k);
         }
         *out_count = n;
         break;
@@ -1607,17 +1668,23 @@ int o2v_hip_debug_hits(o2v_hip_ctx *ctx, uint32_t *out8, uint64_t max_hits, uint
     O2V_CHECK(hipMemcpy(vox.data(), ctx->d_out, vox.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     uint64_t total = 0, end = 0;
     for (const Occ &o : occ) {
-        total += o.count;
-        end = std::max<uint64_t>(end, (uint64_t) o.offset + o.count);
+        total += o.count & ~kOccInline;
+        if (!(o.count & kOccInline)) end = std::max<uint64_t>(end, (uint64_t) o.offset + o.count);
     }
     *n_hits = total;
     if (total > max_hits) return O2V_HIP_OK;  // (the caller sizes its buffer from *n_hits and calls again)
     std::vector<uint32_t> raw((size_t) end * ctx->sorted_stride);
     if (end) O2V_CHECK(hipMemcpy(raw.data(), ctx->d_sorted, raw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // (cells with up to kInlineHits hits keep them side by side in their bricks' slabs)
+    std::vector<uint32_t> slabs((size_t) ctx->cap_slabs * kInlineHits * kBrickCells * ctx->sorted_stride);
+    if (!slabs.empty()) O2V_CHECK(hipMemcpy(slabs.data(), ctx->d_slabs, slabs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     uint64_t k = 0;
     for (uint64_t i = 0; i < ctx->n_vox; ++i) {
-        for (uint32_t h = 0; h < occ[i].count; ++h, ++k) {
-            const uint32_t *r = &raw[((size_t) occ[i].offset + h) * ctx->sorted_stride];
+        const bool inl = (occ[i].count & kOccInline) != 0u;
+        const uint32_t cnt = occ[i].count & ~kOccInline;
+        const size_t first = inl ? ((size_t) occ[i].offset * kBrickCells + (occ[i].cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) occ[i].offset;
+        for (uint32_t h = 0; h < cnt; ++h, ++k) {
+            const uint32_t *r = inl ? &slabs[(first + h) * ctx->sorted_stride] : &raw[(first + h) * ctx->sorted_stride];
             uint32_t *o = out8 + k * 8;
             o[0] = vox[i].x;
             o[1] = vox[i].y;
@@ -1648,7 +1715,7 @@ int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32)
     O2V_CHECK(hipMemcpy(occ.data(), ctx->d_occ, occ.size() * sizeof(Occ), hipMemcpyDeviceToHost));
     for (const Occ &o : occ) {
         uint32_t b = 0;
-        while ((1u << b) < o.count && b < 31) ++b;
+        while ((1u << b) < (o.count & ~kOccInline) && b < 31) ++b;
         out32[b]++;
     }
     return O2V_HIP_OK;

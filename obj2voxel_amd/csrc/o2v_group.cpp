@@ -164,6 +164,75 @@ int o2v_hip_group_exchange_selftest(uint32_t n_threads)
     return 0;
 }
 
+// The RCCL code path of an in-process group without its GPUs: the unique id, one thread per rank joining the communicator
+// (ncclCommInitRank blocks until every rank has), every collective of o2v_hip_comm with patterns whose result is known in
+// closed form, teardown.  No device is selected and the buffers are host memory, so it needs a librccl that works on host
+// memory - the threads-and-memcpy stand-in of tests/mock/mock_rccl.c, named by O2V_RCCL_LIB.  This is how the start-up,
+// id exchange and teardown of an 8-rank group are executed before the first run on an 8-GPU node.  0 = everything behaved.
+int o2v_hip_group_rccl_selftest(uint32_t n_ranks)
+{
+    if (!n_ranks) return O2V_HIP_ERR_BAD_ARGUMENT;
+    uint8_t id[O2V_HIP_COMM_ID_BYTES];
+    std::string err;
+    if (!o2v::rccl_unique_id(id, err)) {
+        std::fprintf(stderr, "[o2v] rccl selftest: %s\n", err.c_str());
+        return 100;
+    }
+    std::vector<o2v_hip_comm *> comm(n_ranks, nullptr);
+    std::vector<std::string> errs(n_ranks);
+    std::vector<int> rc(n_ranks, 0);
+    {
+        std::vector<std::thread> threads;
+        for (uint32_t r = 0; r < n_ranks; ++r)
+            threads.emplace_back([&, r] { comm[r] = o2v::make_rccl_comm(id, (int) r, (int) n_ranks, -1, errs[r]); });
+        for (std::thread &t : threads) t.join();
+    }
+    int result = 0;
+    for (uint32_t r = 0; r < n_ranks; ++r)
+        if (!comm[r]) {
+            std::fprintf(stderr, "[o2v] rccl selftest, rank %u: %s\n", r, errs[r].c_str());
+            result = 101;
+        }
+    if (!result) {
+        std::vector<std::thread> threads;
+        for (uint32_t r = 0; r < n_ranks; ++r)
+            threads.emplace_back([&, r] {
+                o2v_hip_comm *c = comm[r];
+                const uint32_t W = n_ranks, R = r;
+                for (int round = 0; round < 10 && !rc[r]; ++round) {
+                    // (the same patterns as o2v_hip_comm_callbacks_selftest: bounds min / max, histogram sum, gathers, broadcast)
+                    uint32_t mn[3] = {0x80000000u + R, 0xfffffff0u - R, 7u + R}, mx[3] = {0x80000000u + R, 0xfffffff0u - R, 7u + R};
+                    if (c->allreduce_min_u32(mn, 3, nullptr) || c->allreduce_max_u32(mx, 3, nullptr)) { rc[r] = 1; break; }
+                    if (mn[0] != 0x80000000u || mn[1] != 0xfffffff0u - (W - 1) || mn[2] != 7u) { rc[r] = 2; break; }
+                    if (mx[0] != 0x80000000u + (W - 1) || mx[1] != 0xfffffff0u || mx[2] != 7u + (W - 1)) { rc[r] = 3; break; }
+                    std::vector<unsigned long long> sum(2048);
+                    for (size_t i = 0; i < sum.size(); ++i) sum[i] = (unsigned long long) i * 1000003ull + R + (i == 5 ? (1ull << 40) : 0);
+                    if (c->allreduce_sum_u64(sum.data(), sum.size(), nullptr)) { rc[r] = 4; break; }
+                    for (size_t i = 0; i < sum.size() && !rc[r]; ++i)
+                        if (sum[i] != W * ((unsigned long long) i * 1000003ull + (i == 5 ? (1ull << 40) : 0)) + (unsigned long long) W * (W - 1) / 2) rc[r] = 5;
+                    const size_t per = 24;
+                    std::vector<unsigned char> gather(per * W, 0xee);
+                    for (size_t i = 0; i < per; ++i) gather[R * per + i] = (unsigned char) (R * 31 + i);
+                    if (c->allgather(gather.data(), per, nullptr)) { rc[r] = 6; break; }
+                    for (uint32_t q = 0; q < W && !rc[r]; ++q)
+                        for (size_t i = 0; i < per; ++i)
+                            if (gather[q * per + i] != (unsigned char) (q * 31 + i)) rc[r] = 7;
+                    const int root = (int) W - 1 - (round % (int) W);
+                    std::vector<unsigned char> bc(1000);
+                    for (size_t i = 0; i < bc.size(); ++i) bc[i] = (unsigned char) ((int) R == root ? i * 7 : 0);
+                    if (c->broadcast(bc.data(), bc.size(), root, nullptr)) { rc[r] = 8; break; }
+                    for (size_t i = 0; i < bc.size() && !rc[r]; ++i)
+                        if (bc[i] != (unsigned char) (i * 7)) rc[r] = 9;
+                }
+            });
+        for (std::thread &t : threads) t.join();
+        for (uint32_t r = 0; r < n_ranks; ++r)
+            if (rc[r] && !result) result = rc[r];
+    }
+    for (o2v_hip_comm *c : comm) delete c;  // ncclCommDestroy
+    return result;
+}
+
 int o2v_hip_group_create(const int *devices, uint32_t n_devices, o2v_hip_group **out)
 {
     if (!devices || !n_devices || !out) return O2V_HIP_ERR_BAD_ARGUMENT;

@@ -180,19 +180,20 @@ def test_planned_slabs_union_equals_whole_and_balance(dv, oracle, n_slabs):
     cuts, bnd = dv.plan_slabs(res, n_slabs)
     assert cuts[0] == 0 and cuts[-1] == res and all(a < b for a, b in zip(cuts, cuts[1:]))
     assert np.array_equal(bnd, np.concatenate([v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)]).astype(np.float32))
-    parts, hits = [], []
+    parts, hits, work = [], [], []
     for k in range(n_slabs):
         parts.append(dv.voxelize(res, strategy=1, zslab=(cuts[k], cuts[k + 1]), bounds=bnd))
         hits.append(dv.stats()["hits"])
+        work.append(dv.stats()["hits"] + 4.0 * dv.stats()["leaves"])   # what the plan balances: hits + 4 per leaf (k_zhist)
     assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), meshes.sorted_voxels(got))
     assert sum(hits) == whole_hits
-    assert max(hits) < 1.08 * whole_hits / n_slabs, (cuts, hits)
+    assert max(work) < 1.08 * sum(work) / n_slabs, (cuts, hits, work)
     equal = []
     for k in range(n_slabs):
         z0, z1 = k * res // n_slabs, (k + 1) * res // n_slabs
         dv.voxelize(res, strategy=1, zslab=(z0, z1), read=False)
-        equal.append(dv.stats()["hits"])
-    assert max(equal) > max(hits)
+        equal.append(dv.stats()["hits"] + 4.0 * dv.stats()["leaves"])
+    assert max(equal) > max(work)
 
 
 def test_planned_slabs_edge_cases(dv):
@@ -448,3 +449,35 @@ def test_direct_max_path_with_textures(dv, oracle, supersampling, wrap):
     _compare(got, want)
     st = dv.stats()
     assert 0 < st["direct_hits"] < st["hits"]
+
+
+@pytest.mark.parametrize("mode", ["none", "few"])
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_hit_slabs_are_a_budget_not_a_requirement(oracle, monkeypatch, mode, strategy):
+    """A cell's first eight hits go straight into the slab of its brick (k_voxelize -> Params::slabs), the rest through the pool
+    and the counting sort.  The slabs are sized from a budget: with none at all (O2V_NO_SLABS=1, a fresh context) every hit is
+    pooled, with four slabs (the tiny-buffer hook) a handful of bricks are inline and all the others pooled - both must give
+    the oracle's voxels, like the default.  Textured mesh with subdivided triangles, cells from 1 to hundreds of hits, 2 x
+    supersampling; MAX takes the route through the pool for the leaves of subdivided triangles only."""
+    from obj2voxel_amd import hip
+    if mode == "none":
+        monkeypatch.setenv("O2V_NO_SLABS", "1")
+    else:
+        monkeypatch.setenv("O2V_TEST_TINY_BUFFERS", "1")
+    v, uv = meshes.uv_sphere(24, with_uv=True)
+    big = meshes.box_room(2) * 0.8 + 0.1
+    v = np.concatenate([v * 0.4 + 0.5, big, meshes.uv_sphere(30, radius=0.02, center=(0.5, 0.5, 0.93))])
+    T = len(v)
+    uvs = np.concatenate([uv, np.tile(np.array([0, 0, 1, 0, 1, 1], np.float32), (T - len(uv), 1))])
+    types = np.full(T, hip.TRI_TEXTURED, np.uint32)
+    types[1::3] = hip.TRI_UNTEXTURED
+    kw = dict(uvs=uvs, types=types, colors=meshes.triangle_colors(T), texids=np.zeros(T, np.int32))
+    tex = [(meshes.checker_texture(64, 8), 1)]
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_textures(tex)
+        d.set_triangles(v, **kw)
+        got = d.voxelize(160, strategy=strategy, supersampling=2)
+        _compare(got, oracle.voxelize(v, 160, strategy=strategy, supersampling=2, textures=tex, **kw))
+    finally:
+        d.close()

@@ -61,6 +61,28 @@ def test_line_of_the_profiled_workload_uses_the_measured_counters():
     assert r["valu_instructions_per_launch"] == int(cur["kernels"]["k_voxelize<false>"]["sq"]["SQ_INSTS_VALU"])
     assert out["pipeline"]["measured_traffic_bytes"] > 0 and out["roofline_hbm_view"]["bound"] == "hbm"
     assert abs(out["value"] - cur["workload_stats"]["voxels"] / 1.18e-3 / 1e6) < 1
+    # the mix-weighted ceiling: recomputable from profiles/ alone (histogram x measured issue costs; instruction count; time)
+    isa = json.load(open(bench.ISA_HIST))
+    m = isa["k_voxelize<false>"]["mix_cycles_per_valu"]
+    assert 2.0 < m < 5.0 and abs(r["mix_cycles_per_valu_instruction"] - m) < 1e-2
+    assert abs(r["mix_ceiling"] - bench.N_SIMDS * bench.CLOCK_GHZ / m) < 0.1
+    assert abs(r["frac_of_mix_ceiling"] - r["achieved"] / r["mix_ceiling"]) < 1e-3
+    assert r["frac_of_mix_ceiling"] > r["frac"]          # (the 2-cycle peak is the looser bound)
+    assert bool(r.get("mix_stale")) == (isa.get("build_id") != hip.build_id())
+
+
+def test_isa_histogram_prices_every_opcode_of_the_clip_loop():
+    """tools/isa_hist.py: the committed histogram names the rates file it was priced with, and every opcode's price is one of
+    that file's measured loops (w4 column)."""
+    isa = json.load(open(bench.ISA_HIST))
+    rates = json.load(open(os.path.join(bench.ROOT, isa["rates_file"])))["results"]
+    for k in ("k_voxelize<false>", "k_voxelize<true>"):
+        e = isa[k]
+        total = 0.0
+        for op, d in e["valu_by_opcode"].items():
+            assert d["priced_as"] in rates and abs(rates[d["priced_as"]]["w4"] - d["cycles"]) < 1e-9, op
+            total += d["count"] * d["cycles"]
+        assert abs(total / e["valu"] - e["mix_cycles_per_valu"]) < 1e-6
 
 
 def test_other_workloads_get_an_estimate_not_the_counters():

@@ -162,6 +162,16 @@ def analyze(asm_path, rates):
     return out
 
 
+def source_build_id():
+    """The hash the Makefile gives the library (o2v_hip_build_id): sha256 of the device sources, first 16 hex digits."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(SRC, "o2v_device.hip")] + sorted(glob.glob(os.path.join(SRC, "o2v_dev_*.hpp"))) + [os.path.join(SRC, "o2v_math.h")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r03", "valu_rates.json"))
@@ -173,6 +183,7 @@ def main():
     asm = a.asm or compile_asm()
     res = analyze(asm, rates)
     res["rates_file"] = os.path.relpath(a.rates, ROOT)
+    res["build_id"] = source_build_id()
     res["note"] = ("static histogram of the clip loop (phase 2 of k_voxelize), priced with the w4 column of the rates file; "
                    "mix_cycles_per_valu x (VALU instructions of a launch) / (SIMDs x clock) is the mix-weighted minimum issue time")
     if a.json:

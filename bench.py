@@ -407,18 +407,20 @@ def report(args, n, run, dv, comm):
         "expand": 36 * T + 96 * L + 8 * tiles,
         # leaves and tiles staged, a job record written and read per surviving candidate, then per hit: 64-bit atomic + flag
         # byte (direct) or pool record + counter atomic + flag byte (pooled)
-        "voxelize": 96 * L + 8 * tiles + 16 * st["jobs"] + (8 + 1) * Hd + (32 + 4 + 1) * Hp,
+        # (a pooled hit: the counter atomic + its record, in the brick's slab - the first eight of a cell - or in the pool)
+        "voxelize": 96 * L + 8 * tiles + 16 * st["jobs"] + (8 + 1) * Hd + (REC + 4) * Hp + (32 * slots if Hp else 0),
         # counting sort of the pooled hits (nothing to do when every hit was direct)
-        "scan": (B + 4 * CPB * D + (16 + 4) * Vr + 32 * slots + (4 + REC) * Hp + 4 * CPB * D) if Hp else 0,
+        # the listed bricks' counters read, the occupied cells filed; the pool's overflow hits (slots) scattered; counters reset
+        "scan": (4 * CPB * D + 16 * Vr + (32 + 4 + REC) * slots + 4 * CPB * D) if Hp else 0,
         # replay of the pooled hits + emission of the 64-bit grid: flag map, the dirty bricks (8 bytes per cell) read, the occupied
         # 32-byte lane groups zeroed (at most one per voxel), records written
         "resolve": (16 * Vr + REC * Hp if Hp else 0) + ((B + 8 * CPB * D + 32 * Vr + 16 * Vr) if direct else 16 * Vr),
     }
     stage_kernels = {
         "bounds": ["k_init", "k_bounds", "k_setup"],
-        "expand": ["k_expand_roots", "k_expand_nodes", "k_expand_big"],
+        "expand": ["k_expand_roots", "k_expand_nodes", "k_expand_big", "k_mark_bricks"],
         "voxelize": ["k_voxelize<false>", "k_voxelize<true>"],
-        "scan": ["k_scan_flags", "k_scan_bricks", "k_scatter", "k_reset_bricks"],
+        "scan": ["k_scan_flags", "k_scan_bricks", "k_promote", "k_scatter", "k_reset_bricks"],
         "resolve": ["k_resolve<4>", "k_resolve<6>", "k_resolve_list16<4>", "k_resolve_list16<6>", "k_resolve_wave<32>", "k_resolve_wave<64>",
                     "k_resolve_sorted", "k_resolve_big", "k_resolve_huge", "k_pick", "k_emit_max"],
     }

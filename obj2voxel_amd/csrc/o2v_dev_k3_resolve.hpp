@@ -254,10 +254,14 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const SortedView &
     return f.finish(p.blend);
 }
 
+// `part` 0: the inline cells (hits in their bricks' slabs: they need nothing but k_scan_bricks' list, so this launch runs
+// beside the counting sort); 1: the short cells of bricks without a slab (hits in the sorted array; none if every listed brick
+// has a slab, the usual case).
 template <uint32_t STRIDE>
 __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ, SortedView sorted_dyn, SortedView slabs_dyn,
-                                                    const Counters *c, Materials m, uint4 *out, Params p)
+                                                    const Counters *c, Materials m, uint4 *out, uint32_t part, Params p)
 {
+    if (part == 1u && c->n_dirty <= p.cap_slabs) return;
     __shared__ DevTexture s_tex[kTexCache];  // the first textures' descriptors (the colour lookup reads them per group)
     if (pass_overflowed(c, p)) return;
     if (STRIDE == 6) {
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         if (count > kShortList) continue;  // filed for another tier by k_scan_bricks
         // an inline cell's hits are in its brick's slab (Occ::offset names it), the others' in the sorted array
         const bool inl = (o.count & kOccInline) != 0u;
+        if (inl != (part == 0u)) continue;
         const SortedView from{inl ? slabs_dyn.base : sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
         const size_t first = inl ? ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) o.offset;
         GroupFold f;

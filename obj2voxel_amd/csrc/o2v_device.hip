@@ -97,8 +97,11 @@ struct o2v_hip_ctx {
     // work buffers (grown on demand)
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;  // pinned
+    uint64_t no_pool_key = 0;   // (key + 1 of) the mesh and settings whose last pass pooled no hits (run_pass: k_mark_bricks left out)
+    bool marked_bricks = false, mark_missing = false; // the current pass listed its bricks before k_voxelize
+    bool ctr_clean = false;     // d_ctr was zeroed (k_init) behind the last pass and nothing has touched it since
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the cooperative resolve tiers run beside tier 1
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     unsigned long long *d_zhist = nullptr, *h_zhist = nullptr;  // kPlanBins each (h_: pinned), o2v_hip_plan_slabs
     float2 *d_zrange = nullptr;      // z extent per 256 triangles, written by the slab plan
     float *d_zrange_xform = nullptr;  // the transform they were computed with (12 floats)
@@ -297,13 +300,16 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     const uint32_t persistent = (uint32_t) ctx->num_cus * 8u;
     ctx->ktimes_used = 0;
     O2V_CHECK(hipEventRecord(ctx->ev[0], s));
-    O2V_LAUNCH("k_init", s, k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    // (the counters were zeroed behind the previous pass, off its critical path, unless something else used them since)
+    if (!ctx->ctr_clean) O2V_LAUNCH("k_init", s, k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    ctx->ctr_clean = false;
     if (!p.bounds_known) {
         // one workgroup per CU: every workgroup ends with six atomics on the same six words, which serialise (1024
         // workgroups: 43 us for 31 MB, 256: 24 us)
         O2V_LAUNCH("k_bounds", s, k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
     }
+    // (letting the last workgroup of k_bounds compute the transform - one launch less - was measured: the stage 0.021 -> 0.027 ms)
     O2V_LAUNCH("k_setup", s, k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
     O2V_CHECK(hipEventRecord(ctx->ev[1], s));
 
@@ -330,7 +336,12 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
     }
     O2V_LAUNCH("k_expand_big", s, k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
-    if (!p.occupancy_only) {
+    // (a mesh that pooled no hits in its last pass with these settings - every triangle whole and on the direct MAX path - will
+    // not pool any now: the two launches are left out; should K1's counters say otherwise, the pass is repeated with them)
+    const uint64_t mark_key = ctx->tri_generation * 1000003ull + p.blend * 7u + p.S * 131ull + p.zs0 * 31ull + p.zs1 + p.exact_clip * 3u;
+    const bool skip_mark = !ctx->force_general && ctx->no_pool_key == mark_key + 1u;
+    ctx->marked_bricks = !p.occupancy_only && !skip_mark;
+    if (ctx->marked_bricks) {
         // The bricks that can receive pooled hits are listed before k_voxelize (every brick a leaf's clamped box touches: a
         // superset of the bricks that do), and every listed brick gets a hit slab: the first kInlineHits hits of a cell go
         // there directly.  Neither kernel has work if the pass pools no hits (decided on the device from K1's counters).
@@ -382,18 +393,21 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         }
     }
 
+    if (run_general && !ctx->marked_bricks && !p.occupancy_only) {
+        // the guess above was wrong (it cannot be for the same triangles and settings): no brick has a slab number, the pass is void
+        ctx->no_pool_key = 0;
+        ctx->mark_missing = true;
+        run_general = false;
+    }
+    else if (!p.occupancy_only) {
+        ctx->no_pool_key = run_general ? 0 : mark_key + 1u;
+    }
+    const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
+                             ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
     if (run_general) {
         // (the brick list was made before k_voxelize: see k_mark_bricks)
-        const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
-                                 ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
         O2V_LAUNCH("k_scan_bricks", s, k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, lists, p);
-        O2V_LAUNCH("k_promote", s, k_promote, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_occ, lists, ctx->d_ctr,
-                           reinterpret_cast<uint32_t *>(ctx->d_sorted), p);
-        O2V_LAUNCH("k_scatter", s, k_scatter, dim3(persistent), dim3(kBlock), 0, s, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
-                           reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
-        O2V_LAUNCH("k_reset_bricks", s, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_grid,
-                           ctx->d_dirty_list, ctx->d_ctr, p);
     }
     ctx->last_ran_general = run_general;
     O2V_CHECK(hipEventRecord(ctx->ev[4], s));
@@ -401,8 +415,12 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
     if (run_general) {
         const SortedView sorted_view{reinterpret_cast<const uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u};
-        // The tiers work on disjoint cells and were filed by k_scan_bricks, so they run side by side: tier 1 on the
-        // main stream, the cooperative tiers (short, latency-bound launches) on three auxiliary streams.
+        const SortedView slab_view{ctx->d_slabs, use_uv ? 6u : 4u};
+        // What follows k_scan_bricks runs side by side (the tiers work on disjoint cells, filed by k_scan_bricks):
+        //   main stream   tier 1 on the inline cells - most cells; their hits are in the slabs, so it needs no sorted array -
+        //                 then, once that exists, on the short cells of bricks without a slab (none as a rule)
+        //   aux 0         the counting sort of what the slabs do not hold: k_promote, k_scatter; then the 9..16-hit tier
+        //   aux 1, 2      (behind the sort) the counter reset and the cooperative tiers
         const bool fork = debug_sync_level() != 1;
         hipStream_t sw = s, sm = s, sl = s;
         if (fork) {
@@ -410,26 +428,42 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             sm = ctx->aux[1];
             sl = ctx->aux[2];
             O2V_CHECK(hipEventRecord(ctx->ev_fork, s));
-            for (hipStream_t a : ctx->aux) O2V_CHECK(hipStreamWaitEvent(a, ctx->ev_fork, 0));
+            O2V_CHECK(hipStreamWaitEvent(sw, ctx->ev_fork, 0));
         }
-        // (cells with up to kInlineHits hits: straight from their bricks' slabs)
-        const SortedView slab_view{ctx->d_slabs, use_uv ? 6u : 4u};
+        O2V_LAUNCH("k_promote", sw, k_promote, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_occ, lists, ctx->d_ctr,
+                           reinterpret_cast<uint32_t *>(ctx->d_sorted), p);
+        O2V_LAUNCH("k_scatter", sw, k_scatter, dim3(persistent), dim3(kBlock), 0, sw, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
+                           reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
+        if (fork) {
+            O2V_CHECK(hipEventRecord(ctx->ev_sorted, sw));
+            O2V_CHECK(hipStreamWaitEvent(sm, ctx->ev_sorted, 0));
+            O2V_CHECK(hipStreamWaitEvent(sl, ctx->ev_sorted, 0));
+        }
         if (use_uv)
             O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
-                               ctx->d_out, p);
+                               ctx->d_out, 0u, p);
         else
             O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
-                               ctx->d_out, p);
+                               ctx->d_out, 0u, p);
+        if (fork) O2V_CHECK(hipStreamWaitEvent(s, ctx->ev_sorted, 0));
+        if (use_uv)
+            O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
+                               ctx->d_out, 1u, p);
+        else
+            O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
+                               ctx->d_out, 1u, p);
         if (use_uv)
             O2V_LAUNCH("k_resolve_list16<6>", sw, k_resolve_list16<6>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
                                &ctx->d_ctr->n_lane16, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         else
             O2V_LAUNCH("k_resolve_list16<4>", sw, k_resolve_list16<4>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
                                &ctx->d_ctr->n_lane16, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_LAUNCH("k_resolve_wave<32>", sw, k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane,
-                           &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_LAUNCH("k_reset_bricks", sm, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_grid,
+                           ctx->d_dirty_list, ctx->d_ctr, p);
         O2V_LAUNCH("k_resolve_wave<64>", sm, k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_w64,
                            &ctx->d_ctr->n_w64, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
+        O2V_LAUNCH("k_resolve_wave<32>", sm, k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_lane,
+                           &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
         O2V_LAUNCH("k_resolve_sorted<64,256>", sm, (k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 8u), dim3(64), 0, sm,
                            ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
@@ -482,6 +516,9 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         it->ms += ms;
         it->launches += 1;
     }
+    // the next pass's counters: zeroed now, behind this pass (its results are on the host)
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    ctx->ctr_clean = true;
     return O2V_HIP_OK;
 }
 
@@ -542,6 +579,7 @@ int ctx_finish_triangles(o2v_hip_ctx *ctx, bool any_textured, const TriHints *hi
         ctx->any_textured = hints->any_textured;
     }
     else if (count) {
+        ctx->ctr_clean = false;
         hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
         hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (count * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
@@ -590,6 +628,7 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
             return O2V_HIP_ERR_HIP;
         }
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_sorted, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_k1, hipEventDisableTiming) == hipSuccess;
     for (int j = 0; j < 3 && ok; ++j)
         ok = hipStreamCreateWithFlags(&ctx->aux[j], hipStreamNonBlocking) == hipSuccess &&
@@ -650,6 +689,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
         if (b.e1) (void) hipEventDestroy(b.e1);
     }
     if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_sorted) (void) hipEventDestroy(ctx->ev_sorted);
     if (ctx->ev_k1) (void) hipEventDestroy(ctx->ev_k1);
     for (int j = 0; j < 3; ++j) {
         if (ctx->ev_join[j]) (void) hipEventDestroy(ctx->ev_join[j]);
@@ -1149,6 +1189,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             n_rounds = kMaxRounds;  // unusually deep subdivision
             again = true;
         }
+        if (ctx->mark_missing) {
+            // (run_pass left k_mark_bricks out on the strength of the last pass and K1's counters then asked for the general route)
+            ctx->mark_missing = false;
+            again = true;
+        }
         if (!again && !ctx->last_ran_general && h.n_hits != h.n_direct) {
             // The stages behind k_voxelize were chosen from K1's counters alone, on the premise that only leaves of subdivided
             // triangles are pooled (order key 0 <=> unsplit triangle, a convention of k_expand_*).  Pooled hits exist although
@@ -1247,6 +1292,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
         ctx->err = std::string("collective failed: ") + comm->err;
         return rc;
     };
+    ctx->ctr_clean = false;
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
     if (!p.bounds_known) {
         if (n_range)

@@ -166,11 +166,15 @@ def kernel_algorithmic_bytes(stats, textured, strategy_blend):
     out = {
         "k_bounds": 36 * T,
         "k_expand_roots": (36 + (24 if textured else 0)) * T + 96 * L + 8 * tiles,
-        ("k_voxelize<true>" if textured else "k_voxelize<false>"): 96 * L + 8 * tiles + 16 * jobs + (8 + 1 + pick) * Hd + (32 + 4 + 1) * Hp,
+        # per pooled hit: the counter atomic and the record - in the brick's slab for a cell's first eight hits, in the pool (32
+        # bytes) for the later ones of crowded cells, which `slots` counts
+        ("k_voxelize<true>" if textured else "k_voxelize<false>"): 96 * L + 8 * tiles + 16 * jobs + (8 + 1 + pick) * Hd + (4 + rec) * Hp + 32 * (slots if Hp else 0),
     }
     if Hp:
-        out["k_scan_bricks"] = 4 * cpb * D + 20 * V
-        out["k_scatter"] = 32 * slots + (4 + rec) * Hp
+        # (D = the bricks listed before k_voxelize: every brick a leaf's box touches)
+        out["k_mark_bricks"] = 12 * L + D
+        out["k_scan_bricks"] = 4 * cpb * D + 16 * V
+        out["k_scatter"] = (32 + 4 + rec) * slots
         out["k_reset_bricks"] = 4 * cpb * D
         out["k_resolve<6>" if textured else "k_resolve<4>"] = 16 * V + rec * Hp + 16 * V   # (all tiers together: cells + records + output)
     if direct and stats.get("certain_hits"):

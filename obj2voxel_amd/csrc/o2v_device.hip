@@ -430,7 +430,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             O2V_CHECK(hipEventRecord(ctx->ev_fork, s));
             O2V_CHECK(hipStreamWaitEvent(sw, ctx->ev_fork, 0));
         }
-        O2V_LAUNCH("k_promote", sw, k_promote, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_occ, lists, ctx->d_ctr,
+        O2V_LAUNCH("k_promote", sw, k_promote, dim3((uint32_t) ctx->num_cus * 2u, kResolveClasses), dim3(kBlock), 0, sw, ctx->d_occ, lists, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), p);
         O2V_LAUNCH("k_scatter", sw, k_scatter, dim3(persistent), dim3(kBlock), 0, sw, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);

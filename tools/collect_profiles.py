@@ -11,7 +11,7 @@ import re
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = "gpurun_out/prof"
 out_dir = os.path.join("profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
@@ -42,7 +42,7 @@ def counters(path):
 
 
 summary = {}
-for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_max", "config1", "config3"):
+for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_max", "scan_colored_max", "config1", "config3"):
     stats = find(f"{src}/{w}_stats/**/s_kernel_stats.csv")
     if not stats:
         continue

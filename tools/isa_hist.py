@@ -27,30 +27,41 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # Which measured loop of tools/ubench/valu_rates.hip prices an opcode (w4 column: four wavefronts per SIMD, as k_voxelize
 # runs).  Opcodes that were not measured take the class of their closest measured relative; the mapping is printed with -v.
+# (several candidates: the first one the rates file holds is used - round 3's file has fewer loops than round 4's)
 PRICE_KEYS = [
-    (r"^v_(mul|add|sub|subrev)_f32", "ind_mul_f32"),
-    (r"^v_(and|or|xor|not)_b32", "ind_and_b32"),
-    (r"^v_(add|sub|subrev)(_co)?_u32", "ind_add_u32"),
-    (r"^v_mov_b32", "ind_mov"),
-    (r"^v_(lshlrev|lshrrev|ashrrev)_b32", "ind_and_b32"),
-    (r"^v_accvgpr", "ind_mov"),
-    (r"^v_rcp_|^v_rsq_|^v_sqrt_|^v_exp_|^v_log_", "ind_rcp_f32"),
-    (r"^v_cmp|^v_cmpx", "ind_cmp_sgpr"),
-    (r"^v_cndmask_b32_e64", "ind_cndmask_e64"),
-    (r"^v_cndmask_b32", "ind_cndmask_e64"),  # (runs of the two-operand form are excluded by tests/test_host_isa.py)
-    (r"^v_(fma|fmac|mad|mac)_f32", "ind_fma_f32"),
-    (r"^v_(max|min)3?_f32|^v_med3", "ind_max_f32"),
-    (r"^v_(fma|mul|add)_f64", "ind_mul_f64"),
-    (r"^v_cvt_f64_f32", "ind_cvt_f64_f32"),
-    (r"^v_cvt_f32_f64", "ind_cvt_f32_f64"),
-    (r"^v_cvt_", "ind_cvt_f32_f64"),
-    (r"^v_div_scale", "ind_div_scale"),
-    (r"^v_div_fixup", "ind_div_fixup"),
-    (r"^v_div_fmas", "dep_div_fmas"),
-    (r"^v_readlane|^v_readfirstlane|^v_writelane", "ind_readlane"),
-    (r"^v_alignbit|^v_bfe|^v_bfi|^v_perm|^v_lshl_or|^v_lshl_add|^v_add_lshl|^v_and_or|^v_or3|^v_add3|^v_mad_u|^v_mul_u32_u24|^v_mul_lo|^v_mul_hi|^v_mbcnt|^v_bcnt|^v_ffb|^v_max_u|^v_min_u|^v_max_i|^v_min_i", "ind_lshl_or"),
-    (r"_dpp$|^v_mov_b32_dpp", "ind_dpp_mov"),
-    (r"^v_pk_", "ind_pk_mul_f32"),
+    (r"^v_(mul|add|sub|subrev)_f32", ["ind_mul_f32"]),
+    (r"^v_(or|xor)_b32", ["ind_or_b32", "ind_and_b32"]),
+    (r"^v_(and|not)_b32", ["ind_and_b32"]),
+    (r"^v_(add|sub|subrev)(_co)?_u32", ["ind_add_u32"]),
+    (r"^v_mov_b32_dpp|_dpp$", ["ind_dpp_mov"]),
+    (r"^v_mov_b32", ["ind_mov"]),
+    (r"^v_lshlrev_b32", ["ind_lshlrev_b32", "ind_and_b32"]),
+    (r"^v_(lshrrev|ashrrev)_b32", ["ind_lshrrev_b32", "ind_and_b32"]),
+    (r"^v_accvgpr", ["ind_mov"]),
+    (r"^v_rcp_|^v_rsq_|^v_sqrt_|^v_exp_|^v_log_", ["ind_rcp_f32"]),
+    (r"^v_cmpx?_\w+_(u|i)(16|32|64)", ["ind_cmp_u32", "ind_cmp_sgpr"]),
+    (r"^v_cmp|^v_cmpx", ["ind_cmp_sgpr"]),
+    (r"^v_cndmask_b32", ["ind_cndmask_e64"]),  # (runs of the two-operand form are excluded by tests/test_host_isa.py)
+    (r"^v_(fma|fmac|mad|mac)_f32", ["ind_fma_f32"]),
+    (r"^v_(max|min)3_f32|^v_med3", ["ind_max3_f32", "ind_min3", "ind_max_f32"]),
+    (r"^v_(max|min)_f32", ["ind_max_f32"]),
+    (r"^v_(fma|mul|add)_f64", ["ind_mul_f64"]),
+    (r"^v_cvt_f64_f32", ["ind_cvt_f64_f32"]),
+    (r"^v_cvt_f32_f64", ["ind_cvt_f32_f64"]),
+    (r"^v_cvt_f32_(u|i)32|^v_cvt_(u|i)32_f32", ["ind_cvt_f32_u32", "ind_cvt_f32_f64"]),
+    (r"^v_cvt_", ["ind_cvt_f32_f64"]),
+    (r"^v_div_scale", ["ind_div_scale"]),
+    (r"^v_div_fixup", ["ind_div_fixup"]),
+    (r"^v_div_fmas", ["dep_div_fmas"]),
+    (r"^v_readlane|^v_readfirstlane|^v_writelane", ["ind_readlane"]),
+    (r"^v_or3_b32|^v_bitop3", ["ind_or3_b32", "ind_lshl_or"]),
+    (r"^v_and_or_b32", ["ind_and_or_b32", "ind_lshl_or"]),
+    (r"^v_bfe_|^v_bfi_", ["ind_bfe_u32", "ind_lshl_or"]),
+    (r"^v_mbcnt", ["ind_mbcnt", "ind_lshl_or"]),
+    (r"^v_lshl_add_u64|^v_lshlrev_b64|^v_mad_u64", ["ind_lshl_add_u64", "ind_lshl_or"]),
+    (r"^v_mul_u32_u24|^v_mad_u32_u24|^v_mul_lo|^v_mul_hi", ["ind_mul_u32_u24", "ind_lshl_or"]),
+    (r"^v_alignbit", ["ind_alignbit"]),
+    (r"^v_pk_", ["ind_pk_mul_f32"]),
 ]
 DEFAULT_KEY = "ind_lshl_or"  # the 4-cycle class
 
@@ -109,10 +120,12 @@ def clip_loop(body):
     return idx
 
 
-def price_key(op):
-    for pat, key in PRICE_KEYS:
+def price_key(op, rates=None):
+    for pat, keys in PRICE_KEYS:
         if re.search(pat, op):
-            return key
+            for key in keys:
+                if rates is None or key in rates:
+                    return key
     return DEFAULT_KEY
 
 
@@ -129,7 +142,7 @@ def summarize(ops, rates):
     valu = {o: n for o, n in ops.items() if o.startswith("v_")}
     cost = {}
     for o in valu:
-        k = price_key(o)
+        k = price_key(o, rates)
         r = rates.get(k) or rates[DEFAULT_KEY]
         cost[o] = (k, r["w4"])
     n_valu = sum(valu.values())

@@ -13,7 +13,7 @@ SQ1="SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_W
 SQ2="SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"
 # front end and pipes (instruction fetches, scalar unit cycles, the second VALU pipe, transcendentals, SE cycles)
 SQ3="SQ_IFETCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU_TRANS_F32 SQ_INST_LEVEL_VMEM"
-WL="${@:-config2 config2_colored_max config2_blend config2_textured_max config1 config3}"
+WL="${@:-config2 config2_colored_max config2_blend config2_textured_max scan_colored_max config1 config3}"
 for W in $WL; do
   if [ $W = config2 ]; then CMD="python bench.py --no-cpu-baseline --no-capi --no-routes"; S1="--steps 20 --warmup 3"; S2="--steps 3 --warmup 1"
   else CMD="python tools/run_workload.py $W"; S1="--steps 10 --warmup 2"; S2="--steps 3 --warmup 1"; fi
@@ -33,7 +33,11 @@ python -c "from obj2voxel_amd import hip; print(hip.build_id())" > $OUT/build_id
 [ -x tools/ubench/_build/valu_rates ] && timeout -k 5 60 tools/ubench/_build/valu_rates > $OUT/valu_rates.json 2>/dev/null
 # the summaries are made here, so that the bench line below reads the counters of THIS build (profiles/current.json), and
 # travel back under gpurun_out/ (copy gpurun_out/prof/profiles/* into profiles/ afterwards)
-ROUND=${O2V_ROUND:-r03}
+ROUND=${O2V_ROUND:-r04}
+mkdir -p profiles/$ROUND
+# the clip loop's instruction histogram priced with the measured issue costs (the mix-weighted ceiling of bench.py's roofline)
+RATES=profiles/r03/valu_rates.json; [ -s $OUT/valu_rates.json ] && cp $OUT/valu_rates.json profiles/$ROUND/valu_rates.json && RATES=profiles/$ROUND/valu_rates.json
+python tools/isa_hist.py --rates $RATES --json profiles/$ROUND/isa_hist.json > $OUT/isa_hist.txt 2>&1 && cp profiles/$ROUND/isa_hist.json profiles/current_isa.json
 python tools/collect_profiles.py $ROUND > $OUT/collect.log 2>&1
 # the bench line itself (with the routes, the CPU baseline and the C API wall time), unprofiled
 timeout -k 5 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
@@ -42,7 +46,7 @@ cp $OUT/bench_line.json profiles/$ROUND/bench_line.json
 timeout -k 5 200 python tools/predict_scaling.py 8 weak > $OUT/predict_scaling_8_weak.jsonl 2>&1
 timeout -k 5 500 python tools/predict_scaling.py 8 config4 > $OUT/predict_scaling_8_config4.jsonl 2>&1
 cp $OUT/predict_scaling_8_*.jsonl profiles/$ROUND/ 2>/dev/null
-mkdir -p $OUT/profiles && cp -r profiles/$ROUND profiles/current.json $OUT/profiles/
+mkdir -p $OUT/profiles && cp -r profiles/$ROUND profiles/current.json profiles/current_isa.json $OUT/profiles/
 # keep the merge small: only the summaries travel back
 find $OUT -name "*_agent_info.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete
 du -sh $OUT; tail -c 400 $OUT/bench_line.json

@@ -97,6 +97,20 @@ KERNEL_IND(ind_add_u32, "v_add_u32 %0, %0, %8\n", "v_add_u32 %1, %1, %8\n", "v_a
 KERNEL_IND(ind_lshl_or, "v_lshl_or_b32 %0, %0, 1, %8\n", "v_lshl_or_b32 %1, %1, 1, %8\n", "v_lshl_or_b32 %2, %2, 1, %8\n", "v_lshl_or_b32 %3, %3, 1, %8\n")
 KERNEL_IND(ind_saveexec, "s_and_saveexec_b64 s[20:21], vcc\n", "v_mul_f32 %1, %1, %8\n", "s_or_b64 exec, exec, s[20:21]\n", "v_mul_f32 %3, %3, %8\n")
 
+// opcodes of the clip loop that round 3 priced by a relative (tools/isa_hist.py: PRICE_KEYS)
+KERNEL_IND(ind_or_b32, "v_or_b32 %0, %0, %8\n", "v_or_b32 %1, %1, %8\n", "v_or_b32 %2, %2, %8\n", "v_or_b32 %3, %3, %8\n")
+KERNEL_IND(ind_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0\n", "v_lshlrev_b32 %1, 3, %1\n", "v_lshlrev_b32 %2, 3, %2\n", "v_lshlrev_b32 %3, 3, %3\n")
+KERNEL_IND(ind_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0\n", "v_lshrrev_b32 %1, 3, %1\n", "v_lshrrev_b32 %2, 3, %2\n", "v_lshrrev_b32 %3, 3, %3\n")
+KERNEL_IND(ind_or3_b32, "v_or3_b32 %0, %0, %8, %9\n", "v_or3_b32 %1, %1, %8, %9\n", "v_or3_b32 %2, %2, %8, %9\n", "v_or3_b32 %3, %3, %8, %9\n")
+KERNEL_IND(ind_and_or_b32, "v_and_or_b32 %0, %0, %8, %9\n", "v_and_or_b32 %1, %1, %8, %9\n", "v_and_or_b32 %2, %2, %8, %9\n", "v_and_or_b32 %3, %3, %8, %9\n")
+KERNEL_IND(ind_bfe_u32, "v_bfe_u32 %0, %0, 3, 6\n", "v_bfe_u32 %1, %1, 3, 6\n", "v_bfe_u32 %2, %2, 3, 6\n", "v_bfe_u32 %3, %3, 3, 6\n")
+KERNEL_IND(ind_max3_f32, "v_max3_f32 %0, %0, %8, %9\n", "v_max3_f32 %1, %1, %8, %9\n", "v_max3_f32 %2, %2, %8, %9\n", "v_max3_f32 %3, %3, %8, %9\n")
+KERNEL_IND(ind_cvt_f32_u32, "v_cvt_f32_u32 %0, %0\n", "v_cvt_f32_u32 %1, %1\n", "v_cvt_f32_u32 %2, %2\n", "v_cvt_f32_u32 %3, %3\n")
+KERNEL_IND(ind_mul_u32_u24, "v_mul_u32_u24 %0, %0, %8\n", "v_mul_u32_u24 %1, %1, %8\n", "v_mul_u32_u24 %2, %2, %8\n", "v_mul_u32_u24 %3, %3, %8\n")
+KERNEL_IND(ind_mbcnt, "v_mbcnt_lo_u32_b32 %0, -1, %0\n", "v_mbcnt_hi_u32_b32 %1, -1, %1\n", "v_mbcnt_lo_u32_b32 %2, -1, %2\n", "v_mbcnt_hi_u32_b32 %3, -1, %3\n")
+KERNEL_IND(ind_lshl_add_u64, "v_lshl_add_u64 %4, %4, 3, %5\n", "v_lshl_add_u64 %5, %5, 3, %6\n", "v_lshl_add_u64 %6, %6, 3, %7\n", "v_lshl_add_u64 %7, %7, 3, %4\n")
+KERNEL_IND(ind_cmp_u32, "v_cmp_eq_u32 s[20:21], %0, %8\n", "v_cmp_eq_u32 s[22:23], %1, %8\n", "v_cmp_eq_u32 s[20:21], %2, %8\n", "v_cmp_eq_u32 s[22:23], %3, %8\n")
+
 #define KERNEL_SEQ(NAME, BODY)                                                                                 \
     __global__ void NAME(float *out, int iters)                                                                \
     {                                                                                                          \
@@ -154,7 +168,11 @@ int main()
                           {"ind_div_fixup", ind_div_fixup, 256}, {"ind_min3", ind_min3, 256}, {"ind_cmp_vcc", ind_cmp_vcc, 256},
                           {"ind_cmp_sgpr", ind_cmp_sgpr, 256}, {"ind_pk_mul_f32", ind_pk_mul_f32, 256}, {"ind_pk_fma_f32", ind_pk_fma_f32, 256},
                           {"ind_salu", ind_salu, 256}, {"ind_valu_salu_mix", ind_valu_salu_mix, 256}, {"ind_alignbit", ind_alignbit, 256},
-                          {"ind_mov", ind_mov, 256}, {"ind_readlane", ind_readlane, 256}, {"ind_dpp_mov", ind_dpp_mov, 256}};
+                          {"ind_mov", ind_mov, 256}, {"ind_readlane", ind_readlane, 256}, {"ind_dpp_mov", ind_dpp_mov, 256},
+                          {"ind_or_b32", ind_or_b32, 256}, {"ind_lshlrev_b32", ind_lshlrev_b32, 256}, {"ind_lshrrev_b32", ind_lshrrev_b32, 256},
+                          {"ind_or3_b32", ind_or3_b32, 256}, {"ind_and_or_b32", ind_and_or_b32, 256}, {"ind_bfe_u32", ind_bfe_u32, 256},
+                          {"ind_max3_f32", ind_max3_f32, 256}, {"ind_cvt_f32_u32", ind_cvt_f32_u32, 256}, {"ind_mul_u32_u24", ind_mul_u32_u24, 256},
+                          {"ind_mbcnt", ind_mbcnt, 256}, {"ind_lshl_add_u64", ind_lshl_add_u64, 256}, {"ind_cmp_u32", ind_cmp_u32, 256}};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;

@@ -553,7 +553,7 @@ def capi_wall(nv, res):
     out: callback pulls + H2D + device pipeline + D2H + sink calls.  PCIe-inclusive, so it is never `value`."""
     try:
         from tools import bench_capi
-        r = bench_capi.measure(nv, res, reps=5)
+        r = bench_capi.measure(nv, res, reps=5, debug=os.environ.get("O2V_CAPI_DEBUG") == "1")
         return {"ms": round(min(r["wall_s"][1:]) * 1e3, 3), "ms_all": [round(t * 1e3, 3) for t in r["wall_s"]],
                 "mvoxels_per_s": round(r["voxels"] / min(r["wall_s"][1:]) / 1e6, 1),
                 "what": "obj2voxel_voxelize(): triangle callback in, voxel callback out; best of the calls after the first "

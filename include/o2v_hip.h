@@ -122,17 +122,22 @@ int o2v_hip_set_textures(o2v_hip_ctx *ctx, const o2v_hip_texture *textures, uint
  * commits it - the block is copied to the device asynchronously while the caller fills the other block - and finishes.
  * `arrays` says which optional arrays the mesh has so far (bit 0 uvs, 1 types, 2 colors, 3 texids; verts always); an
  * array may appear at any commit, the triangles before it get its default (zero uvs / MATERIALLESS / zero colour /
- * texture 0) on the device, and from then on the caller fills it for every triangle. */
+ * texture 0) on the device, and from then on the caller fills it for every triangle.  Only verts is there from the
+ * start: before the caller writes an optional array for the first time it asks for it with o2v_hip_stage_arrays (page
+ * locking memory costs ~0.1 ms per MiB, and most meshes are vertices only). */
 typedef struct {
     float *verts;      /* [capacity][9] */
-    float *uvs;        /* [capacity][6] */
-    uint32_t *types;   /* [capacity]    */
-    float *colors;     /* [capacity][3] */
-    int32_t *texids;   /* [capacity]    */
+    float *uvs;        /* [capacity][6], NULL until asked for */
+    uint32_t *types;   /* [capacity]    , NULL until asked for */
+    float *colors;     /* [capacity][3], NULL until asked for */
+    int32_t *texids;   /* [capacity]    , NULL until asked for */
     uint64_t capacity; /* triangles per block */
 } o2v_hip_staging;
 enum { O2V_HIP_ARRAY_UVS = 1, O2V_HIP_ARRAY_TYPES = 2, O2V_HIP_ARRAY_COLORS = 4, O2V_HIP_ARRAY_TEXIDS = 8 };
 int o2v_hip_begin_triangles(o2v_hip_ctx *ctx, o2v_hip_staging *out_block);
+/* Makes the optional arrays named by `arrays` part of both staging blocks; *inout_block (the block being filled) gets their
+ * addresses.  What the block holds already stays. */
+int o2v_hip_stage_arrays(o2v_hip_ctx *ctx, uint32_t arrays, o2v_hip_staging *inout_block);
 int o2v_hip_commit_triangles(o2v_hip_ctx *ctx, uint64_t count, uint32_t arrays, o2v_hip_staging *out_next_block);
 int o2v_hip_end_triangles(o2v_hip_ctx *ctx, uint32_t any_textured);
 

@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -38,7 +39,12 @@ struct obj2voxel_texture {
 // reference src/triangle.hpp:170-195; filled only through obj2voxel_set_triangle_*
 // "implementation-defined" in the public header (include/obj2voxel.h): the cached-triangle record itself, so that a
 // triangle callback fills the staging object the cache reads from (reference triangle.hpp:170-195)
-struct obj2voxel_triangle : o2v::HostTriangle {};
+struct obj2voxel_triangle : o2v::HostTriangle {
+    // Where a setter puts the vertices: the object's own v, or - while a callback source is drained on the one-GPU path -
+    // the triangle's place in the page-locked block the device copies from (one 36-byte copy per triangle instead of two).
+    float *v_out = v;
+    bool v_set = false;
+};
 
 namespace {
 
@@ -147,6 +153,7 @@ struct CallbackTriangleSource final : TriangleSource {
         return callback(data, &staging) ? &staging : nullptr;
     }
     obj2voxel_triangle staging{};
+    bool is_callback() const override { return true; }
 };
 
 struct CallbackVoxelSink final : VoxelSink {
@@ -252,6 +259,10 @@ struct StreamedUpload {
     // an optional array appears: the triangles of this block so far get its default (earlier blocks: on the device)
     void activate(uint32_t which)
     {
+        if (o2v_hip_stage_arrays(ctx, which, &st) != O2V_HIP_OK) {
+            failed = true;
+            return;
+        }
         if (which & O2V_HIP_ARRAY_TYPES) std::fill(st.types, st.types + in_block, (uint32_t) O2V_HIP_TRI_MATERIALLESS);
         if (which & O2V_HIP_ARRAY_COLORS) std::fill(st.colors, st.colors + in_block * 3, 0.f);
         if (which & O2V_HIP_ARRAY_UVS) std::fill(st.uvs, st.uvs + in_block * 6, 0.f);
@@ -264,10 +275,16 @@ struct StreamedUpload {
         total += in_block;
         in_block = 0;
     }
+    float *vertex_slot() { return st.verts + in_block * 9; }
     void push(const HostTriangle &t)
     {
         if (failed) return;
-        std::memcpy(st.verts + in_block * 9, t.v, sizeof(t.v));
+        std::memcpy(vertex_slot(), t.v, sizeof(t.v));
+        push_rest(t);
+    }
+    /// the triangle's vertices are in vertex_slot() already
+    void push_rest(const HostTriangle &t)
+    {
         if (t.type != O2V_HIP_TRI_MATERIALLESS && !(arrays & O2V_HIP_ARRAY_TYPES)) activate(O2V_HIP_ARRAY_TYPES);
         if (t.type == O2V_HIP_TRI_UNTEXTURED && !(arrays & O2V_HIP_ARRAY_COLORS)) activate(O2V_HIP_ARRAY_COLORS);
         if (t.type == O2V_HIP_TRI_TEXTURED) {
@@ -275,6 +292,7 @@ struct StreamedUpload {
             if (!(arrays & O2V_HIP_ARRAY_UVS)) activate(O2V_HIP_ARRAY_UVS | O2V_HIP_ARRAY_TEXIDS);
             any_textured = true;
         }
+        if (failed) return;  // an array could not be page-locked
         if (arrays & O2V_HIP_ARRAY_TYPES) st.types[in_block] = t.type;
         if (arrays & O2V_HIP_ARRAY_COLORS) std::memcpy(st.colors + in_block * 3, t.color, sizeof(t.color));
         if (arrays & O2V_HIP_ARRAY_UVS) {
@@ -292,6 +310,43 @@ struct StreamedUpload {
         }
         if (++in_block == st.capacity) commit();
     }
+    /// Pulls the rest of a callback source, the setters writing each triangle's vertices where the device copies them from
+    /// (t holds the triangle pushed last).  A callback that returns true without calling a setter repeats the previous
+    /// vertices, as the reference's reused CachedTriangle does (obj2voxel.cpp:585-588).  The loop for triangles that are
+    /// nothing but vertices keeps its cursor in registers: at 870 k triangles the per-triangle cost is the drop-in's wall time.
+    void drain(obj2voxel_triangle_callback *callback, void *data, obj2voxel_triangle &t)
+    {
+        float last[9];
+        std::memcpy(last, t.v, sizeof(last));
+        const float *previous = last;
+        float *slot = vertex_slot();
+        const float *end = st.verts + st.capacity * 9;
+        while (!failed) {
+            t.v_out = slot;
+            t.v_set = false;
+            if (!callback(data, &t)) break;
+            if (!t.v_set) std::memcpy(slot, previous, sizeof(last));
+            previous = slot;
+            if (t.type == O2V_HIP_TRI_MATERIALLESS && !arrays) {
+                slot += 9;
+                if (slot != end) continue;
+                in_block = st.capacity;
+                commit();
+            }
+            else {
+                in_block = uint64_t(slot - st.verts) / 9;
+                push_rest(t);
+            }
+            if (in_block == 0) {  // the block went to the device and its memory will be written again
+                std::memcpy(last, previous, sizeof(last));
+                previous = last;
+            }
+            slot = vertex_slot();
+            end = st.verts + st.capacity * 9;
+        }
+        if (!failed) in_block = uint64_t(slot - st.verts) / 9;
+        t.v_out = t.v;
+    }
     bool finish()
     {
         if (in_block && !failed) commit();
@@ -304,18 +359,35 @@ struct StreamedUpload {
 // (O2V_DEVICES=0,1,2,3 or O2V_DEVICES=all) - an in-process group of GPUs with the grid sharded by z-slab
 // (include/o2v_hip.h, multi-GPU section), where the reference hands its chunks to a worker pool
 // (src/obj2voxel.cpp:467-520).
+constexpr uint64_t kReadBackBatch = 1u << 20;  // (x, y, z, argb) records per sink call
+
 struct Session {
     std::vector<int> devices;
     o2v_hip_ctx *ctx = nullptr;      // one device
     o2v_hip_group *group = nullptr;  // several
     uint32_t *pinned[2] = {nullptr, nullptr};  // read-back staging (pinned: D2H runs at link rate and asynchronously)
     uint64_t pinned_records = 0;
+    // Page-locking the two read-back buffers takes ~2 ms: a new session does it on a thread of its own while the triangle
+    // source is drained (wait_for_pinned() before the first use).
+    std::thread pinning;
+    void start_pinning()
+    {
+        pinning = std::thread{[this] {
+            for (uint32_t *&p : pinned) p = static_cast<uint32_t *>(o2v_hip_alloc_pinned(kReadBackBatch * 16));
+            pinned_records = pinned[0] && pinned[1] ? kReadBackBatch : 0;
+        }};
+    }
+    void wait_for_pinned()
+    {
+        if (pinning.joinable()) pinning.join();
+    }
 
     uint32_t ranks() const { return group ? o2v_hip_group_size(group) : 1u; }
     o2v_hip_ctx *rank_ctx(uint32_t r) { return group ? o2v_hip_group_ctx(group, r) : ctx; }
     const char *last_error() const { return group ? o2v_hip_group_last_error(group) : o2v_hip_last_error(ctx); }
     ~Session()
     {
+        wait_for_pinned();
         for (uint32_t *p : pinned)
             if (p) o2v_hip_free_pinned(p);
         if (group) o2v_hip_group_destroy(group);
@@ -384,6 +456,7 @@ Session *acquire_session(const std::vector<int> &devices, bool &from_cache, std:
         delete s;
         return nullptr;
     }
+    s->start_pinning();
     return s;
 }
 
@@ -466,15 +539,7 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session,
     // Hand the (x, y, z, argb) records to the sink in batches (reference obj2voxel.cpp:298-303; the callback may be
     // invoked any number of times, in any order), rank by rank.  Two pinned staging buffers: while the sink consumes one
     // batch the next one is already on its way from the device.
-    constexpr uint64_t kBatch = 1u << 20;
-    if (session->pinned_records < kBatch) {
-        for (uint32_t *&p : session->pinned) {
-            if (p) o2v_hip_free_pinned(p);
-            p = static_cast<uint32_t *>(o2v_hip_alloc_pinned(kBatch * 16));
-        }
-        session->pinned_records = session->pinned[0] && session->pinned[1] ? kBatch : 0;
-        if (!session->pinned_records) return device_error("allocating read-back staging failed");
-    }
+    constexpr uint64_t kBatch = kReadBackBatch;
     double ms_device = 0.0, ms_sink = 0.0;
     auto drain_to_sink = [&]() -> obj2voxel_error_t {
         struct Batch {
@@ -488,6 +553,8 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session,
             const Batch &b = batches[k];
             return o2v_hip_read_voxels_async(session->rank_ctx(b.rank), session->pinned[k & 1], b.first, b.n) == O2V_HIP_OK;
         };
+        session->wait_for_pinned();
+        if (!session->pinned_records) return device_error("allocating read-back staging failed");
         if (!batches.empty() && !start_read(0)) return device_error("reading voxels failed");
         for (size_t k = 0; k < batches.size(); ++k) {
             if (!inst.sink->can_write()) break;
@@ -617,6 +684,7 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
         bool from_cache;
         ~Guard() { release_session(s, from_cache); }
     } guard{session, from_cache};
+    if (!from_cache) log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: creating the device session " + std::to_string(clock.lap_ms()) + " ms");
 
     MeshArrays mesh;
     StreamedUpload stream;
@@ -629,7 +697,14 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
     else {
         upload_ok = stream.begin(session->ctx);
         if (upload_ok) {
-            for (; tri; tri = input->next()) stream.push(*tri);
+            if (input->is_callback()) {
+                auto *source = static_cast<CallbackTriangleSource *>(input.get());
+                stream.push(*tri);
+                stream.drain(source->callback, source->data, source->staging);
+            }
+            else {
+                for (; tri; tri = input->next()) stream.push(*tri);
+            }
             upload_ok = stream.finish();
         }
         n_tris = stream.total;
@@ -855,14 +930,16 @@ const obj2voxel_byte_t *obj2voxel_get_output_memory(obj2voxel_instance *instance
 void obj2voxel_set_triangle_basic(obj2voxel_triangle *triangle, const float vertices[9])
 {
     triangle->type = O2V_HIP_TRI_MATERIALLESS;
-    std::memcpy(triangle->v, vertices, sizeof(triangle->v));
+    std::memcpy(triangle->v_out, vertices, sizeof(triangle->v));
+    triangle->v_set = true;
 }
 
 void obj2voxel_set_triangle_colored(obj2voxel_triangle *triangle, const float vertices[9], const float color[3])
 {
     // the reference stores the colour but marks the triangle MATERIALLESS (obj2voxel.cpp:828-837): white
     triangle->type = O2V_HIP_TRI_MATERIALLESS;
-    std::memcpy(triangle->v, vertices, sizeof(triangle->v));
+    std::memcpy(triangle->v_out, vertices, sizeof(triangle->v));
+    triangle->v_set = true;
     std::memcpy(triangle->color, color, sizeof(triangle->color));
 }
 
@@ -870,7 +947,8 @@ void obj2voxel_set_triangle_textured(obj2voxel_triangle *triangle, const float v
                                      obj2voxel_texture *texture)
 {
     triangle->type = O2V_HIP_TRI_TEXTURED;
-    std::memcpy(triangle->v, vertices, sizeof(triangle->v));
+    std::memcpy(triangle->v_out, vertices, sizeof(triangle->v));
+    triangle->v_set = true;
     std::memcpy(triangle->t, textures, sizeof(triangle->t));
     triangle->texture = texture;
 }

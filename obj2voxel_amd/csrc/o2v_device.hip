@@ -424,6 +424,8 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         const bool fork = debug_sync_level() != 1;
         hipStream_t sw = s, sm = s, sl = s;
         if (fork) {
+            for (int j = 1; j < 3; ++j)
+                if (!ctx->aux[j]) O2V_CHECK(hipStreamCreateWithFlags(&ctx->aux[j], hipStreamNonBlocking));
             sw = ctx->aux[0];
             sm = ctx->aux[1];
             sl = ctx->aux[2];
@@ -630,9 +632,10 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
     bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_sorted, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_k1, hipEventDisableTiming) == hipSuccess;
-    for (int j = 0; j < 3 && ok; ++j)
-        ok = hipStreamCreateWithFlags(&ctx->aux[j], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming) == hipSuccess;
+    // (aux[1] and aux[2] - the cooperative resolve tiers - are created by the first pass that forks; a stream costs 0.3 ms
+    // in a warm process and several in a new one, and a mesh on the direct route never needs them)
+    for (int j = 0; j < 3 && ok; ++j) ok = hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking) == hipSuccess;
     if (!ok) {
         delete ctx;
         return O2V_HIP_ERR_HIP;
@@ -730,14 +733,16 @@ int o2v_hip_set_triangles(o2v_hip_ctx *ctx, const float *verts, const float *uvs
 
 namespace {
 
-constexpr uint64_t kStageTriangles = 1u << 17;  // per staging block: 4.5 MiB of vertices, 10 MiB with every optional array
+constexpr uint64_t kStageTriangles = 1u << 16;  // per staging block: 2.25 MiB of vertices, 5 MiB with every optional array
 
 // Makes room for `need` elements in a device array that already holds `have` valid ones (copied over if it has to move).
 template <typename T>
-int grow_keep(o2v_hip_ctx *ctx, T *&dptr, uint64_t &cap_bytes, uint64_t have, uint64_t need)
+int grow_keep(o2v_hip_ctx *ctx, T *&dptr, uint64_t &cap_bytes, uint64_t have, uint64_t need, uint64_t floor_elems)
 {
     if (dptr && need * sizeof(T) <= cap_bytes) return O2V_HIP_OK;
-    const uint64_t want = std::max<uint64_t>(need, 2 * (cap_bytes / sizeof(T))) * sizeof(T);
+    // (floor_elems: room for 2^20 triangles from the start, so that a streamed mesh does not pay for a chain of allocations
+    // and device-to-device moves)
+    const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(need, 2 * (cap_bytes / sizeof(T))), floor_elems) * sizeof(T);
     T *bigger = nullptr;
     O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&bigger), want));
     if (dptr) {
@@ -762,10 +767,6 @@ int o2v_hip_begin_triangles(o2v_hip_ctx *ctx, o2v_hip_staging *out_block)
         for (int b = 0; b < 2; ++b) {
             o2v_hip_staging &st = ctx->stage[b];
             O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.verts), kStageTriangles * 9 * sizeof(float), hipHostMallocDefault));
-            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.uvs), kStageTriangles * 6 * sizeof(float), hipHostMallocDefault));
-            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.types), kStageTriangles * sizeof(uint32_t), hipHostMallocDefault));
-            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.colors), kStageTriangles * 3 * sizeof(float), hipHostMallocDefault));
-            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.texids), kStageTriangles * sizeof(int32_t), hipHostMallocDefault));
             st.capacity = kStageTriangles;
             O2V_CHECK(hipEventCreateWithFlags(&ctx->ev_stage[b], hipEventDisableTiming));
         }
@@ -778,9 +779,35 @@ int o2v_hip_begin_triangles(o2v_hip_ctx *ctx, o2v_hip_staging *out_block)
     return O2V_HIP_OK;
 }
 
+int o2v_hip_stage_arrays(o2v_hip_ctx *ctx, uint32_t arrays, o2v_hip_staging *inout_block)
+{
+    if (!ctx || !inout_block || !ctx->stage[0].verts) return O2V_HIP_ERR_BAD_ARGUMENT;
+    O2V_CHECK(hipSetDevice(ctx->device));
+    for (o2v_hip_staging &st : ctx->stage) {
+        if ((arrays & O2V_HIP_ARRAY_UVS) && !st.uvs)
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.uvs), kStageTriangles * 6 * sizeof(float), hipHostMallocDefault));
+        if ((arrays & O2V_HIP_ARRAY_TYPES) && !st.types)
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.types), kStageTriangles * sizeof(uint32_t), hipHostMallocDefault));
+        if ((arrays & O2V_HIP_ARRAY_COLORS) && !st.colors)
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.colors), kStageTriangles * 3 * sizeof(float), hipHostMallocDefault));
+        if ((arrays & O2V_HIP_ARRAY_TEXIDS) && !st.texids)
+            O2V_CHECK(hipHostMalloc(reinterpret_cast<void **>(&st.texids), kStageTriangles * sizeof(int32_t), hipHostMallocDefault));
+    }
+    *inout_block = ctx->stage[ctx->stage_cur];
+    return O2V_HIP_OK;
+}
+
 int o2v_hip_commit_triangles(o2v_hip_ctx *ctx, uint64_t count, uint32_t arrays, o2v_hip_staging *out_next_block)
 {
     if (!ctx || !out_next_block || !ctx->stage[0].verts || count > kStageTriangles) return O2V_HIP_ERR_BAD_ARGUMENT;
+    {
+        const o2v_hip_staging &st = ctx->stage[ctx->stage_cur];
+        if (((arrays & O2V_HIP_ARRAY_UVS) && !st.uvs) || ((arrays & O2V_HIP_ARRAY_TYPES) && !st.types) ||
+            ((arrays & O2V_HIP_ARRAY_COLORS) && !st.colors) || ((arrays & O2V_HIP_ARRAY_TEXIDS) && !st.texids)) {
+            ctx->err = "an optional triangle array was committed without o2v_hip_stage_arrays";
+            return O2V_HIP_ERR_BAD_ARGUMENT;
+        }
+    }
     const uint64_t have = ctx->stream_count, need = have + count;
     if (need >= (1ull << 29)) {
         ctx->err = "triangle count must be below 2^29";
@@ -792,21 +819,21 @@ int o2v_hip_commit_triangles(o2v_hip_ctx *ctx, uint64_t count, uint32_t arrays, 
     const uint32_t fresh = arrays & ~ctx->stream_arrays;  // arrays that appear with this block
     ctx->stream_arrays |= arrays;
     int rc;
-    if ((rc = grow_keep(ctx, ctx->d_verts, ctx->cap_tri_bytes[0], have * 9, need * 9))) return rc;
+    if ((rc = grow_keep(ctx, ctx->d_verts, ctx->cap_tri_bytes[0], have * 9, need * 9, 9ull << 20))) return rc;
     if (ctx->stream_arrays & O2V_HIP_ARRAY_UVS) {
-        if ((rc = grow_keep(ctx, ctx->d_uvs, ctx->cap_tri_bytes[1], (fresh & O2V_HIP_ARRAY_UVS) ? 0 : have * 6, need * 6))) return rc;
+        if ((rc = grow_keep(ctx, ctx->d_uvs, ctx->cap_tri_bytes[1], (fresh & O2V_HIP_ARRAY_UVS) ? 0 : have * 6, need * 6, 6ull << 20))) return rc;
         if ((fresh & O2V_HIP_ARRAY_UVS) && have) O2V_CHECK(hipMemsetAsync(ctx->d_uvs, 0, have * 6 * sizeof(float), s));
     }
     if (ctx->stream_arrays & O2V_HIP_ARRAY_TYPES) {
-        if ((rc = grow_keep(ctx, ctx->d_types, ctx->cap_tri_bytes[2], (fresh & O2V_HIP_ARRAY_TYPES) ? 0 : have, need))) return rc;
+        if ((rc = grow_keep(ctx, ctx->d_types, ctx->cap_tri_bytes[2], (fresh & O2V_HIP_ARRAY_TYPES) ? 0 : have, need, 1ull << 20))) return rc;
         if ((fresh & O2V_HIP_ARRAY_TYPES) && have) O2V_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_types), (int) O2V_HIP_TRI_MATERIALLESS, have, s));
     }
     if (ctx->stream_arrays & O2V_HIP_ARRAY_COLORS) {
-        if ((rc = grow_keep(ctx, ctx->d_colors, ctx->cap_tri_bytes[3], (fresh & O2V_HIP_ARRAY_COLORS) ? 0 : have * 3, need * 3))) return rc;
+        if ((rc = grow_keep(ctx, ctx->d_colors, ctx->cap_tri_bytes[3], (fresh & O2V_HIP_ARRAY_COLORS) ? 0 : have * 3, need * 3, 3ull << 20))) return rc;
         if ((fresh & O2V_HIP_ARRAY_COLORS) && have) O2V_CHECK(hipMemsetAsync(ctx->d_colors, 0, have * 3 * sizeof(float), s));
     }
     if (ctx->stream_arrays & O2V_HIP_ARRAY_TEXIDS) {
-        if ((rc = grow_keep(ctx, ctx->d_texids, ctx->cap_tri_bytes[4], (fresh & O2V_HIP_ARRAY_TEXIDS) ? 0 : have, need))) return rc;
+        if ((rc = grow_keep(ctx, ctx->d_texids, ctx->cap_tri_bytes[4], (fresh & O2V_HIP_ARRAY_TEXIDS) ? 0 : have, need, 1ull << 20))) return rc;
         if ((fresh & O2V_HIP_ARRAY_TEXIDS) && have) O2V_CHECK(hipMemsetAsync(ctx->d_texids, 0, have * sizeof(int32_t), s));
     }
     if (count) {

@@ -34,6 +34,8 @@ struct TriangleSource {  // reference io.hpp:29-67
     virtual ~TriangleSource() = default;
     /// The next triangle (valid until the following call), or null at the end of the stream.
     virtual const HostTriangle *next() = 0;
+    /// true for the source that pulls from an obj2voxel_triangle_callback (it can be drained without the copy next() implies)
+    virtual bool is_callback() const { return false; }
 };
 
 struct VoxelSink {  // reference io.hpp:69-92

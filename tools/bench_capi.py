@@ -61,7 +61,10 @@ def measure(nv=467, res=1024, reps=3, debug=False):
     a.obj2voxel_set_output_callback.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     times = []
     cnt = Count(0, 0)
-    for _ in range(reps):
+    for rep in range(reps):
+        if rep and rep == int(os.environ.get("O2V_CAPI_NEW_SESSION_AT", "0")):
+            # what a first call costs once the HIP runtime is up: the cached device session goes back to the system
+            C.CDLL(obj2voxel_amd.LIB_PATH).o2v_release_cached_device_memory()
         feed = Feed(verts.ctypes.data, len(verts), 0)
         cnt = Count(0, 0)
         inst = a.obj2voxel_alloc()

@@ -349,6 +349,18 @@ __device__ __forceinline__ bool leaf_is_small(const uint32_t *q, float &m)
 }
 __device__ __forceinline__ float out_margin(float m) { return 3.0517578125e-5f + 1e-5f * m; }
 
+// The eighteen conditions are read off the sign bits of differences: one subtraction (the cheap issue class) and one
+// v_alignbit (which shifts a sign bit into the mask) per condition instead of a compare and a select.  With dn = min - f and
+// dx = max - f per axis (f: the voxel's integer coordinate):
+//   fail lo   min < f            sign(dn)          exact: a difference of two floats is negative iff the first is smaller
+//   fail hi   max >= f + 1       !sign(dx - 1)     exact: dx is exact for max in [f/2, 2f] (Sterbenz) and on the right side
+//                                                  of 1 outside it (rounding is monotonic); likewise dx - 1
+//   out / near                   the same differences against -margin, 1 + margin, margin, 1 - margin: their rounding (a few
+//                                1e-8 of the coordinate) is far inside the factor 8 the margin has over the drift it covers
+// The one case in which a sign bit and the comparison differ is min = -0 at f = 0 (-0 - 0 = -0): a spurious `fail` bit, which
+// only sends the plane through the classification (always exact).
+__device__ __forceinline__ uint32_t push_sign(uint32_t mask, float d) { return __builtin_amdgcn_alignbit(mask, __float_as_uint(d), 31); }
+
 template <bool UV>
 __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float fy, float fz, bool small, float margin, uint32_t planes,
                                             uint32_t &fail, uint32_t &out, uint32_t &near)
@@ -356,26 +368,18 @@ __device__ __forceinline__ void piece_masks(const Piece<UV> &q, float fx, float 
     // all coordinates are finite here (small), so min / max need no NaN rule
     const float nx = fminf(fminf(q.a.x, q.b.x), q.c.x), ny = fminf(fminf(q.a.y, q.b.y), q.c.y), nz = fminf(fminf(q.a.z, q.b.z), q.c.z);
     const float xx = fmaxf(fmaxf(q.a.x, q.b.x), q.c.x), xy = fmaxf(fmaxf(q.a.y, q.b.y), q.c.y), xz = fmaxf(fmaxf(q.a.z, q.b.z), q.c.z);
-    uint32_t f = 0, o = 0;
-    f |= (nx >= fx) ? 0u : 1u;
-    f |= (ny >= fy) ? 0u : 2u;
-    f |= (nz >= fz) ? 0u : 4u;
-    f |= (xx < fx + 1.0f) ? 0u : 8u;
-    f |= (xy < fy + 1.0f) ? 0u : 16u;
-    f |= (xz < fz + 1.0f) ? 0u : 32u;
-    o |= (xx < fx - margin) ? 1u : 0u;
-    o |= (xy < fy - margin) ? 2u : 0u;
-    o |= (xz < fz - margin) ? 4u : 0u;
-    o |= (nx > fx + (1.0f + margin)) ? 8u : 0u;
-    o |= (ny > fy + (1.0f + margin)) ? 16u : 0u;
-    o |= (nz > fz + (1.0f + margin)) ? 32u : 0u;
-    uint32_t r = 0;
-    r |= (nx >= fx + margin) ? 0u : 1u;
-    r |= (ny >= fy + margin) ? 0u : 2u;
-    r |= (nz >= fz + margin) ? 0u : 4u;
-    r |= (xx < fx + (1.0f - margin)) ? 0u : 8u;
-    r |= (xy < fy + (1.0f - margin)) ? 0u : 16u;
-    r |= (xz < fz + (1.0f - margin)) ? 0u : 32u;
+    const float dnx = nx - fx, dny = ny - fy, dnz = nz - fz, dxx = xx - fx, dxy = xy - fy, dxz = xz - fz;
+    const float one_p = 1.0f + margin, one_m = 1.0f - margin;
+    // (bit order: the sign pushed last is bit 0 - lo x, y, z, hi x, y, z = bits 0..5)
+    uint32_t f = 0u, o = 0u, r = 0u;
+    f = push_sign(f, dxz - 1.0f); f = push_sign(f, dxy - 1.0f); f = push_sign(f, dxx - 1.0f);
+    f = push_sign(f, dnz); f = push_sign(f, dny); f = push_sign(f, dnx);
+    f ^= 0x38u;  // hi planes: fail = NOT (max < f + 1)
+    o = push_sign(o, one_p - dnz); o = push_sign(o, one_p - dny); o = push_sign(o, one_p - dnx);
+    o = push_sign(o, dxz + margin); o = push_sign(o, dxy + margin); o = push_sign(o, dxx + margin);
+    r = push_sign(r, dxz - one_m); r = push_sign(r, dxy - one_m); r = push_sign(r, dxx - one_m);
+    r = push_sign(r, dnz - margin); r = push_sign(r, dny - margin); r = push_sign(r, dnx - margin);
+    r ^= 0x38u;
     fail = small ? (f & planes) : planes;
     out = small ? (o & planes) : 0u;
     near = small ? (r & planes) : planes;

@@ -310,6 +310,27 @@ __device__ __forceinline__ const uint8_t *texel_address(const DevTexture &tx, fl
     if (py >= tx.height) py = tx.height - 1;
     return tx.pixels + ((size_t) py * tx.width + px) * tx.channels + (tx.channels == 4 ? 1u : 0u);
 }
+// The same texel as one or two aligned 32-bit loads instead of three byte loads (a lookup per lane: every load instruction
+// of a wavefront touches 64 different cache lines, and the lane tiers are bound by exactly that).  `word` holds the texel's
+// first byte at bit `shift`; a second word is needed when the three bytes straddle it (never for 4-channel textures, whose
+// r, g, b are bytes 1..3 of their word).  Texture allocations end with 8 spare bytes (o2v_hip_set_textures).
+struct TexelRef {
+    const uint32_t *word;
+    uint32_t shift;  // 0, 8, 16, 24
+    __device__ __forceinline__ bool straddles() const { return shift >= 16u; }
+};
+__device__ __forceinline__ TexelRef texel_ref(const uint8_t *first_byte)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(first_byte);
+    return TexelRef{reinterpret_cast<const uint32_t *>(a & ~(uintptr_t) 3u), (uint32_t) (a & 3u) * 8u};
+}
+__device__ __forceinline__ void texel_bytes(const TexelRef &t, uint32_t w0, uint32_t w1, uint8_t &q0, uint8_t &q1, uint8_t &q2)
+{
+    const uint32_t x = (uint32_t) ((((uint64_t) w1 << 32) | w0) >> t.shift);
+    q0 = (uint8_t) x;
+    q1 = (uint8_t) (x >> 8);
+    q2 = (uint8_t) (x >> 16);
+}
 // step 3: the colour from the material and the three texel bytes
 __device__ __forceinline__ void mat_color(const MatFetch &f, bool have_textures, uint8_t q0, uint8_t q1, uint8_t q2, float &r, float &g, float &b)
 {
@@ -361,11 +382,13 @@ __device__ __forceinline__ void color_at(const Materials &m, uint32_t tri, float
         uint32_t px = (uint32_t) (tu * (float) tx.width), py = (uint32_t) (tv * (float) tx.height);
         if (px >= tx.width) px = tx.width - 1;
         if (py >= tx.height) py = tx.height - 1;
-        const uint8_t *q = tx.pixels + ((size_t) py * tx.width + px) * tx.channels;
-        const uint32_t o = tx.channels == 4 ? 1u : 0u;
-        r = (float) q[o] / 255.f;
-        g = (float) q[o + 1] / 255.f;
-        b = (float) q[o + 2] / 255.f;
+        const TexelRef t = texel_ref(tx.pixels + ((size_t) py * tx.width + px) * tx.channels + (tx.channels == 4 ? 1u : 0u));
+        const uint32_t w0 = t.word[0], w1 = t.straddles() ? t.word[1] : 0u;
+        uint8_t q0, q1, q2;
+        texel_bytes(t, w0, w1, q0, q1, q2);
+        r = (float) q0 / 255.f;
+        g = (float) q1 / 255.f;
+        b = (float) q2 / 255.f;
     }
     else {
         r = 1.f;

@@ -214,15 +214,16 @@ __device__ __forceinline__ Piece<UV> sel_piece(bool take_x, const Piece<UV> &x, 
 template <bool UV>
 __device__ __forceinline__ void stack_store(PieceStack<UV> &st, uint32_t slot, const Piece<UV> &pc)
 {
-    st.s0 = sel_piece<UV>(slot == 0, pc, st.s0);
-    st.s1 = sel_piece<UV>(slot == 1, pc, st.s1);
+    if (stack_regs<UV>() > 0u) st.s0 = sel_piece<UV>(slot == 0, pc, st.s0);
+    if (stack_regs<UV>() > 1u) st.s1 = sel_piece<UV>(slot == 1, pc, st.s1);
     if (stack_regs<UV>() > 2u) st.s2 = sel_piece<UV>(slot == 2, pc, st.s2);
 }
 template <bool UV>
 __device__ __forceinline__ Piece<UV> stack_load(const PieceStack<UV> &st, uint32_t slot)
 {
-    return stack_regs<UV>() > 2u ? sel_piece<UV>(slot == 0, st.s0, sel_piece<UV>(slot == 1, st.s1, st.s2))
-                                 : sel_piece<UV>(slot == 0, st.s0, st.s1);
+    if (stack_regs<UV>() > 2u) return sel_piece<UV>(slot == 0, st.s0, sel_piece<UV>(slot == 1, st.s1, st.s2));
+    if (stack_regs<UV>() > 1u) return sel_piece<UV>(slot == 0, st.s0, st.s1);
+    return st.s0;
 }
 
 // Conservative triangle / voxel overlap test (separating axes: the triangle's plane and the nine edge x axis

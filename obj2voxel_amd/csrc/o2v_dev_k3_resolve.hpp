@@ -162,7 +162,10 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const SortedView &
     {
         SortedRec r[N];
 #pragma unroll
-        for (uint32_t k = 0; k < N; ++k) r[k] = sorted.load(first + (size_t) ((k < o.count ? k : 0u) * step));
+        for (uint32_t k = 0; k < N; ++k) {
+            r[k] = SortedRec{0u, 0u, 0.f, 0.f, 0.f, 0u};
+            if (k < o.count) r[k] = sorted.load(first + (size_t) (k * step));  // (lanes without a k-th hit stay out of the load)
+        }
 #pragma unroll
         for (uint32_t k = 0; k < N; ++k) {
             key[k] = k < o.count ? (((uint64_t) r[k].keyhi << 32) | r[k].keylo) : ~0ull;
@@ -219,28 +222,38 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const SortedView &
         if (g0 >= o.count) continue;
         MatFetch mf[4];
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j)
-            mf[j] = mat_fetch(m, (last[g0 + j] ? hi[g0 + j] : hi[0]) & 0x1fffffffu);  // (a valid triangle: the loads are unconditional)
+        for (uint32_t j = 0; j < 4; ++j) {
+            mf[j] = MatFetch{kTriMaterialless, 0u, 0.f, 0.f, 0.f};
+            if (last[g0 + j]) mf[j] = mat_fetch(m, hi[g0 + j] & 0x1fffffffu);  // (only the slots that end a group load)
+        }
         uint8_t q[4][3] = {};
         // (without a uv array - 16-byte records - a textured triangle samples its texture at uv = (0, 0), as colorAt_f does with
         // the default-initialised t of such a triangle and as the other tiers' color_at does; the descriptor cache is only
         // filled by the uv variants)
         if (m.n_textures) {
-            const uint8_t *qa[4];
+            // only the slots that end a textured group load (every load instruction of this kernel touches one cache line per
+            // active lane, which is what bounds it), one aligned word per texel - two if its bytes straddle a word
+            TexelRef tr[4];
+            bool want[4];
+            uint32_t w0[4] = {}, w1[4] = {};
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t id = mf[j].texid < m.n_textures ? mf[j].texid : 0u;
-                const DevTexture tx = (kUv && id < kTexCache) ? s_tex[id] : m.textures[id];
-                // (a slot that is not a textured group reads three bytes of texture 0's first texel: any valid address)
-                qa[j] = (last[g0 + j] && mf[j].type == kTriTextured) ? texel_address(tx, u[g0 + j], v[g0 + j])
-                                                                     : (kUv ? s_tex[0].pixels : m.textures[0].pixels);
+                want[j] = last[g0 + j] && mf[j].type == kTriTextured;
+                tr[j] = TexelRef{nullptr, 0u};
+                if (want[j]) {
+                    const DevTexture tx = (kUv && id < kTexCache) ? s_tex[id] : m.textures[id];
+                    tr[j] = texel_ref(texel_address(tx, u[g0 + j], v[g0 + j]));
+                }
             }
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                q[j][0] = qa[j][0];
-                q[j][1] = qa[j][1];
-                q[j][2] = qa[j][2];
-            }
+            for (uint32_t j = 0; j < 4; ++j)
+                if (want[j]) w0[j] = tr[j].word[0];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (want[j] && tr[j].straddles()) w1[j] = tr[j].word[1];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) texel_bytes(tr[j], w0[j], w1[j], q[j][0], q[j][1], q[j][2]);
         }
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {

@@ -441,11 +441,14 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             O2V_CHECK(hipStreamWaitEvent(sm, ctx->ev_sorted, 0));
             O2V_CHECK(hipStreamWaitEvent(sl, ctx->ev_sorted, 0));
         }
+        // (tier 1 on the inline cells runs as fast with two workgroups per CU as with eight - it is not bound by the wavefronts in
+        // flight - and leaves the counting sort and the cooperative tiers beside it room: bench mesh with BLEND -0.1 ms)
+        const uint32_t resolve_wgs = (uint32_t) ctx->num_cus * 2u;
         if (use_uv)
-            O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
+            O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(resolve_wgs), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
                                ctx->d_out, 0u, p);
         else
-            O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(persistent), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
+            O2V_LAUNCH("k_resolve<4>", s, k_resolve<4>, dim3(resolve_wgs), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
                                ctx->d_out, 0u, p);
         if (fork) O2V_CHECK(hipStreamWaitEvent(s, ctx->ev_sorted, 0));
         if (use_uv)
@@ -893,8 +896,9 @@ int o2v_hip_set_textures(o2v_hip_ctx *ctx, const o2v_hip_texture *textures, uint
         }
         const size_t bytes = (size_t) t.width * t.height * t.channels;
         uint8_t *d = nullptr;
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&d), bytes + 8));  // (+ 8: a texel is read as aligned 32-bit words, texel_ref)
         ctx->d_texpix.push_back(d);
+        O2V_CHECK(hipMemset(d + bytes, 0, 8));
         O2V_CHECK(hipMemcpy(d, t.pixels, bytes, hipMemcpyHostToDevice));
         host[i] = DevTexture{d, t.width, t.height, t.channels, t.wrap};
     }

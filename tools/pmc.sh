@@ -1,6 +1,7 @@
 #!/bin/bash
 # Developer tool: hardware counters of the pipeline's kernels on one workload.
-# usage: tools/pmc.sh WORKLOAD OUT_PREFIX "COUNTER ..." ["COUNTER ..." ...]     (O2V_LIB selects the library)
+# usage: tools/pmc.sh WORKLOAD OUT_PREFIX "COUNTER ..." ["COUNTER ..." ...]     (O2V_LIB selects the library,
+#        O2V_PMC_KERNELS a regular expression of the kernels to report: default k_voxelize and k_scatter)
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 W=$1; OUT=$2; shift 2
@@ -19,7 +20,8 @@ for f in glob.glob("/tmp/pmc_x/**/p_counter_collection.csv", recursive=True):
         if m: acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(sys.argv[1] + ".txt", "a") as out:
     for k, d in acc.items():
-        if not (k.startswith("k_voxelize") or k.startswith("k_candidates") or k.startswith("k_scatter")): continue
+        import os
+        if not re.search(os.environ.get("O2V_PMC_KERNELS", "^k_voxelize|^k_scatter"), k): continue
         print(k, {c: round(sum(v) / len(v) / 1e6, 2) for c, v in d.items()}, "(millions per launch)", file=out)
 PY
 done

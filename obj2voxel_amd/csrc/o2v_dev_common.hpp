@@ -87,9 +87,12 @@ struct SortedView {
 };
 
 struct __attribute__((aligned(16))) Occ {  // 16 B: one occupied cell
-    uint32_t cell_lo, cell_hi;  // brick * kBrickCells + cell in brick
-    uint32_t offset;            // first SortedRec of the cell; for an inline cell: the number of its brick's slab
+    uint32_t cell_lo;           // brick * kBrickCells + cell in brick, low 32 bits
+    uint32_t cell_hi;           // bits 0..4: its bits 32..36; bits 5..31: the number of the brick's slab (>= cap_slabs: none)
+    uint32_t offset;            // an inline cell: the number of its brick's slab; else its first record in the sorted array
     uint32_t count;             // number of hits; | kOccInline: the hits (at most kInlineHits) are in the brick's slab
+    __device__ __host__ __forceinline__ uint64_t cell() const { return ((uint64_t) (cell_hi & 31u) << 32) | cell_lo; }
+    __device__ __host__ __forceinline__ uint32_t slab() const { return cell_hi >> 5; }
 };
 
 struct DevTexture {
@@ -227,6 +230,33 @@ __device__ __forceinline__ float ord2f(uint32_t o)
 constexpr uint32_t kBrickXs = O2V_BRICK_XS, kBrickYs = O2V_BRICK_YS, kBrickZs = O2V_BRICK_ZS;  // log2 of the brick's extents
 constexpr uint32_t kBrickShift = kBrickXs + kBrickYs + kBrickZs;
 constexpr uint32_t kBrickX = 1u << kBrickXs, kBrickY = 1u << kBrickYs, kBrickZ = 1u << kBrickZs, kBrickCells = 1u << kBrickShift;
+
+// Where the hits of a cell with more than kInlineHits hits are: the first kInlineHits (ranks 0 .. 7, written by k_voxelize)
+// in its brick's slab, the others (placed by k_scatter) in the cell's range of the sorted array; a cell of a brick without a
+// slab has all of them in the sorted array.  The cooperative resolve tiers read a cell's k-th record through this.
+struct CellRecords {
+    const uint32_t *sorted, *slabs;
+    uint32_t stride;      // dwords per record: 6 or 4
+    size_t slab_first;    // the cell's first record in the slab array
+    uint32_t n_slab;      // 0 or kInlineHits
+    uint32_t offset;      // the cell's first record in the sorted array
+    __device__ __forceinline__ SortedRec load(uint32_t k) const
+    {
+        const uint32_t *at = k < n_slab ? slabs + (slab_first + k) * stride : sorted + ((size_t) offset + (k - n_slab)) * stride;
+        if (stride == 4u) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(at);
+            return SortedRec{q.x, q.y, __uint_as_float(q.z), 0.f, 0.f, 0u};
+        }
+        return *reinterpret_cast<const SortedRec *>(at);
+    }
+};
+__device__ __forceinline__ CellRecords cell_records(const SortedView &sorted, const Occ &o, const Params &p)
+{
+    const uint32_t slab = o.slab();
+    return CellRecords{sorted.base, p.slabs, sorted.stride, ((size_t) slab * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits,
+                       slab < p.cap_slabs ? kInlineHits : 0u, o.offset};
+}
+
 // The kernels that read whole bricks give every lane four consecutive cells (one 16-byte load in the 32-bit grid, two in
 // the 64-bit one), so one wavefront load covers 256 cells = kBricksPerLoad bricks.
 constexpr uint32_t kLanesPerBrick = kBrickCells / 4u, kBricksPerLoad = 64u / kLanesPerBrick;

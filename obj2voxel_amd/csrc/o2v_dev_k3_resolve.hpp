@@ -54,7 +54,7 @@ struct CellFold {
 
 __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const Params &p)
 {
-    const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+    const uint64_t cell = o.cell();
     uint32_t x, y, z;
     cell_position((uint32_t) (cell >> kBrickShift), (uint32_t) cell & (kBrickCells - 1u), p, x, y, z);
     return make_uint4(x, y, z + p.zo0, argb);
@@ -68,7 +68,7 @@ __device__ __forceinline__ void emit_cell(const Occ &o, uint32_t argb, float w, 
                                           const Counters *c, const Params &p)
 {
     if (direct_active(c, p)) {
-        const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
+        const uint64_t cell = o.cell();
         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(w) << 32) | (0xffffffffu - keyhi));
         if (p.pick_max) {
             // textured mesh: the colour is known here, the winner of the cell only later (k_pick)
@@ -76,7 +76,7 @@ __device__ __forceinline__ void emit_cell(const Occ &o, uint32_t argb, float w, 
             if (slot < p.cap_vox) {
                 uint32_t *q = p.pick_extra + (size_t) slot * 6u;
                 q[0] = o.cell_lo;
-                q[1] = o.cell_hi;
+                q[1] = o.cell_hi & 31u;
                 q[2] = keyhi;
                 q[3] = __float_as_uint(w);
                 q[4] = argb;
@@ -145,10 +145,9 @@ struct SortNet {
 // One cell with up to N hits, resolved by one lane out of its registers (compile-time indices only): the records are sorted
 // by a sorting network, reduced to their (sub-voxel, triangle) groups in one forward pass, coloured four groups at a time
 // and folded.  Returns the cell's ARGB; `f` holds the winner for the direct MAX path.
-// The cell's `count` hits are the records first, first + step, ... of `sorted` (step 1: the sorted array and the slabs both
-// keep a cell's hits side by side).
-template <uint32_t STRIDE, uint32_t N>
-__device__ __forceinline__ uint32_t resolve_cell_in_registers(const SortedView &sorted, size_t first, uint32_t step, uint32_t count, const Materials &m,
+// load_record(k) fetches the cell's k-th hit (k < count).
+template <uint32_t STRIDE, uint32_t N, class Load>
+__device__ __forceinline__ uint32_t resolve_cell_in_registers(const Load &load_record, uint32_t count, const Materials &m,
                                                               const DevTexture *s_tex, const Params &p, GroupFold &f)
 {
     struct {
@@ -164,7 +163,7 @@ __device__ __forceinline__ uint32_t resolve_cell_in_registers(const SortedView &
 #pragma unroll
         for (uint32_t k = 0; k < N; ++k) {
             r[k] = SortedRec{0u, 0u, 0.f, 0.f, 0.f, 0u};
-            if (k < o.count) r[k] = sorted.load(first + (size_t) (k * step));  // (lanes without a k-th hit stay out of the load)
+            if (k < o.count) r[k] = load_record(k);  // (lanes without a k-th hit stay out of the load)
         }
 #pragma unroll
         for (uint32_t k = 0; k < N; ++k) {
@@ -292,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         const SortedView from{inl ? slabs_dyn.base : sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
         const size_t first = inl ? ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) o.offset;
         GroupFold f;
-        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>(from, first, 1u, count, m, s_tex, p, f);
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return from.load(first + k); }, count, m, s_tex, p, f);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
@@ -316,7 +315,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve_list16(const uint32_t *__res
         const uint32_t i = list[item];
         const Occ o = occ[i];
         GroupFold f;
-        const uint32_t argb = resolve_cell_in_registers<STRIDE, kLane16List>(sorted, (size_t) o.offset, 1u, o.count, m, s_tex, p, f);
+        const CellRecords recs = cell_records(sorted, o, p);
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kLane16List>([&](uint32_t k) { return recs.load(k); }, o.count, m, s_tex, p, f);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restr
         uint32_t hi = 0, idx = sl;
         float w = 0.f, u = 0.f, v = 0.f;
         if (sl < n) {
-            const SortedRec r = sorted.load(o.offset + sl);
+            const SortedRec r = cell_records(sorted, o, p).load(sl);
             key = ((uint64_t) r.keyhi << 32) | r.keylo;
             hi = r.keyhi;
             w = r.w;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
         while (n_pow2 < n) n_pow2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n_pow2; t += THREADS) {
             if (t < n) {
-                const SortedRec r = sorted.load(o.offset + t);
+                const SortedRec r = cell_records(sorted, o, p).load(t);
                 s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
                 s_idx[t] = t;
             }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
         __syncthreads();
         bitonic_sort(s_key, s_idx, n_pow2, threadIdx.x, THREADS);
         for (uint32_t t = threadIdx.x; t < n; t += THREADS) {
-            const SortedRec r = sorted.load(o.offset + s_idx[t]);
+            const SortedRec r = cell_records(sorted, o, p).load(s_idx[t]);
             s_hi[t] = r.keyhi;
             s_w[t] = r.w;
             s_u[t] = r.u;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__r
         while (n_pow2 < n) n_pow2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n_pow2; t += kBigThreads) {
             if (t < n) {
-                const SortedRec r = sorted.load(o.offset + t);
+                const SortedRec r = cell_records(sorted, o, p).load(t);
                 s_key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
                 s_idx[t] = t;
             }
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__r
                 const uint32_t m_here = n - base < kBigStage ? n - base : kBigStage;
                 __syncthreads();
                 for (uint32_t t = threadIdx.x; t < m_here; t += kBigThreads) {
-                    const SortedRec r = sorted.load(o.offset + s_idx[base + t]);
+                    const SortedRec r = cell_records(sorted, o, p).load(s_idx[base + t]);
                     s_hi[t] = r.keyhi;
                     s_w[t] = r.w;
                     s_u[t] = r.u;
@@ -652,10 +652,10 @@ __global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__r
             for (uint32_t t = threadIdx.x; t < n; t += kBigThreads) {
                 const uint32_t hi = (uint32_t) (s_key[t] >> 32);
                 if (t == 0 || (uint32_t) (s_key[t - 1] >> 32) != hi) {
-                    SortedRec r = sorted.load(o.offset + s_idx[t]);
+                    SortedRec r = cell_records(sorted, o, p).load(s_idx[t]);
                     WUv acc{r.w, r.u, r.v};
                     for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
-                        r = sorted.load(o.offset + s_idx[j]);
+                        r = cell_records(sorted, o, p).load(s_idx[j]);
                         acc = wmix(WUv{r.w, r.u, r.v}, acc);
                     }
                     const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
@@ -674,10 +674,10 @@ __global__ __launch_bounds__(kBigThreads) void k_resolve_big(const uint32_t *__r
                 for (uint32_t wv = 1; wv < kBigThreads / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
                 const uint32_t t = 0xffffffffu - (uint32_t) best;
                 const uint32_t hi = (uint32_t) (s_key[t] >> 32);
-                SortedRec r = sorted.load(o.offset + s_idx[t]);
+                SortedRec r = cell_records(sorted, o, p).load(s_idx[t]);
                 WUv acc{r.w, r.u, r.v};
                 for (uint32_t j = t + 1; j < n && (uint32_t) (s_key[j] >> 32) == hi; ++j) {
-                    r = sorted.load(o.offset + s_idx[j]);
+                    r = cell_records(sorted, o, p).load(s_idx[j]);
                     acc = wmix(WUv{r.w, r.u, r.v}, acc);
                 }
                 float cr, cg, cb;
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
         uint32_t *idx = scratch_idx + s_base;
         for (uint32_t t = threadIdx.x; t < n_pow2; t += kBlock) {
             if (t < n) {
-                const SortedRec r = sorted.load(o.offset + t);
+                const SortedRec r = cell_records(sorted, o, p).load(t);
                 key[t] = ((uint64_t) r.keyhi << 32) | r.keylo;
                 idx[t] = t;
             }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
             if (threadIdx.x == 0) {
                 CellFold f;
                 for (uint32_t t = 0; t < n; ++t) {
-                    const SortedRec r = sorted.load(o.offset + idx[t]);
+                    const SortedRec r = cell_records(sorted, o, p).load(idx[t]);
                     f.add(m, p.blend, r.keyhi, r.w, r.u, r.v);
                 }
                 out[i] = cell_record(o, f.finish(m, p.blend), p);
@@ -750,10 +750,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
             for (uint32_t t = threadIdx.x; t < n; t += kBlock) {
                 const uint32_t hi = (uint32_t) (key[t] >> 32);
                 if (t == 0 || (uint32_t) (key[t - 1] >> 32) != hi) {
-                    SortedRec r = sorted.load(o.offset + idx[t]);
+                    SortedRec r = cell_records(sorted, o, p).load(idx[t]);
                     WUv acc{r.w, r.u, r.v};
                     for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
-                        r = sorted.load(o.offset + idx[j]);
+                        r = cell_records(sorted, o, p).load(idx[j]);
                         acc = wmix(WUv{r.w, r.u, r.v}, acc);
                     }
                     const unsigned long long cand = ((unsigned long long) __float_as_uint(acc.w) << 32) | (0xffffffffu - t);
@@ -772,10 +772,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve_huge(const uint32_t *__restr
                 for (uint32_t wv = 1; wv < kBlock / 64; ++wv) best = s_best[wv] > best ? s_best[wv] : best;
                 const uint32_t t = 0xffffffffu - (uint32_t) best;
                 const uint32_t hi = (uint32_t) (key[t] >> 32);
-                SortedRec r = sorted.load(o.offset + idx[t]);
+                SortedRec r = cell_records(sorted, o, p).load(idx[t]);
                 WUv acc{r.w, r.u, r.v};
                 for (uint32_t j = t + 1; j < n && (uint32_t) (key[j] >> 32) == hi; ++j) {
-                    r = sorted.load(o.offset + idx[j]);
+                    r = cell_records(sorted, o, p).load(idx[j]);
                     acc = wmix(WUv{r.w, r.u, r.v}, acc);
                 }
                 float cr, cg, cb;

@@ -115,8 +115,8 @@ __device__ __forceinline__ uint32_t *class_counter(Counters *c, uint32_t k)
 // The offset is also stored in the cell itself, where k_scatter reads it.
 // Cells with at most kInlineHits hits whose brick has a slab keep them there (written by k_voxelize): their occ entry names
 // the slab (kOccInline) and they take no part in the counting sort.  The other cells get a range of the sorted array as
-// before; what a slab holds of them - their first kInlineHits hits - is copied there by k_promote, the rest arrives through
-// k_scatter (a brick beyond the slab budget has all its hits pooled).
+// for the hits their slab does not hold (ranks kInlineHits and up, placed by k_scatter; a brick beyond the slab budget has
+// all its hits pooled and placed); the resolve tiers read a cell's records from both places (CellRecords).
 __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi /* cell >> 32 | slab << 5 */, uint32_t *s_cnt,
                                            uint32_t *s_wave, uint32_t *s_base, uint32_t *s_cls /*[7], zero*/,
                                            uint32_t *s_cls_base /*[7]*/, uint32_t *grid, Counters *c, Occ *occ,
@@ -126,7 +126,12 @@ __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, con
     const uint32_t per = (n + kBlock - 1) / kBlock;
     const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += (s_cnt[i] > kInlineHits || (s_hi[i] >> 5) >= p.cap_slabs) ? s_cnt[i] : 0u;
+    // (what a cell needs of the sorted array: nothing if it is inline, its hits beyond the slab's eight if its brick has a slab)
+    auto sorted_need = [&](uint32_t i) -> uint32_t {
+        const bool has_slab = (s_hi[i] >> 5) < p.cap_slabs;
+        return !has_slab ? s_cnt[i] : (s_cnt[i] > kInlineHits ? s_cnt[i] - kInlineHits : 0u);
+    };
+    for (uint32_t i = lo; i < hi; ++i) sum += sorted_need(i);
     uint32_t total;
     uint32_t run = block_exscan(sum, s_wave, total);
     __syncthreads();
@@ -143,17 +148,19 @@ __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, con
         const uint32_t cell_hi = s_hi[i] & 31u, slab = s_hi[i] >> 5;
         const bool has_slab = slab < p.cap_slabs;
         if (cnt <= kInlineHits && has_slab) {
-            if (listed) occ[base_vox + i] = Occ{s_lo[i], cell_hi, slab, cnt | kOccInline};
+            if (listed) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], slab, cnt | kOccInline};
             continue;
         }
-        if (listed) occ[base_vox + i] = Occ{s_lo[i], cell_hi, run, cnt};
-        grid[((uint64_t) cell_hi << 32) | s_lo[i]] = run;  // (k_scatter places the pooled hits at run + rank)
+        const uint32_t need = sorted_need(i);
+        if (listed) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], run, cnt};
+        // (k_scatter places a pooled hit at this + its rank; with a slab the pooled hits' ranks start at kInlineHits)
+        grid[((uint64_t) cell_hi << 32) | s_lo[i]] = has_slab ? run - kInlineHits : run;
         if (listed && cnt > kShortList) {
             // rank within its class among this flush's cells; the count is not needed again, the slot keeps the tag
             const uint32_t cls = resolve_class(cnt);
             s_cnt[i] = 0x80000000u | (cls << 24) | atomicAdd(&s_cls[cls], 1u);
         }
-        run += cnt;
+        run += need;
     }
     __syncthreads();
     if (threadIdx.x < kResolveClasses) {
@@ -239,31 +246,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
     }
     const uint32_t n = s_n;
     if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
-}
-
-// The cells with more than kInlineHits hits whose brick has a slab: their first kInlineHits hits (ranks 0 .. 7, written there
-// by k_voxelize) move to the head of the cell's range of the sorted array - eight lanes per cell, one record each - so that
-// the cooperative tiers find a cell's hits in one place.  The cells are the ones k_scan_bricks filed for those tiers.
-__global__ __launch_bounds__(kBlock) void k_promote(const Occ *__restrict__ occ, ResolveLists lists, const Counters *c, uint32_t *sorted, Params p)
-{
-    if (pass_overflowed(c, p)) return;
-    static_assert(kInlineHits == 8, "eight lanes per cell");
-    // blockIdx.y = the tier's list: every list is a chain of four dependent loads per record (list, occ, slab number, slab), so
-    // the lists run side by side (one after the other: 1.8 ms on configs[3] in a launch of its own)
-    const uint32_t cls = blockIdx.y;
-    const uint32_t *list = class_list(lists, cls);
-    const uint32_t n_raw = *class_counter(const_cast<Counters *>(c), cls);
-    const uint32_t n = n_raw < lists.cap ? n_raw : lists.cap;
-    for (uint64_t t = (uint64_t) blockIdx.x * kBlock + threadIdx.x; t < (uint64_t) n * kInlineHits; t += (uint64_t) gridDim.x * kBlock) {
-        const Occ o = occ[list[t / kInlineHits]];
-        const uint32_t k = (uint32_t) (t % kInlineHits);
-        const uint64_t cell = ((uint64_t) o.cell_hi << 32) | o.cell_lo;
-        const uint32_t slab = p.brick_slab[cell >> kBrickShift];
-        if (slab >= p.cap_slabs || (uint64_t) o.offset + k >= p.cap_hits) continue;  // (no slab: every hit of the cell was pooled)
-        const size_t from = ((size_t) slab * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits + k;
-        if (p.slab_stride == 4u) reinterpret_cast<uint4 *>(sorted)[o.offset + k] = reinterpret_cast<const uint4 *>(p.slabs)[from];
-        else reinterpret_cast<SortedRec *>(sorted)[o.offset + k] = reinterpret_cast<const SortedRec *>(p.slabs)[from];
-    }
 }
 
 #ifndef O2V_SCATTER_UNROLL

@@ -419,7 +419,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         // What follows k_scan_bricks runs side by side (the tiers work on disjoint cells, filed by k_scan_bricks):
         //   main stream   tier 1 on the inline cells - most cells; their hits are in the slabs, so it needs no sorted array -
         //                 then, once that exists, on the short cells of bricks without a slab (none as a rule)
-        //   aux 0         the counting sort of what the slabs do not hold: k_promote, k_scatter; then the 9..16-hit tier
+        //   aux 0         the counting sort of what the slabs do not hold (k_scatter), then the 9..16-hit tier
         //   aux 1, 2      (behind the sort) the counter reset and the cooperative tiers
         const bool fork = debug_sync_level() != 1;
         hipStream_t sw = s, sm = s, sl = s;
@@ -432,8 +432,6 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             O2V_CHECK(hipEventRecord(ctx->ev_fork, s));
             O2V_CHECK(hipStreamWaitEvent(sw, ctx->ev_fork, 0));
         }
-        O2V_LAUNCH("k_promote", sw, k_promote, dim3((uint32_t) ctx->num_cus * 2u, kResolveClasses), dim3(kBlock), 0, sw, ctx->d_occ, lists, ctx->d_ctr,
-                           reinterpret_cast<uint32_t *>(ctx->d_sorted), p);
         O2V_LAUNCH("k_scatter", sw, k_scatter, dim3(persistent), dim3(kBlock), 0, sw, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
         if (fork) {
@@ -1682,6 +1680,28 @@ int o2v_hip_voxels_device_ptr(o2v_hip_ctx *ctx, const uint32_t **out_ptr, uint64
     return O2V_HIP_OK;
 }
 
+namespace {
+// Where a cell's hit records are after a run of the general route (the host-side twin of CellRecords): the first n_slab in its
+// brick's slab, the other n_sorted in the sorted array.
+struct HostCellRecords {
+    size_t slab_first, sorted_first;
+    uint32_t n_slab, n_sorted;
+};
+HostCellRecords host_cell_records(const Occ &o, uint32_t cap_slabs)
+{
+    const uint32_t cnt = o.count & ~kOccInline;
+    const bool inl = (o.count & kOccInline) != 0u;
+    const uint32_t slab = inl ? o.offset : o.slab();
+    const bool has_slab = inl || slab < cap_slabs;
+    HostCellRecords w{};
+    w.slab_first = ((size_t) slab * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits;
+    w.n_slab = !has_slab ? 0u : (cnt < kInlineHits ? cnt : kInlineHits);
+    w.n_sorted = cnt - w.n_slab;
+    w.sorted_first = inl ? 0u : (size_t) o.offset;
+    return w;
+}
+}  // namespace
+
 // Debugging aid: the hit records of one output cell of the last run (the occupied-cell list and the hit pool
 // stay valid after a run).  Each record is 6 words: keyhi, keylo, w, u, v (as float bits) and the pool index.
 int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z, uint32_t *out, uint32_t max_records,
@@ -1701,15 +1721,18 @@ int o2v_hip_debug_cell_hits(o2v_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t z
     O2V_CHECK(hipMemcpy(vox.data(), ctx->d_out, vox.size() * sizeof(uint4), hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < ctx->n_vox; ++i) {
         if (vox[i].x != x || vox[i].y != y || vox[i].z != z) continue;
-        const bool inl = (occ[i].count & kOccInline) != 0u;  // (the hits are in the brick's slab)
+        const HostCellRecords where = host_cell_records(occ[i], ctx->cap_slabs);
         const uint32_t cnt = occ[i].count & ~kOccInline;
         const uint32_t n = cnt < max_records ? cnt : max_records;
         std::vector<uint32_t> raw((size_t) n * ctx->sorted_stride);
-        const size_t first = inl ? ((size_t) occ[i].offset * kBrickCells + (occ[i].cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) occ[i].offset;
-        for (uint32_t k = 0; k < n; ++k)
+        const size_t first = where.n_slab ? where.slab_first : where.sorted_first;
+        for (uint32_t k = 0; k < n; ++k) {
+            const bool in_slab = k < where.n_slab;
+            const size_t at = in_slab ? where.slab_first + k : where.sorted_first + (k - where.n_slab);
             O2V_CHECK(hipMemcpy(raw.data() + (size_t) k * ctx->sorted_stride,
-                                (inl ? ctx->d_slabs : reinterpret_cast<const uint32_t *>(ctx->d_sorted)) + (first + (size_t) k) * ctx->sorted_stride,
+                                (in_slab ? ctx->d_slabs : reinterpret_cast<const uint32_t *>(ctx->d_sorted)) + at * ctx->sorted_stride,
                                 ctx->sorted_stride * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
         for (uint32_t k = 0; k < n; ++k) {
             const uint32_t *r = &raw[(size_t) k * ctx->sorted_stride];
             uint32_t *o = out + k * 6;
@@ -1746,7 +1769,8 @@ int o2v_hip_debug_hits(o2v_hip_ctx *ctx, uint32_t *out8, uint64_t max_hits, uint
     uint64_t total = 0, end = 0;
     for (const Occ &o : occ) {
         total += o.count & ~kOccInline;
-        if (!(o.count & kOccInline)) end = std::max<uint64_t>(end, (uint64_t) o.offset + o.count);
+        const HostCellRecords where = host_cell_records(o, ctx->cap_slabs);
+        if (where.n_sorted) end = std::max<uint64_t>(end, (uint64_t) where.sorted_first + where.n_sorted);
     }
     *n_hits = total;
     if (total > max_hits) return O2V_HIP_OK;  // (the caller sizes its buffer from *n_hits and calls again)
@@ -1757,11 +1781,11 @@ int o2v_hip_debug_hits(o2v_hip_ctx *ctx, uint32_t *out8, uint64_t max_hits, uint
     if (!slabs.empty()) O2V_CHECK(hipMemcpy(slabs.data(), ctx->d_slabs, slabs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     uint64_t k = 0;
     for (uint64_t i = 0; i < ctx->n_vox; ++i) {
-        const bool inl = (occ[i].count & kOccInline) != 0u;
+        const HostCellRecords where = host_cell_records(occ[i], ctx->cap_slabs);
         const uint32_t cnt = occ[i].count & ~kOccInline;
-        const size_t first = inl ? ((size_t) occ[i].offset * kBrickCells + (occ[i].cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) occ[i].offset;
         for (uint32_t h = 0; h < cnt; ++h, ++k) {
-            const uint32_t *r = inl ? &slabs[(first + h) * ctx->sorted_stride] : &raw[(first + h) * ctx->sorted_stride];
+            const uint32_t *r = h < where.n_slab ? &slabs[(where.slab_first + h) * ctx->sorted_stride]
+                                                 : &raw[(where.sorted_first + (h - where.n_slab)) * ctx->sorted_stride];
             uint32_t *o = out8 + k * 8;
             o[0] = vox[i].x;
             o[1] = vox[i].y;

@@ -115,7 +115,7 @@ struct Counters {
     uint32_t n_dirty, n_sorted, n_bigl, cursor_big;
     uint32_t cursor_mid, cursor_long, cursor_huge, n_lane;
     uint32_t n_nodes[kMaxRounds + 1];
-    uint32_t n_w64, n_dirty_max, n_out;
+    uint32_t n_w64, n_dirty_max, n_out, n_lane8;  // n_lane8: inline cells with 5 .. 8 hits (their own launch of tier 1)
     unsigned long long n_candidates, n_hits;
     uint32_t bounds_enc[6];
     uint32_t n_root_leaves, pad2;  // root triangles that became leaves as they are (the others are in n_nodes[0]);

@@ -288,10 +288,40 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         // an inline cell's hits are in its brick's slab (Occ::offset names it), the others' in the sorted array
         const bool inl = (o.count & kOccInline) != 0u;
         if (inl != (part == 0u)) continue;
+        if (inl && count > kFourList) continue;  // filed for k_resolve_inline_list by k_scan_bricks
         const SortedView from{inl ? slabs_dyn.base : sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
         const size_t first = inl ? ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) o.offset;
         GroupFold f;
-        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return from.load(first + k); }, count, m, s_tex, p, f);
+        // (part is uniform: the inline cells left here have at most four hits - a 5-exchange network instead of 19 and one colour
+        // step instead of two)
+        const uint32_t argb = part == 0u ? resolve_cell_in_registers<STRIDE, kFourList>([&](uint32_t k) { return from.load(first + k); }, count, m, s_tex, p, f)
+                                         : resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return from.load(first + k); }, count, m, s_tex, p, f);
+        emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
+    }
+}
+
+// Tier 1 for the inline cells with 5 .. 8 hits, from their list (k_scan_bricks files them): the eight-slot form with every
+// lane in it.  Needs nothing but the slabs, so it runs beside the four-slot launch and the counting sort.
+template <uint32_t STRIDE>
+__global__ __launch_bounds__(kBlock) void k_resolve_inline_list(const uint32_t *__restrict__ list, const uint32_t *n_list, const Counters *c,
+                                                                const Occ *__restrict__ occ, SortedView slabs_dyn, Materials m, uint4 *out,
+                                                                uint32_t list_cap, Params p)
+{
+    const SortedView slabs{slabs_dyn.base, STRIDE};
+    __shared__ DevTexture s_tex[kTexCache];
+    if (pass_overflowed(c, p)) return;
+    if (STRIDE == 6) {
+        for (uint32_t t = threadIdx.x; t < kTexCache && t < m.n_textures; t += kBlock) s_tex[t] = m.textures[t];
+        __syncthreads();
+    }
+    const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < total; item += gridDim.x * kBlock) {
+        const uint32_t i = list[item];
+        const Occ o = occ[i];
+        const size_t first = ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits;
+        GroupFold f;
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return slabs.load(first + k); }, o.count & ~kOccInline, m,
+                                                                            s_tex, p, f);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }

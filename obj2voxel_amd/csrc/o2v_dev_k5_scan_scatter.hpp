@@ -84,12 +84,14 @@ constexpr uint32_t kBigList = 8192;    // up to this: one workgroup per cell, ke
 
 struct ResolveLists {  // cells k_resolve defers, by hit count class (indices into occ[])
     uint32_t *lane16, *lane, *w64, *mid, *lng, *big, *huge;
+    uint32_t *lane8;  // inline cells with 5 .. 8 hits
     uint32_t cap;
 };
 
 // Cells with more than kShortList hits are resolved by the cooperative tiers; k_scan_bricks files them by hit count
 // while it builds occ[] (one global atomic per class and flush), so that every resolve tier can start at once.
-constexpr uint32_t kResolveClasses = 7;
+constexpr uint32_t kResolveClasses = 8;  // seven for the cells with more than kShortList hits, one for the inline cells with 5 .. 8
+constexpr uint32_t kLane8Class = 7, kFourList = 4;
 __device__ __forceinline__ uint32_t resolve_class(uint32_t cnt)
 {
     return cnt <= kLane16List ? 0u
@@ -102,12 +104,12 @@ __device__ __forceinline__ uint32_t resolve_class(uint32_t cnt)
 }
 __device__ __forceinline__ uint32_t *class_list(const ResolveLists &l, uint32_t k)
 {
-    return k == 0 ? l.lane16 : k == 1 ? l.lane : k == 2 ? l.w64 : k == 3 ? l.mid : k == 4 ? l.lng : k == 5 ? l.big : l.huge;
+    return k == 0 ? l.lane16 : k == 1 ? l.lane : k == 2 ? l.w64 : k == 3 ? l.mid : k == 4 ? l.lng : k == 5 ? l.big : k == 6 ? l.huge : l.lane8;
 }
 __device__ __forceinline__ uint32_t *class_counter(Counters *c, uint32_t k)
 {
     return k == 0 ? &c->n_lane16 : k == 1 ? &c->n_lane : k == 2 ? &c->n_w64 : k == 3 ? &c->n_mid : k == 4 ? &c->n_long
-           : k == 5 ? &c->n_bigl : &c->n_huge;
+           : k == 5 ? &c->n_bigl : k == 6 ? &c->n_huge : &c->n_lane8;
 }
 
 // Writes the staged occupied cells of one workgroup to `occ`, giving every cell the offset of its hits in the sorted
@@ -149,6 +151,9 @@ __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, con
         const bool has_slab = slab < p.cap_slabs;
         if (cnt <= kInlineHits && has_slab) {
             if (listed) occ[base_vox + i] = Occ{s_lo[i], s_hi[i], slab, cnt | kOccInline};
+            // (tier 1 takes the inline cells with at most four hits straight from occ[] in its four-slot form; the others are
+            // filed, so that one launch's lanes all run the eight-slot form)
+            if (listed && cnt > kFourList) s_cnt[i] = 0x80000000u | (kLane8Class << 24) | atomicAdd(&s_cls[kLane8Class], 1u);
             continue;
         }
         const uint32_t need = sorted_need(i);

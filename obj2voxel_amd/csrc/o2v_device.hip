@@ -121,6 +121,7 @@ struct o2v_hip_ctx {
     uint32_t sorted_stride = 6;
     Occ *d_occ = nullptr;
     uint4 *d_out = nullptr;
+    uint32_t *d_list_lane8 = nullptr;
     uint32_t *d_list_lane16 = nullptr, *d_list_w64 = nullptr, *d_list_lane = nullptr, *d_list_mid = nullptr, *d_list_long = nullptr, *d_list_big = nullptr,
              *d_list_huge = nullptr;  // cap_vox each
     uint64_t *d_scratch_key = nullptr;  // tier-4 resolve scratch, allocated on first need
@@ -403,7 +404,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         ctx->no_pool_key = run_general ? 0 : mark_key + 1u;
     }
     const ResolveLists lists{ctx->d_list_lane16, ctx->d_list_lane, ctx->d_list_w64, ctx->d_list_mid, ctx->d_list_long,
-                             ctx->d_list_big, ctx->d_list_huge, p.cap_vox};
+                             ctx->d_list_big, ctx->d_list_huge, ctx->d_list_lane8, p.cap_vox};
     if (run_general) {
         // (the brick list was made before k_voxelize: see k_mark_bricks)
         O2V_LAUNCH("k_scan_bricks", s, k_scan_bricks, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_grid,
@@ -432,6 +433,14 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             O2V_CHECK(hipEventRecord(ctx->ev_fork, s));
             O2V_CHECK(hipStreamWaitEvent(sw, ctx->ev_fork, 0));
         }
+        // (the inline cells with 5 .. 8 hits: from the slabs like the main stream's launch, so it starts with it)
+        if (fork) O2V_CHECK(hipStreamWaitEvent(sm, ctx->ev_fork, 0));
+        if (use_uv)
+            O2V_LAUNCH("k_resolve_inline_list<6>", sm, k_resolve_inline_list<6>, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sm, ctx->d_list_lane8,
+                               &ctx->d_ctr->n_lane8, ctx->d_ctr, ctx->d_occ, slab_view, m, ctx->d_out, p.cap_vox, p);
+        else
+            O2V_LAUNCH("k_resolve_inline_list<4>", sm, k_resolve_inline_list<4>, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sm, ctx->d_list_lane8,
+                               &ctx->d_ctr->n_lane8, ctx->d_ctr, ctx->d_occ, slab_view, m, ctx->d_out, p.cap_vox, p);
         O2V_LAUNCH("k_scatter", sw, k_scatter, dim3(persistent), dim3(kBlock), 0, sw, ctx->d_pool, ctx->d_grid, ctx->d_ctr,
                            reinterpret_cast<uint32_t *>(ctx->d_sorted), use_uv ? 6u : 4u, p);
         if (fork) {
@@ -661,7 +670,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
                     ctx->d_ctr,   ctx->d_leaves, ctx->d_tiles,  ctx->d_big,      ctx->d_nodes[0], ctx->d_nodes[1],
                     ctx->d_pool,  ctx->d_sorted, ctx->d_occ,  ctx->d_out,      ctx->d_grid, ctx->d_jobq,
-                    ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
+                    ctx->d_list_lane8, ctx->d_list_lane16, ctx->d_list_w64, ctx->d_list_lane, ctx->d_list_mid, ctx->d_list_long, ctx->d_list_big, ctx->d_list_huge, ctx->d_scratch_key, ctx->d_scratch_idx,
                     ctx->d_brick_dirty, ctx->d_dirty_list, ctx->d_brick_slab, ctx->d_slabs, ctx->d_maxgrid, ctx->d_dirty_max, ctx->d_dirty_list_max, ctx->d_pick_extra};
     for (void *q : ptrs)
         if (q) (void) hipFree(q);
@@ -1161,7 +1170,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->cap_pick_extra = cap_px;
             p.pick_extra = reinterpret_cast<uint32_t *>(ctx->d_pick_extra);
         }
-        for (uint32_t **lp : {&ctx->d_list_lane16, &ctx->d_list_w64, &ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
+        for (uint32_t **lp : {&ctx->d_list_lane8, &ctx->d_list_lane16, &ctx->d_list_w64, &ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
             uint32_t cap_l = ctx->cap_vox;
             if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;
         }

@@ -61,3 +61,14 @@ def test_no_runs_of_two_operand_selects(device_asm, variant):
         run = run + 1 if op == "v_cndmask_b32_e32" else 0
         longest = max(longest, run)
     assert longest <= 2, longest
+
+
+@pytest.mark.parametrize("variant,min_alignbit", [("Lb0E", 20), ("Lb1E", 12)])
+def test_piece_masks_are_built_from_sign_bits(device_asm, variant, min_alignbit):
+    """piece_masks reads its conditions off the sign bits of differences: one v_alignbit_b32 per condition instead of a
+    compare and a select (profiles/r04/NOTES.md: -4 .. -7 % on the clip kernel).  If the compiler turns that back into
+    compares, the instruction mix the bench line's mix ceiling is priced with changes: this pins the form."""
+    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_ZN\S*k_voxelizeI" + variant + r"\S*:", l))
+    end = next(i for i in range(start, len(device_asm)) if device_asm[i].startswith(".Lfunc_end"))
+    ops = [l.split()[0] for l in (x.strip() for x in device_asm[start:end]) if l and not l.startswith((";", ".")) and not l.endswith(":")]
+    assert sum(op == "v_alignbit_b32" for op in ops) >= min_alignbit, sum(op == "v_alignbit_b32" for op in ops)

@@ -172,6 +172,9 @@ int o2v_hip_read_voxels_async(o2v_hip_ctx *ctx, uint32_t *out, uint64_t first, u
 int o2v_hip_read_voxels_wait(o2v_hip_ctx *ctx);
 /* Page-locked host memory (hipHostMalloc / hipHostFree): transfers from and to it run asynchronously at link rate. */
 void *o2v_hip_alloc_pinned(size_t bytes);
+/* The same on a thread that has not selected a device yet: `device` becomes the calling thread's current device first (a
+ * thread's default is device 0, which need not be the one the caller works on - or one it may touch at all). */
+void *o2v_hip_alloc_pinned_on(int device, size_t bytes);
 void o2v_hip_free_pinned(void *p);
 /* Releases the device session that obj2voxel_voxelize() keeps between calls (contexts, dense grids, staging memory). */
 void o2v_release_cached_device_memory(void);

@@ -22,7 +22,7 @@
 #include <string>
 #include <vector>
 
-// Extension to the reference's error codes: the GPU pipeline could not run (no device, HIP failure, device OOM).
+// (OBJ2VOXEL_ERR_DEVICE - no device, HIP failure, device out of memory - is declared in include/obj2voxel.h)
 
 using namespace o2v;
 
@@ -354,13 +354,13 @@ struct StreamedUpload {
     }
 };
 
+constexpr uint64_t kReadBackBatch = 1u << 20;  // (x, y, z, argb) records per sink call
+
 // ---- device sessions -----------------------------------------------------------------------------------------------
 // What one obj2voxel_voxelize call drives: one GPU (a context), or - if the environment names several devices
 // (O2V_DEVICES=0,1,2,3 or O2V_DEVICES=all) - an in-process group of GPUs with the grid sharded by z-slab
 // (include/o2v_hip.h, multi-GPU section), where the reference hands its chunks to a worker pool
 // (src/obj2voxel.cpp:467-520).
-constexpr uint64_t kReadBackBatch = 1u << 20;  // (x, y, z, argb) records per sink call
-
 struct Session {
     std::vector<int> devices;
     o2v_hip_ctx *ctx = nullptr;      // one device
@@ -372,8 +372,9 @@ struct Session {
     std::thread pinning;
     void start_pinning()
     {
+        // (on the session's first device: a new thread's current device is device 0, which this process may not be meant to touch)
         pinning = std::thread{[this] {
-            for (uint32_t *&p : pinned) p = static_cast<uint32_t *>(o2v_hip_alloc_pinned(kReadBackBatch * 16));
+            for (uint32_t *&p : pinned) p = static_cast<uint32_t *>(o2v_hip_alloc_pinned_on(devices[0], kReadBackBatch * 16));
             pinned_records = pinned[0] && pinned[1] ? kReadBackBatch : 0;
         }};
     }

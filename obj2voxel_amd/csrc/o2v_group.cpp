@@ -141,6 +141,15 @@ struct o2v_hip_group {
 
 extern "C" {
 
+// (lives here rather than beside o2v_hip_alloc_pinned: the device translation unit's hash identifies the kernels a profile
+// was taken with, and this is host plumbing)
+void *o2v_hip_alloc_pinned_on(int device, size_t bytes)
+{
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    return o2v_hip_alloc_pinned(bytes);
+}
+
+
 // The shared-memory exchange on its own (no GPU): n threads run the callbacks self-test against each other, several rounds.
 int o2v_hip_group_exchange_selftest(uint32_t n_threads)
 {

@@ -103,6 +103,10 @@ typedef struct {
     uint64_t jobs;        /* candidates that passed the plane cull and the separating-axis pre-test: voxel jobs of the clip loop */
     uint64_t certain_hits;/* occupancy-only mode: hits established without a voxel job (the voxel centre's column meets the leaf
                              well inside both), included in hits and direct_hits */
+    uint64_t skipped_jobs;/* occupancy-only mode: those of `jobs` that were not run because their voxel was marked already when
+                             phase 2 of their batch began (which ones depends on the order the workgroups happen to run in, so
+                             this number and `hits` - only hits that were established are counted - vary from run to run;
+                             the voxels do not) */
 } o2v_hip_stats;
 
 int o2v_hip_device_count(void);

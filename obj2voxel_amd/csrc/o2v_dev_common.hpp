@@ -124,6 +124,7 @@ struct Counters {
     float xform[12];
     unsigned long long n_certain;   // occupancy-only mode: hits established without a voxel job (certain_prepare)
     unsigned long long n_jobs;      // candidate voxels that passed phase 1 of k_voxelize (= voxel jobs of phase 2)
+    unsigned long long n_jobs_skipped;  // occupancy-only mode: jobs dropped before phase 2 because their voxel was marked already
     unsigned long long dbg[16];  // event counts of an instrumented build (-DO2V_INSTRUMENT, tools/instrument.sh); else zero
 };
 

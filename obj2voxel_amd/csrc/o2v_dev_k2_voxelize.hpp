@@ -313,6 +313,112 @@ __device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, floa
 }
 
 
+// The same test with everything that does not depend on the row taken out of it ("tile mode" of phase 1: a lane owns a tile
+// and walks its rows).  Every axis' interval of admissible x is linear in the row's (cy, cz): for the axis y x E the two
+// projections au, aw of row_clip_edge differ by a constant, so which one is the larger is a property of the leaf, and the
+// interval is [yl, yu] + ys cz with three numbers per edge; likewise z x E with cy, the plane axis with both, and the axes
+// x x E reject a row iff a linear form of (cy, cz) leaves [rlo, rhi].  Same inflation, radii, error bound of the plane axis and
+// slack as row_span; the products are grouped differently (and fused), which moves an interval's end by a few ulp of the
+// extent - four orders of magnitude below the 0.02-voxel inflation and the 0.01-voxel slack.  Infinite bounds switch an axis
+// off (a NaN anywhere compares false / is ignored by fmaxf and fminf: it rejects nothing).  34 registers per lane against
+// ~300 instructions per row.  Not reference arithmetic.
+struct RowPlan {
+    float ra[3], rb[3], rhi[3], rlo[3];                  // x x E_i: lin = ra cy + rb cz must stay within [rlo, rhi]
+    float yl[3], yu[3], ys[3], zl[3], zu[3], zs[3];      // y x E_i: [yl, yu] + ys cz;  z x E_i: [zl, zu] + zs cy
+    float pc, py, pz, pw;                                // plane axis: centre pc + py cy + pz cz, half width pw
+    __device__ __forceinline__ void edge(int i, V3 E, V3 U, V3 W, float slack, float h)
+    {
+        const float inf = __builtin_inff();
+        {
+            const float ku = E.z * U.y - E.y * U.z, kw = E.z * W.y - E.y * W.z;
+            const float rad = h * (abs_f(E.z) + abs_f(E.y));
+            ra[i] = -E.z;
+            rb[i] = E.y;
+            rhi[i] = rad - fminf(ku, kw);
+            rlo[i] = -rad - fmaxf(ku, kw);
+        }
+        {
+            const float gu = E.x * U.z - E.z * U.x, gw = E.x * W.z - E.z * W.x;
+            const float rad = h * (abs_f(E.x) + abs_f(E.z));
+            yl[i] = -inf;
+            yu[i] = inf;
+            ys[i] = 0.f;
+            if (abs_f(E.z) > 1e-20f) {
+                const float r = __builtin_amdgcn_rcpf(E.z);
+                const float a = (-rad - fmaxf(gu, gw)) * r, b = (rad - fminf(gu, gw)) * r;
+                yl[i] = fminf(a, b) - slack;
+                yu[i] = fmaxf(a, b) + slack;
+                ys[i] = E.x * r;
+            }
+        }
+        {
+            const float hu = E.y * U.x - E.x * U.y, hw = E.y * W.x - E.x * W.y;
+            const float rad = h * (abs_f(E.y) + abs_f(E.x));
+            zl[i] = -inf;
+            zu[i] = inf;
+            zs[i] = 0.f;
+            if (abs_f(E.y) > 1e-20f) {
+                const float r = __builtin_amdgcn_rcpf(-E.y);
+                const float a = (-rad - fmaxf(hu, hw)) * r, b = (rad - fminf(hu, hw)) * r;
+                zl[i] = fminf(a, b) - slack;
+                zu[i] = fmaxf(a, b) + slack;
+                zs[i] = -E.x * r;
+            }
+        }
+    }
+    // p0, p1, p2, extent, margin: as for row_span
+    __device__ __forceinline__ void prepare(V3 p0, V3 p1, V3 p2, float extent, float margin)
+    {
+        const float h = 0.5f + margin;
+        const float slack = 0.01f + 4e-6f * extent;
+        const V3 e0 = p1 - p0, e1 = p2 - p1, e2 = p0 - p2;
+        {
+            const V3 n = cross(e0, e1);
+            const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
+            const float far = extent + abs_f(p0.x) + abs_f(p0.y) + abs_f(p0.z);
+            const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) + 1e-5f * l0 * l1 * (far + 1.0f);
+            pc = py = pz = 0.f;
+            pw = __builtin_inff();
+            if (abs_f(n.x) > 1e-20f) {
+                const float r = __builtin_amdgcn_rcpf(n.x);
+                pc = r * (n.x * p0.x + n.y * p0.y + n.z * p0.z);
+                py = -(r * n.y);
+                pz = -(r * n.z);
+                pw = rad * abs_f(r) + slack;
+            }
+        }
+        edge(0, e0, p0, p2, slack, h);
+        edge(1, e1, p1, p0, slack, h);
+        edge(2, e2, p2, p1, slack, h);
+    }
+    // the row at (cy, cz): the first admissible voxel of [xlo, xhi] and their number
+    __device__ __forceinline__ uint32_t span(float cy, float cz, uint32_t xlo, uint32_t xhi, uint32_t &first) const
+    {
+        float lo = (float) xlo + 0.5f, hi = (float) xhi + 0.5f;
+        bool any = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float lin = __builtin_fmaf(ra[i], cy, rb[i] * cz);
+            any = any && !(lin > rhi[i] || lin < rlo[i]);
+            lo = fmaxf(lo, __builtin_fmaf(ys[i], cz, yl[i]));
+            hi = fminf(hi, __builtin_fmaf(ys[i], cz, yu[i]));
+            lo = fmaxf(lo, __builtin_fmaf(zs[i], cy, zl[i]));
+            hi = fminf(hi, __builtin_fmaf(zs[i], cy, zu[i]));
+        }
+        const float c = __builtin_fmaf(py, cy, __builtin_fmaf(pz, cz, pc));
+        lo = fmaxf(lo, c - pw);
+        hi = fminf(hi, c + pw);
+        const float fa = ceilf(lo - 0.5f), fb = floorf(hi - 0.5f);
+        if (!any || !(fa <= fb)) {
+            first = xlo;
+            return 0u;
+        }
+        first = (uint32_t) fa;
+        return (uint32_t) fb - (uint32_t) fa + 1u;
+    }
+};
+
+
 // Early decisions about a piece from its bounding box (speed only, results unchanged).  For the planes in `planes` (bit =
 // level: lo x, y, z, hi x, y, z) of the voxel at (fx, fy, fz):
 //   fail  planes the piece does not pass whole.  A piece whose vertices all satisfy v >= plane (lo planes) or v < plane
@@ -545,16 +651,19 @@ __device__ __forceinline__ uint32_t vox_exscan(uint32_t v, uint32_t *s_wave /*[k
     return base + inc - v;
 }
 
-template <bool UV>
-__global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
-                                                     Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
-                                                     uint2 *jobq_all, Params p)
+// (UV: the mesh has textured triangles - pieces carry uv coordinates.  OCC: occupancy-only mode, Params::occupancy_only -
+// its own kernel, k_voxelize_occ, so that the weighted routes' code is not in it and vice versa.)
+template <bool UV, bool OCC>
+__device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+                                              Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
+                                              uint2 *jobq_all, const Params &p)
 {
+    static_assert(!(UV && OCC), "occupancy-only mode has no uv arithmetic");
     constexpr uint32_t kVoxBlock = VoxShape<UV>::block, kVoxTiles = VoxShape<UV>::tiles, kQueueCap = VoxShape<UV>::queue;
     // (occupancy-only mode: most candidates are settled in phase 1, so a batch leaves few voxel jobs - half as many, larger
     // batches keep phase 2's lanes busier: bench mesh 0.54 -> 0.50 ms)
-    const uint32_t kBatchesPerBlock = (!UV && p.occupancy_only) ? (VoxShape<UV>::batches + 1u) / 2u : VoxShape<UV>::batches;
-    const uint32_t kBatchesPerBlockLarge = (!UV && p.occupancy_only) ? (VoxShape<UV>::batches_large + 1u) / 2u : VoxShape<UV>::batches_large;
+    constexpr uint32_t kBatchesPerBlock = OCC ? (VoxShape<UV>::batches + 1u) / 2u : VoxShape<UV>::batches;
+    constexpr uint32_t kBatchesPerBlockLarge = OCC ? (VoxShape<UV>::batches_large + 1u) / 2u : VoxShape<UV>::batches_large;
     constexpr uint32_t kFinerBatchMinTiles = VoxShape<UV>::finer_min;
     __shared__ uint32_t s_leaf[kVoxTiles * kLeafStride];
     __shared__ uint32_t s_tleaf[kVoxTiles];
@@ -564,26 +673,29 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
     __shared__ uint32_t s_scan[kVoxBlock / 64];
     __shared__ uint32_t s_tend;
     __shared__ uint8_t s_chunk_tile[kQueueCap / 64 + 4];  // tile slot (< 256) of each 64-candidate chunk's first candidate
-    __shared__ float s_inv_dx[kVoxTiles], s_inv_dy[kVoxTiles];
-    __shared__ float s_margin[kVoxTiles];  // out_margin of the tile's leaf (piece_masks)
-    __shared__ float s_satm[kVoxTiles];    // sat_margin of the tile's leaf (row_span)
+    __shared__ float s_inv_dy[kVoxTiles];
+    __shared__ float s_mcoord[kVoxTiles];  // the largest |coordinate| of the tile's leaf: out_margin (piece_masks) and sat_margin (row_span) follow from it
+    // Survivors of the candidate rows wait here, per wavefront, until 64 of them are together (phase 1): {x in the leaf's box |
+    // tile slot << 16, y | z << 16}
+    constexpr uint32_t kRing = 128;
+    __shared__ uint2 s_ring[(kVoxBlock / 64) * kRing];
     __shared__ uint32_t s_trow0[kVoxTiles];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
     __shared__ uint32_t s_rprefix[kVoxTiles + 6];  // rows before tile k (+ total + padding, as s_tprefix)
-    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct, s_certain;
+    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct, s_certain, s_nlive, s_skipped, s_maxrows;
     // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
     // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
     // voxel (the long ones) are filed from the front, the others from the back, and the queue is served front to back:
     // longest jobs first keeps the end of a sub-batch, when lanes run out of work, short.
-    uint2 *jobq = jobq_all + (size_t) blockIdx.x * kQueueCap;
+    uint2 *jobq = jobq_all + (size_t) blockIdx.x * (OCC ? 2u * kQueueCap : kQueueCap);
     __shared__ uint32_t s_next_x[kVoxBlock], s_next_y[kVoxBlock];  // every lane's prefetched next job record (take_job)
     __shared__ uint8_t s_cls[64];    // classify_flags
     __shared__ uint8_t s_kept[128];  // classify_kept: index | keep_lo << 6
 
     if (expand_overflowed(c, p)) return;
-    const bool use_direct = direct_active(c, p) && (!UV || p.pick_max);
+    const bool use_direct = OCC || (direct_active(c, p) && (!UV || p.pick_max));
     // occupancy-only mode (Params::occupancy_only): a job is decided by its first surviving piece - splitTriangle only
     // ever adds the leaf's area per surviving piece (voxelization.cpp:414-420), so the weight is non-zero from then on
-    const bool occ_only = !UV && p.occupancy_only != 0u;
+    constexpr bool occ_only = OCC;
     const uint32_t n_tiles = c->n_tiles < p.cap_tiles ? c->n_tiles : p.cap_tiles;
     // Batch size: about kBatchesPerBlock batches per workgroup (VoxShape), between one tile per wavefront and what the LDS staging holds.  Few
     // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
@@ -603,6 +715,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
 #ifdef O2V_INSTRUMENT
     uint32_t dbgc[16] = {};
+    unsigned long long t_drain = 0;  // cycles inside file_survivor (of this wavefront), calls, survivors
+    uint32_t n_drain = 0, n_drain_lanes = 0;
     unsigned long long tmr[4] = {0, 0, 0, 0};  // cycles: staging + phase 1 | phase 2 loop | waiting at the barrier after phase 2 | whole kernel
     unsigned long long t_mark = __builtin_readcyclecounter();
     const unsigned long long t_kernel0 = t_mark;
@@ -619,13 +733,17 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
         s_hits = 0;
         s_direct = 0;
         s_certain = 0;
+        s_skipped = 0;
     }
     if (threadIdx.x < 64u) s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
     for (uint32_t i = threadIdx.x; i < 128u; i += kVoxBlock) s_kept[i] = (uint8_t) classify_kept(i & 63u, i >= 64u);
 
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_batch = atomicAdd(&c->batch_cursor, 1u);
+        if (threadIdx.x == 0) {
+            s_batch = atomicAdd(&c->batch_cursor, 1u);
+            s_maxrows = 0;
+        }
         __syncthreads();
         const uint32_t batch = s_batch;
         if (batch >= n_batches) break;
@@ -667,9 +785,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 lean_ok = lean_ok && a >= kLeanAreaMin && a <= kLeanAreaMax && uvmax <= kLeanUv && uvsum == uvsum;
             }
             s_tcount[threadIdx.x] = my_count | (is_small ? 0x80000000u : 0u) | (lean_ok ? 0x40000000u : 0u);
-            s_margin[threadIdx.x] = out_margin(m);
-            s_satm[threadIdx.x] = sat_margin(m);
-            if (!UV && occ_only) {
+            s_mcoord[threadIdx.x] = m;
+            if (OCC) {
                 // the certain-hit test's per-leaf part goes where the staged leaf keeps its uv coordinates (unused without uv)
                 uint32_t *lw = &s_leaf[threadIdx.x * kLeafStride];
                 const CertainPrep cp = certain_prepare(V3{__uint_as_float(lw[0]), __uint_as_float(lw[1]), __uint_as_float(lw[2])},
@@ -684,13 +801,13 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 lw[16] = __float_as_uint(cp.tau);
                 lw[17] = cp.axis;
             }
-            s_inv_dx[threadIdx.x] = 1.0f / (float) dx;
             s_inv_dy[threadIdx.x] = 1.0f / (float) dy;
             if (my_count) {
                 const uint32_t start = s_tstart[threadIdx.x];
                 const uint32_t r0 = start / dx;
                 s_trow0[threadIdx.x] = r0;
                 my_rows = (start + my_count - 1u) / dx - r0 + 1u;
+                atomicMax(&s_maxrows, my_rows);
             }
         }
         {
@@ -727,11 +844,13 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             __syncthreads();
             const uint32_t t_end = s_tend;
 
-            // ---- phase 1: the sub-batch's candidate rows flattened over the lanes ---------------------------
+            // ---- phase 1: the sub-batch's candidate rows, their survivors packed 64 to a wavefront ------------------
             // A tile's candidates are a run of the leaf's clamped AABB in x-fastest order, i.e. a few rows (fixed y, z) of it.
             // A lane takes one row, solves the separating-axis test for x (row_span) and so names the row's surviving
-            // voxels without visiting the others; the survivors of the wavefront's 64 rows are then flattened over the
-            // lanes again (prefix sum + search), one voxel each, for the reference's plane cull and the job record.
+            // voxels without visiting the others.  The survivors go into the wavefront's ring in LDS and are taken out 64 at a
+            // time (file_survivor: the reference's plane cull, the certain-hit test, the job record), so that the expensive
+            // per-voxel part always runs with every lane - a 64-row chunk of a tessellated surface leaves ~80 survivors, i.e.
+            // one full and one quarter-full pass when each chunk was flattened on its own (round 4).
             // Row g (in sub-batch order) belongs to the tile k with s_rprefix[k] <= g < s_rprefix[k + 1]; a small table
             // gives every 64-row chunk the tile its first row falls in and a lane walks forward a few tiles at most.
             const uint32_t base_row = s_rprefix[t_begin];
@@ -743,9 +862,208 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             }
             __syncthreads();
             O2V_LAP(0);
+
+            // One survivor per lane (wave-uniform call; `valid`: the lane has one): voxel (lx, ly, lz) of tile slot kk's box.
+            auto file_survivor = [&](bool valid, uint32_t kk, uint32_t lx, uint32_t ly, uint32_t lz) {
+                bool keep = false, heavy = false, certain = false;
+                uint2 rec = make_uint2(0u, 0u);
+                if (valid) {
+                    const uint32_t *lf = &s_leaf[kk * kLeafStride];
+                    const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + ly, qz = (lf[21] & 0xffffu) + lz;
+                    const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
+                    const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
+                    const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
+                    const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
+                    // plane distance cull, voxelization.cpp:451-458
+                    const V3 rel = V3{(float) qx + 0.5f, (float) qy + 0.5f, (float) qz + 0.5f} - v0;
+                    const float sd = dot(nrm, rel);
+                    keep = !(abs_f(sd) > kPlaneDistanceLimit);
+                    if (OCC && keep) {
+                        // certain hit (see certain_prepare): no voxel job, the voxel is marked here.  Tried are the columns
+                        // through a 5 x 5 lattice of points around the voxel centre (every quantity of the test is linear in
+                        // the offset); the lattice stays inside the voxel by the margin D.
+                        const uint32_t axis = lf[17];
+                        const uint32_t iu = axis == 0u ? 1u : 0u, iw = axis == 2u ? 1u : 2u;
+                        const float tau = __uint_as_float(lf[16]);
+                        if (tau < 0.34f) {  // (else no point of the leaf is far enough from its edges)
+                            const float lim = 0.5f - (1.5f * sat_margin(s_mcoord[kk]) + 1e-3f);  // 0.5 - D, D = certain_margin(m)
+                            // kN lines across the voxel (constant offset in the second lattice axis); along a line every
+                            // condition is a linear inequality in the offset o: they leave an interval, the point exists if it is
+                            // not empty (by a slack that absorbs this code's own rounding)
+                            constexpr int kN = O2V_CERTAIN_N;
+                            const float half = 0.5f * (float) (kN - 1);
+                            const float step = fminf(O2V_CERTAIN_STEP, lim / fmaxf(half, 0.5f));
+                            const float m00 = __uint_as_float(lf[12]), m01 = __uint_as_float(lf[13]), m10 = __uint_as_float(lf[14]), m11 = __uint_as_float(lf[15]);
+                            const float rnd = __builtin_amdgcn_rcpf(comp(nrm, axis));
+                            const float tu = comp(nrm, iu) * rnd, tw = comp(nrm, iw) * rnd * step;  // dt per unit of o / per line
+                            const float pu = comp(rel, iu), pw = comp(rel, iw) - half * step;       // the first line's centre
+                            float l1 = m00 * pu + m01 * pw, l2 = m10 * pu + m11 * pw, t0 = sd * rnd - half * tw;
+                            const float d1w = m01 * step, d2w = m11 * step;
+                            // a * o >= b  ->  o >= b / a (a > 0), o <= b / a (a < 0), or b <= 0 (a = 0)
+                            const float a1 = m00, a2 = m10, a0 = -(m00 + m10), a3 = tu, a4 = -tu;
+                            auto inv = [](float a) { return abs_f(a) > 1e-12f ? __builtin_amdgcn_rcpf(a) : 0.f; };
+                            const float r1 = inv(a1), r2 = inv(a2), r0 = inv(a0), r3 = inv(a3), r4 = -r3;
+#pragma unroll
+                            for (int jw = 0; jw < kN; ++jw) {
+                                float lo = -lim, hi = lim;
+                                bool ok = true;
+                                auto bound = [&](float a, float ra, float bb) {
+                                    const float x = bb * ra;
+                                    lo = (ra > 0.f) ? fmaxf(lo, x) : lo;
+                                    hi = (ra < 0.f) ? fminf(hi, x) : hi;
+                                    ok = ok && (ra != 0.f || bb <= 0.f);
+                                };
+                                bound(a1, r1, tau - l1);
+                                bound(a2, r2, tau - l2);
+                                bound(a0, r0, tau - ((1.0f - l1) - l2));
+                                bound(a3, r3, -lim - t0);
+                                bound(a4, r4, t0 - lim);
+                                certain |= ok && hi - lo >= 2e-3f;
+                                l1 += d1w;
+                                l2 += d2w;
+                                t0 += tw;
+                            }
+                        }
+                        if (certain) {
+                            keep = false;
+                            const uint32_t ox = qx >> p.ss_shift, oy = qy >> p.ss_shift, oz = qz >> p.ss_shift;
+                            uint32_t brick;
+                            const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                            p.occgrid[cell] = 1;      // (plain stores; benign races: every writer stores the same value)
+                            p.dirty_max[brick] = 1;
+                        }
+                    }
+                    if (keep) {
+                        // the job record: position, tile slot, the planes of this voxel the leaf does not pass whole
+                        const bool small = (s_tcount[kk] >> 31) != 0u;
+                        Piece<false> leaf;
+                        leaf.a = v0;
+                        leaf.b = v1;
+                        leaf.c = v2;
+                        uint32_t cf0, out_unused, near_unused;
+                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused, near_unused);
+                        rec = make_uint2(qx | (qy << 16), qz | (kk << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u) | ((s_tcount[kk] & 0x40000000u) << 1));
+                        heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
+                    }
+                }
+                if (OCC) {
+                    const unsigned long long mc = __ballot(certain);
+                    if (mc && lane == 0) atomicAdd(&s_certain, (uint32_t) __popcll(mc));
+                }
+                const unsigned long long mh = __ballot(keep && heavy), ml = __ballot(keep && !heavy);
+                if (mh | ml) {
+                    uint32_t base_h = 0, base_l = 0;
+                    if (lane == 0) {
+                        if (mh) base_h = atomicAdd(&s_nheavy, (uint32_t) __popcll(mh));
+                        if (ml) base_l = atomicAdd(&s_nlight, (uint32_t) __popcll(ml));
+                    }
+                    base_h = __shfl(base_h, 0, 64);
+                    base_l = __shfl(base_l, 0, 64);
+                    if (keep) {
+                        const uint32_t at = heavy ? base_h + __builtin_amdgcn_mbcnt_hi((uint32_t) (mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mh, 0u))
+                                                  : kQueueCap - 1u - (base_l + __builtin_amdgcn_mbcnt_hi((uint32_t) (ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ml, 0u)));
+                        jobq[at] = rec;
+                    }
+                }
+            };
+
             // Few long rows (large axis-aligned leaves): every wavefront looks at the same 64 rows and they share the
-            // survivors, 64 at a time; otherwise each wavefront has its own rows.
+            // survivors, 64 at a time; otherwise each wavefront has its own rows and its own ring.
             const bool shared_rows = s_tprefix[t_end] - base_cand > 32u * n_rows;
+            uint2 *ring = &s_ring[wave * kRing];
+            uint32_t r_head = 0, r_count = 0;  // wave-uniform: the ring's entries are [r_head, r_head + r_count) modulo kRing
+            // takes survivors out of the ring, 64 at a time, as long as it holds `at_least` (64; 1 for the last, partial group)
+            auto ring_drain = [&](uint32_t at_least) {
+                while (r_count >= at_least) {
+                    const uint2 e = ring[(r_head + lane) & (kRing - 1u)];
+#ifdef O2V_INSTRUMENT
+                    const unsigned long long t_d0 = __builtin_readcyclecounter();
+#endif
+                    file_survivor(lane < r_count, e.x >> 16, e.x & 0xffffu, e.y & 0xffffu, e.y >> 16);
+#ifdef O2V_INSTRUMENT
+                    t_drain += __builtin_readcyclecounter() - t_d0;
+                    n_drain += 1u;
+                    n_drain_lanes += r_count < 64u ? r_count : 64u;
+#endif
+                    const uint32_t n_taken = r_count < 64u ? r_count : 64u;
+                    r_head += n_taken;
+                    r_count -= n_taken;
+                }
+            };
+            // a row's survivors - voxels x_first .. x_first + n_out - 1 of the row yz of tile slot k (xk = x_first | k << 16) - go
+            // into the ring, as many at a time as it has room for; full groups of 64 leave it (wave-uniform call)
+            auto ring_push = [&](uint32_t n_out, uint32_t xk, uint32_t yz) {
+                uint32_t inc = n_out;
+#pragma unroll
+                for (uint32_t d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += o;
+                }
+                const uint32_t total = __shfl(inc, 63, 64), exc = inc - n_out;
+                uint32_t pushed = 0;  // wave-uniform: survivors of these 64 rows (in prefix order) already in the ring
+                while (pushed < total) {
+                    const uint32_t room = kRing - r_count;
+                    const uint32_t take = total - pushed < room ? total - pushed : room;
+                    const uint32_t s0 = exc > pushed ? exc : pushed, s1 = exc + n_out < pushed + take ? exc + n_out : pushed + take;
+                    for (uint32_t sq = s0; sq < s1; ++sq) ring[(r_head + r_count + (sq - pushed)) & (kRing - 1u)] = make_uint2(xk + (sq - exc), yz);
+                    __builtin_amdgcn_wave_barrier();
+                    r_count += take;
+                    pushed += take;
+                    ring_drain(64u);
+                }
+            };
+#ifdef O2V_TILE_MODE
+            // Tile mode: many tiles of few rows each (a finely tessellated surface) - a lane owns a tile, works the row test's
+            // leaf-only part out once (RowPlan) and walks the tile's rows.  Taken when the tiles' row counts are even enough
+            // for the lanes to stay busy (at a third of the lanes it still issues fewer instructions than row mode); else, and
+            // for a batch of few tiles with many rows each, the rows are dealt out over all lanes (row mode, below).
+            const uint32_t n_sub = t_end - t_begin;
+            const bool tile_mode = !shared_rows && n_sub >= kVoxBlock / 4u && (uint64_t) s_maxrows * n_sub <= 3ull * n_rows;
+#else
+            const bool tile_mode = false;
+#endif
+            if (tile_mode) {
+                const uint32_t k = threadIdx.x;
+                const bool mine = k >= t_begin && k < t_end && my_count != 0u;
+                const uint32_t *lf = &s_leaf[k * kLeafStride];
+                const uint32_t dx = mine ? lf[21] >> 16 : 1u, dy = mine ? lf[22] & 0xffffu : 1u, dz = mine ? lf[22] >> 16 : 1u;
+                const uint32_t start = mine ? s_tstart[k] : 0u, row0 = mine ? s_trow0[k] : 0u;
+                const uint32_t rows_mine = mine ? my_rows : 0u;
+                const bool small = mine && (s_tcount[k] >> 31) != 0u;
+                RowPlan rp;
+                if (small) {
+                    const float ox = (float) (lf[20] & 0xffffu), oy = (float) (lf[20] >> 16), oz = (float) (lf[21] & 0xffffu);
+                    const V3 p0{__uint_as_float(lf[0]) - ox, __uint_as_float(lf[1]) - oy, __uint_as_float(lf[2]) - oz};
+                    const V3 p1{__uint_as_float(lf[3]) - ox, __uint_as_float(lf[4]) - oy, __uint_as_float(lf[5]) - oz};
+                    const V3 p2{__uint_as_float(lf[6]) - ox, __uint_as_float(lf[7]) - oy, __uint_as_float(lf[8]) - oz};
+                    rp.prepare(p0, p1, p2, (float) (dx + dy + dz), sat_margin(s_mcoord[k]));
+                }
+                uint32_t lz = row0 / dy, ly = row0 - lz * dy;
+                const uint32_t first_x = start - row0 * dx;                                      // the tile's first candidate in its first row
+                const uint32_t last_x = (start + my_count - 1u) - (row0 + rows_mine - 1u) * dx;  // ... and its last one in its last row
+                uint32_t max_rows = rows_mine;
+#pragma unroll
+                for (uint32_t d = 32; d >= 1; d >>= 1) {
+                    const uint32_t o = __shfl_xor(max_rows, d, 64);
+                    max_rows = o > max_rows ? o : max_rows;
+                }
+                for (uint32_t r = 0; r < max_rows; ++r) {
+                    uint32_t n_out = 0, x_first = 0;
+                    if (r < rows_mine) {
+                        const uint32_t xlo = r == 0u ? first_x : 0u, xhi = r + 1u == rows_mine ? last_x : dx - 1u;
+                        x_first = xlo;
+                        n_out = xhi - xlo + 1u;
+                        if (small) n_out = rp.span((float) ly + 0.5f, (float) lz + 0.5f, xlo, xhi, x_first);
+                    }
+                    ring_push(n_out, x_first | (k << 16), ly | (lz << 16));
+                    ly += 1u;
+                    if (ly == dy) {
+                        ly = 0u;
+                        lz += 1u;
+                    }
+                }
+            }
+            else
             for (uint32_t g0 = shared_rows ? 0u : wave * 64u; g0 < n_rows; g0 += shared_rows ? 64u : kVoxBlock) {
                 const uint32_t g = g0 + lane;
                 uint32_t k = s_chunk_tile[g0 / 64u];
@@ -783,8 +1101,13 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         const V3 p0{__uint_as_float(lf[0]) - ox, __uint_as_float(lf[1]) - oy, __uint_as_float(lf[2]) - oz};
                         const V3 p1{__uint_as_float(lf[3]) - ox, __uint_as_float(lf[4]) - oy, __uint_as_float(lf[5]) - oz};
                         const V3 p2{__uint_as_float(lf[6]) - ox, __uint_as_float(lf[7]) - oy, __uint_as_float(lf[8]) - oz};
-                        n_out = row_span(p0, p1, p2, (float) ly + 0.5f, (float) lz + 0.5f, xlo, xhi, (float) (dx + dy + dz), s_satm[k], x_first);
+                        n_out = row_span(p0, p1, p2, (float) ly + 0.5f, (float) lz + 0.5f, xlo, xhi, (float) (dx + dy + dz), sat_margin(s_mcoord[k]), x_first);
                     }
+                }
+                const uint32_t xk = x_first | (k << 16), yz = ly | (lz << 16);
+                if (!shared_rows) {
+                    ring_push(n_out, xk, yz);
+                    continue;
                 }
                 // inclusive prefix of the rows' survivor counts over the wavefront
                 uint32_t inc = n_out;
@@ -794,12 +1117,12 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                     if (lane >= d) inc += o;
                 }
                 const uint32_t total = __shfl(inc, 63, 64);
-                const uint32_t exc = inc - n_out, xk = x_first | (k << 16), yz = ly | (lz << 16);
+                const uint32_t exc = inc - n_out;
                 // (long rows - large axis-aligned leaves - are followed with a wave-uniform cursor instead of the search:
                 // a chunk of 64 survivors then usually comes from one row)
                 const bool long_rows = total > 512u;
                 uint32_t row_b = 0;  // wave-uniform: the row (lane) the survivor b belongs to
-                for (uint32_t b = shared_rows ? wave * 64u : 0u; b < total; b += shared_rows ? kVoxBlock : 64u) {
+                for (uint32_t b = wave * 64u; b < total; b += kVoxBlock) {
                     const uint32_t o = b + lane;  // this lane's survivor
                     // its row: the first lane whose inclusive prefix exceeds o
                     uint32_t src = 0;
@@ -819,112 +1142,62 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                         src &= 63u;  // (lanes beyond the total look at lane 63; they are masked below)
                     }
                     const uint32_t r_exc = __shfl(exc, (int) src, 64), r_xk = __shfl(xk, (int) src, 64), r_yz = __shfl(yz, (int) src, 64);
-                    bool keep = false, heavy = false, certain = false;
-                    uint2 rec = make_uint2(0u, 0u);
-                    if (o < total) {
-                        const uint32_t kk = r_xk >> 16, lx = (r_xk & 0xffffu) + (o - r_exc);
-                        const uint32_t *lf = &s_leaf[kk * kLeafStride];
-                        const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + (r_yz & 0xffffu), qz = (lf[21] & 0xffffu) + (r_yz >> 16);
-                        const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
-                        const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
-                        const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
-                        const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
-                        // plane distance cull, voxelization.cpp:451-458
-                        const V3 rel = V3{(float) qx + 0.5f, (float) qy + 0.5f, (float) qz + 0.5f} - v0;
-                        const float sd = dot(nrm, rel);
-                        keep = !(abs_f(sd) > kPlaneDistanceLimit);
-                        if (!UV && occ_only && keep) {
-                            // certain hit (see certain_prepare): no voxel job, the voxel is marked here.  Tried are the columns
-                            // through a 5 x 5 lattice of points around the voxel centre (every quantity of the test is linear in
-                            // the offset); the lattice stays inside the voxel by the margin D.
-                            const uint32_t axis = lf[17];
-                            const uint32_t iu = axis == 0u ? 1u : 0u, iw = axis == 2u ? 1u : 2u;
-                            const float tau = __uint_as_float(lf[16]);
-                            if (tau < 0.34f) {  // (else no point of the leaf is far enough from its edges)
-                                const float lim = 0.5f - (1.5f * s_satm[kk] + 1e-3f);  // 0.5 - D, D = certain_margin(m)
-                                // kN lines across the voxel (constant offset in the second lattice axis); along a line every
-                                // condition is a linear inequality in the offset o: they leave an interval, the point exists if it is
-                                // not empty (by a slack that absorbs this code's own rounding)
-                                constexpr int kN = O2V_CERTAIN_N;
-                                const float half = 0.5f * (float) (kN - 1);
-                                const float step = fminf(O2V_CERTAIN_STEP, lim / fmaxf(half, 0.5f));
-                                const float m00 = __uint_as_float(lf[12]), m01 = __uint_as_float(lf[13]), m10 = __uint_as_float(lf[14]), m11 = __uint_as_float(lf[15]);
-                                const float rnd = __builtin_amdgcn_rcpf(comp(nrm, axis));
-                                const float tu = comp(nrm, iu) * rnd, tw = comp(nrm, iw) * rnd * step;  // dt per unit of o / per line
-                                const float pu = comp(rel, iu), pw = comp(rel, iw) - half * step;       // the first line's centre
-                                float l1 = m00 * pu + m01 * pw, l2 = m10 * pu + m11 * pw, t0 = sd * rnd - half * tw;
-                                const float d1w = m01 * step, d2w = m11 * step;
-                                // a * o >= b  ->  o >= b / a (a > 0), o <= b / a (a < 0), or b <= 0 (a = 0)
-                                const float a1 = m00, a2 = m10, a0 = -(m00 + m10), a3 = tu, a4 = -tu;
-                                auto inv = [](float a) { return abs_f(a) > 1e-12f ? __builtin_amdgcn_rcpf(a) : 0.f; };
-                                const float r1 = inv(a1), r2 = inv(a2), r0 = inv(a0), r3 = inv(a3), r4 = -r3;
+                    file_survivor(o < total, r_xk >> 16, (r_xk & 0xffffu) + (o - r_exc), r_yz & 0xffffu, r_yz >> 16);
+                }
+            }
+            ring_drain(1u);  // the last, partial group
+            __syncthreads();  // (workgroup scope: the records written above are visible to every wavefront of the workgroup)
+            uint32_t n_heavy = s_nheavy, n_surv = n_heavy + s_nlight;
+            if (threadIdx.x == 0 && n_surv) atomicAdd(&c->n_jobs, (unsigned long long) n_surv);
+            const uint2 *jobs_front = jobq, *jobs_back = jobq + (kQueueCap - 1u);  // job q: front[q] (q < n_heavy), back[-(q - n_heavy)]
+#ifndef O2V_NO_JOB_FILTER
+            if (OCC) {
+                // Occupancy only: a job whose voxel is marked already cannot change the result (the result is the set of marked
+                // voxels), and most jobs are such - a voxel that one triangle merely clips at a corner is, as a rule, a
+                // certain hit of its neighbour, and the certain hits of this batch (and of the earlier ones) are all stored
+                // by now.  The jobs are read once more, those whose cell still reads zero are compacted into the second half of
+                // the workgroup's queue, and phase 2 serves that.  A stale zero (another XCD's L2 holds the byte) only
+                // means the job runs although it need not: the set of marked voxels is the same either way.
+                uint2 *live = jobq + kQueueCap;
+                if (threadIdx.x == 0) s_nlive = 0;
+                __syncthreads();
+                constexpr uint32_t kPerLane = 4;
+                for (uint32_t base = 0; base < n_surv; base += kVoxBlock * kPerLane) {
+                    uint2 rec[kPerLane];
+                    bool ok[kPerLane];
+                    uint8_t seen[kPerLane];
 #pragma unroll
-                                for (int jw = 0; jw < kN; ++jw) {
-                                    float lo = -lim, hi = lim;
-                                    bool ok = true;
-                                    auto bound = [&](float a, float ra, float bb) {
-                                        const float x = bb * ra;
-                                        lo = (ra > 0.f) ? fmaxf(lo, x) : lo;
-                                        hi = (ra < 0.f) ? fminf(hi, x) : hi;
-                                        ok = ok && (ra != 0.f || bb <= 0.f);
-                                    };
-                                    bound(a1, r1, tau - l1);
-                                    bound(a2, r2, tau - l2);
-                                    bound(a0, r0, tau - ((1.0f - l1) - l2));
-                                    bound(a3, r3, -lim - t0);
-                                    bound(a4, r4, t0 - lim);
-                                    certain |= ok && hi - lo >= 2e-3f;
-                                    l1 += d1w;
-                                    l2 += d2w;
-                                    t0 += tw;
-                                }
-                            }
-                            if (certain) {
-                                keep = false;
-                                const uint32_t ox = qx >> p.ss_shift, oy = qy >> p.ss_shift, oz = qz >> p.ss_shift;
-                                uint32_t brick;
-                                const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
-                                p.occgrid[cell] = 1;      // (plain stores; benign races: every writer stores the same value)
-                                p.dirty_max[brick] = 1;
-                            }
-                        }
-                        if (keep) {
-                            // the job record: position, tile slot, the planes of this voxel the leaf does not pass whole
-                            const bool small = (s_tcount[kk] >> 31) != 0u;
-                            Piece<false> leaf;
-                            leaf.a = v0;
-                            leaf.b = v1;
-                            leaf.c = v2;
-                            uint32_t cf0, out_unused, near_unused;
-                            piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused, near_unused);
-                            rec = make_uint2(qx | (qy << 16), qz | (kk << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u) | ((s_tcount[kk] & 0x40000000u) << 1));
-                            heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
-                        }
+                    for (uint32_t j = 0; j < kPerLane; ++j) {
+                        const uint32_t q = base + j * kVoxBlock + threadIdx.x;
+                        ok[j] = q < n_surv;
+                        rec[j] = ok[j] ? (q < n_heavy ? jobs_front[q] : jobs_back[-(int32_t) (q - n_heavy)]) : make_uint2(0u, 0u);
                     }
-                    if (!UV && occ_only) {
-                        const unsigned long long mc = __ballot(certain);
-                        if (mc && lane == 0) atomicAdd(&s_certain, (uint32_t) __popcll(mc));
+#pragma unroll
+                    for (uint32_t j = 0; j < kPerLane; ++j) {
+                        uint32_t brick;
+                        const uint64_t cell = cell_index((rec[j].x & 0xffffu) >> p.ss_shift, (rec[j].x >> 16) >> p.ss_shift,
+                                                         ((rec[j].y & 0xffffu) >> p.ss_shift) - p.zo0, p, brick);
+                        seen[j] = ok[j] ? __hip_atomic_load(&p.occgrid[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t) 1;
                     }
-                    const unsigned long long mh = __ballot(keep && heavy), ml = __ballot(keep && !heavy);
-                    if (mh | ml) {
-                        uint32_t base_h = 0, base_l = 0;
-                        if (lane == 0) {
-                            if (mh) base_h = atomicAdd(&s_nheavy, (uint32_t) __popcll(mh));
-                            if (ml) base_l = atomicAdd(&s_nlight, (uint32_t) __popcll(ml));
-                        }
-                        base_h = __shfl(base_h, 0, 64);
-                        base_l = __shfl(base_l, 0, 64);
-                        if (keep) {
-                            const uint32_t at = heavy ? base_h + __builtin_amdgcn_mbcnt_hi((uint32_t) (mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mh, 0u))
-                                                      : kQueueCap - 1u - (base_l + __builtin_amdgcn_mbcnt_hi((uint32_t) (ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) ml, 0u)));
-                            jobq[at] = rec;
+#pragma unroll
+                    for (uint32_t j = 0; j < kPerLane; ++j) {
+                        const bool keep = ok[j] && seen[j] == 0;
+                        const unsigned long long mk = __ballot(keep);
+                        if (mk) {
+                            uint32_t at = 0;
+                            if (lane == 0) at = atomicAdd(&s_nlive, (uint32_t) __popcll(mk));
+                            at = __shfl(at, 0, 64);
+                            if (keep) live[at + __builtin_amdgcn_mbcnt_hi((uint32_t) (mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mk, 0u))] = rec[j];
                         }
                     }
                 }
+                __syncthreads();
+                if (threadIdx.x == 0 && n_surv != s_nlive) s_skipped += n_surv - s_nlive;
+                n_surv = s_nlive;
+                n_heavy = n_surv;  // (the compacted list is served front to back)
+                jobs_front = live;
             }
-            __syncthreads();  // (workgroup scope: the records written above are visible to every wavefront of the workgroup)
-            const uint32_t n_heavy = s_nheavy, n_surv = n_heavy + s_nlight;
-            if (threadIdx.x == 0 && n_surv) atomicAdd(&c->n_jobs, (unsigned long long) n_surv);
+#endif
 
             O2V_LAP(2);
             // ---- phase 2: persistent lanes ------------------------------------------------------------------
@@ -952,7 +1225,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 const uint32_t q = atomicAdd(&s_next, 1u);
                 next_valid = q < n_surv;
                 if (next_valid) {
-                    const uint2 *src = jobq + (q < n_heavy ? q : kQueueCap - 1u - (q - n_heavy));
+                    const uint2 *src = q < n_heavy ? jobs_front + q : jobs_back - (q - n_heavy);
                     // (LDS address = the wave-uniform base + 4 x lane)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) &src->x,
                                                      (__attribute__((address_space(3))) void *) &s_next_x[threadIdx.x & ~63u], 4, 0, 0);
@@ -972,11 +1245,24 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
             auto flush_results = [&]() {
                 const unsigned long long all = __ballot(d_valid);
                 if (!all) return;
+                if (OCC) {
+                    // occupancy only: the voxel is hit, nothing else about it matters (plain stores; benign races: every writer
+                    // stores the same value)
+                    if (d_valid) {
+                        const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
+                        uint32_t brick;
+                        const uint64_t cell = cell_index(d_px >> p.ss_shift, d_py >> p.ss_shift, (d_pz >> p.ss_shift) - p.zo0, p, brick);
+                        p.occgrid[cell] = 1;
+                        p.dirty_max[brick] = 1;
+                    }
+                    if (lane == 0) atomicAdd(&s_hits, (uint32_t) __popcll(all));
+                    d_valid = false;
+                    return;
+                }
                 // Direct MAX path: a hit of an unsplit triangle (order key 0: its only leaf) is the triangle's whole weight in
                 // this (sub-)voxel, so it competes at once - one 64-bit atomic max on the cell, no hit record.  Hits of
                 // subdivided triangles still go through the pool (their leaves' weights must be added up in order first).
-                // (occupancy-only mode: any hit marks the voxel, also those of subdivided triangles)
-                const bool direct = d_valid && use_direct && (occ_only || s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u);
+                const bool direct = d_valid && use_direct && s_leaf[(d_zk >> 16) * kLeafStride + 19] == 0u;
                 // The cell's counter hands out the hit's rank.  The first kInlineHits hits of a cell (by rank) go straight into
                 // the slab of the cell's brick (Params::brick_slab: listed before this kernel by k_mark_bricks / k_scan_flags) -
                 // they never see the pool, the scatter or a second copy: the random writes of the counting sort happen here,
@@ -1020,13 +1306,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                 const uint32_t mine = chunk_base + chunk_used + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
                 chunk_used += cnt;
                 if (d_valid) {
-                    if (direct && occ_only) {
-                        // occupancy only: the voxel is hit, nothing else about it matters (plain stores; benign races: every
-                        // writer stores the same value)
-                        p.occgrid[cell] = 1;
-                        p.dirty_max[brick] = 1;
-                    }
-                    else if (direct) {
+                    if (direct) {
                         atomicMax(&p.maxgrid[cell], ((unsigned long long) __float_as_uint(d_w) << 32) | (0xffffffffu - keyhi));
                         p.dirty_max[brick] = 1;  // benign race: every writer stores the same value
                         if (UV && mine < p.cap_hits) {
@@ -1111,7 +1391,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             cur.tc = {__uint_as_float(lf[16]), __uint_as_float(lf[17])};
                         }
                         area = __uint_as_float(lf[23]);
-                        margin = s_margin[my_k];
+                        margin = out_margin(s_mcoord[my_k]);
                         w = 0.f;
                         u = 0.f;
                         v = 0.f;
@@ -1223,7 +1503,7 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
                             cur = sel_piece<UV>(s_takes_over, sec, cur);
                             cf = s_takes_over ? s_fail : c_fail;
                             active = s_takes_over || !c_over;
-                            if (!UV && occ_only && (c_kept | s_kept_n) != 0u) {
+                            if (OCC && (c_kept | s_kept_n) != 0u) {
                                 // a piece survived: the voxel is hit, the rest of the job cannot change that
                                 active = false;
                                 sp = 0;
@@ -1250,17 +1530,42 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
         if (chunk_used != kHitChunk && chunk_base + k < p.cap_hits) pool[chunk_base + k].brick = kHoleBrick;
 #ifdef O2V_INSTRUMENT
     tmr[3] = __builtin_readcyclecounter() - t_kernel0;
-    for (uint32_t k = 0; k < 12; ++k) {
+    for (uint32_t k = 0; k < 9; ++k) {
         uint32_t t = dbgc[k];
         for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
         if (lane == 0 && t) atomicAdd(&c->dbg[k], (unsigned long long) t);
     }
     if (lane == 0)
         for (uint32_t k = 0; k < 4; ++k) atomicAdd(&c->dbg[12 + k], tmr[k]);  // summed over the wavefronts
+    if (lane == 0) {  // (phase 1's inside: reported in the slots of the last three cut events)
+        atomicAdd(&c->dbg[9], t_drain);
+        atomicAdd(&c->dbg[10], (unsigned long long) n_drain);
+        atomicAdd(&c->dbg[11], (unsigned long long) n_drain_lanes);
+    }
 #endif
     __syncthreads();
     // (a certain hit is a hit, a direct one, and a voxel job that did not have to run)
     if (threadIdx.x == 0 && (s_hits | s_certain)) atomicAdd(&c->n_hits, (unsigned long long) s_hits + s_certain);
-    if (threadIdx.x == 0 && (s_direct | s_certain)) atomicAdd(&c->n_direct, (unsigned long long) s_direct + s_certain);
+    // (occupancy only: every hit is a direct one)
+    if (threadIdx.x == 0 && OCC && (s_hits | s_certain)) atomicAdd(&c->n_direct, (unsigned long long) s_hits + s_certain);
+    if (threadIdx.x == 0 && !OCC && s_direct) atomicAdd(&c->n_direct, (unsigned long long) s_direct);
     if (threadIdx.x == 0 && s_certain) atomicAdd(&c->n_certain, (unsigned long long) s_certain);
+    if (threadIdx.x == 0 && s_skipped) atomicAdd(&c->n_jobs_skipped, (unsigned long long) s_skipped);
+}
+
+// The clip kernel of the weighted routes (UV: the mesh has textured triangles) ...
+template <bool UV>
+__global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2_WAVES)) void k_voxelize(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+                                                     Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
+                                                     uint2 *jobq_all, Params p)
+{
+    voxelize_body<UV, false>(leaves, tiles, c, grid, brick_dirty, pool, jobq_all, p);
+}
+// ... and of occupancy-only mode (Params::occupancy_only: no triangle of the mesh has a material).  Its job queues are twice
+// as long: the second half holds the jobs that are left when the voxels marked already have been taken out.
+__global__ __launch_bounds__(VoxShape<false>::block, O2V_K2_WAVES) void k_voxelize_occ(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
+                                                     Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
+                                                     uint2 *jobq_all, Params p)
+{
+    voxelize_body<false, true>(leaves, tiles, c, grid, brick_dirty, pool, jobq_all, p);
 }

@@ -367,6 +367,11 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
             O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
                                ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
+        else if (p.occupancy_only) {
+            const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
+            O2V_LAUNCH("k_voxelize_occ", s, k_voxelize_occ, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+        }
         else {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
             O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
@@ -1059,7 +1064,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     }
     if (ctx->n_tris == 0) return O2V_HIP_OK;  // empty mesh: empty model (obj2voxel.cpp:590-594)
     if (!ctx->d_jobq)
-        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) (O2V_K2_WAVES > O2V_K2_WAVES_UV ? O2V_K2_WAVES : O2V_K2_WAVES_UV) * (kBlock / 64u) * (64u * 64u) * sizeof(uint2)));  // = workgroups x VoxShape::queue for every shape
+        O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_jobq), (size_t) ctx->num_cus * (size_t) (O2V_K2_WAVES > O2V_K2_WAVES_UV ? O2V_K2_WAVES : O2V_K2_WAVES_UV) * (kBlock / 64u) * (64u * 64u) * sizeof(uint2) * 2u));  // = workgroups x VoxShape::queue for every shape; twice that for k_voxelize_occ
 
     // initial capacities; every counter keeps counting past its capacity so one re-run sizes it exactly
     uint64_t want_leaves = std::max<uint64_t>(ctx->cap_leaves, ctx->n_tris + ctx->n_tris / 4 + (1u << 16));
@@ -1259,6 +1264,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->stats.direct_hits = h.n_direct;
             ctx->stats.jobs = h.n_jobs;
             ctx->stats.certain_hits = h.n_certain;
+            ctx->stats.skipped_jobs = h.n_jobs_skipped;
             ctx->stats.bricks = p.n_bricks;
             ctx->stats.dirty_bricks = direct ? h.n_dirty_max : h.n_dirty;
             ctx->stats.pool_slots = h.n_hits_reserved;

@@ -67,7 +67,9 @@ def test_config2_dragon_standin_1024_materialless_max(dv, all_cores):
     dv.set_triangles(v)
     got = dv.voxelize(1024)
     st = dv.stats()
-    assert st["direct_hits"] == st["hits"] > 12_000_000
+    # (occupancy-only mode: a voxel job whose voxel is marked already is not run, so only the hits that had to be established
+    # are counted - how many depends on the order the workgroups ran in)
+    assert st["direct_hits"] == st["hits"] and 12_054_853 <= st["hits"] + st["skipped_jobs"] <= st["certain_hits"] + st["jobs"]
     _equal(got, all_cores.voxelize(v, 1024))
     assert len(got) == 4_936_186
 
@@ -141,7 +143,7 @@ def test_config4_50m_sphere_4096_eight_planned_slabs(dv, all_cores):
     hits, leaves, total = [], [], 0
     for r in range(n):
         got = meshes.sorted_voxels(d.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd))
-        hits.append(d.stats()["hits"])
+        hits.append(d.stats()["hits"] + d.stats()["skipped_jobs"])   # (skipped: jobs of voxels that were marked already)
         leaves.append(d.stats()["leaves"])
         # `want` is sorted by (z, y, x): a slab is one contiguous run of it
         lo, hi = np.searchsorted(want[:, 2], [cuts[r], cuts[r + 1]])

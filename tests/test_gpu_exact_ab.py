@@ -73,7 +73,9 @@ def test_fast_equals_exact(oracle, name, kind, T, res, ss, strategy, materials, 
         st_exact = d.stats()
         # the switch really changes the kernel's work: without the row test every candidate of the AABBs is a job candidate
         assert st_exact["jobs"] > st_fast["jobs"], (st_fast, st_exact)
-        assert st_fast["hits"] == st_exact["hits"], (name, st_fast["hits"], st_exact["hits"])
+        # (occupancy-only mode - the fast side of a mesh without materials - does not run the jobs of voxels that are marked
+        # already, so it counts fewer hits, by at most the jobs it skipped)
+        assert st_fast["hits"] <= st_exact["hits"] <= st_fast["hits"] + st_fast["skipped_jobs"], (name, st_fast, st_exact)
         assert len(fast) > (1_000_000 if T >= 1_000_000 else 200_000), len(fast)
         assert fast.shape == exact.shape, (name, fast.shape, exact.shape)
         assert np.array_equal(fast, exact), name

@@ -63,7 +63,7 @@ def test_group_union_equals_single_gpu_and_oracle(oracle, n_ranks, upload):
         whole = meshes.sorted_voxels(single.voxelize(160))
         assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), whole)
         assert np.array_equal(whole, meshes.sorted_voxels(oracle.voxelize(v, 160)))
-        hits = [d.stats()["hits"] for d in g.ranks]
+        hits = [d.stats()["hits"] + d.stats()["skipped_jobs"] for d in g.ranks]
         assert max(hits) < 1.15 * sum(hits) / n_ranks, (cuts, hits)      # the plan balances the work
         tm = g.ranks[0].timings()
         assert tm["plan_ms"] > 0 and tm["collective_ms"] > 0

@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from obj2voxel_amd import hip, workloads  # noqa: E402
 
 NAMES = ["wave_iterations", "lane_events", "acc_passes_all(event)", "whole_keep(event)", "iterations with <= 16 active lanes",
-         "whole_discard(event)", "iterations with <= 32 active lanes", "cut(event)", "cut: first piece final (incl. settled)", "cut: first piece settled by its single plane",
-         "cut: second piece final (incl. settled)", "cut: second piece settled by its single plane", "cycles: staging + barriers (sum over waves)", "cycles: phase 2 loop",
+         "whole_discard(event)", "iterations with <= 32 active lanes", "cut(event)", "cut: first piece final (incl. settled)", "cycles: phase 1 inside file_survivor (sum over waves)",
+         "phase 1: groups of survivors taken from the ring", "phase 1: survivors taken from the ring", "cycles: staging + barriers (sum over waves)", "cycles: phase 2 loop",
          "cycles: phase 1", "cycles: whole kernel"]
 for name in (sys.argv[1:] or ["config2"]):
     verts, mat, textures, res, kw, text = workloads.load(name)

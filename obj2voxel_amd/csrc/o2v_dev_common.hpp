@@ -125,6 +125,7 @@ struct Counters {
     unsigned long long n_certain;   // occupancy-only mode: hits established without a voxel job (certain_prepare)
     unsigned long long n_jobs;      // candidate voxels that passed phase 1 of k_voxelize (= voxel jobs of phase 2)
     unsigned long long n_jobs_skipped;  // occupancy-only mode: jobs dropped before phase 2 because their voxel was marked already
+    unsigned long long n_bypass;        // Params::root_bypass: root triangles that k_voxelize_occ stages itself (no Leaf, no Tile)
     unsigned long long dbg[16];  // event counts of an instrumented build (-DO2V_INSTRUMENT, tools/instrument.sh); else zero
 };
 
@@ -156,6 +157,9 @@ struct Params {
     // picks one white, BLEND computes (w1 * 1 + w2 * 1) / (w1 + w2) = s / s = 1 exactly) and only the set of voxels with a
     // non-zero weight matters: a voxel job ends at its first surviving piece and every hit takes the direct path.
     uint32_t occupancy_only;
+    // Occupancy-only mode: a root triangle that is one leaf of one tile (the usual triangle of a tessellated surface) gets no
+    // Leaf and no Tile record; k_voxelize_occ makes its leaf from the vertex array (k_expand_roots only counts it).
+    uint32_t root_bypass;
     uint32_t exact_clip;   // O2V_HIP_FLAG_EXACT_CLIP: no work-removal shortcuts in k_voxelize (every leaf is treated as not `small`)
     // Direct MAX path (MAX strategy, no textured triangle; section 4 of DESIGN.md): one 64-bit cell per output voxel that
     // holds max over {weight bits << 32 | ~(sub-voxel << 29 | triangle)}, and its own dirty-brick map.

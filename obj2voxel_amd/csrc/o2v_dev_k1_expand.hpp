@@ -201,6 +201,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
     __shared__ float s_v[kBlock * 9];
     __shared__ float s_t[kBlock * 6];
     __shared__ unsigned long long s_cand;
+    __shared__ unsigned long long s_bypass[2];  // Params::root_bypass: this workgroup's bypassed triangles and their candidates
+    unsigned long long my_bypass = 0, my_bypass_cand = 0;
+    if (threadIdx.x < 2) s_bypass[threadIdx.x] = 0;
 
     Affine xf;
     xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
@@ -263,9 +266,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
 
     // stages sub-batch `blk` (prefetching `next`) and classifies this lane's triangle of it; false if the whole
     // sub-batch is skipped
-    auto classify = [&](uint64_t blk, uint64_t next, Sub &s, Emit &e, LeafPlan &pl, float &area, bool &as_leaf, bool &as_node) -> bool {
+    auto classify = [&](uint64_t blk, uint64_t next, Sub &s, Emit &e, LeafPlan &pl, float &area, bool &as_leaf, bool &as_node, bool &bypassed) -> bool {
         e = Emit{0, 0, 0, 0};
-        as_leaf = as_node = false;
+        as_leaf = as_node = bypassed = false;
         if (skipped(blk)) return false;
         if (pre_blk != blk) prefetch(blk);
         const uint64_t base = blk * kBlock;
@@ -297,6 +300,9 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
             if (pl.count >> 32) {
                 atomicOr(&c->err_flags, kErrLeafTooLarge);
             }
+            else if (p.root_bypass && pl.ntiles == 1u) {
+                bypassed = true;  // k_voxelize_occ makes this leaf itself, by the same rules (root_leaf_of_one_tile)
+            }
             else if (pl.ntiles) {
                 as_leaf = true;
                 e.n_leaf = 1;
@@ -316,12 +322,16 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         Emit e{0, 0, 0, 0}, sum{0, 0, 0, 0};
         LeafPlan pl{};
         float area = 0;
-        bool as_leaf = false, as_node = false;
+        bool as_leaf = false, as_node = false, bypassed = false;
         // pass 1: what this lane's (up to) four triangles emit
         for (uint32_t k = 0; k < kRootBatch; ++k) {
             const uint64_t at = sblk * kRootBatch + k, blk = block_at(at);
             // after the last sub-batch of this pass comes the first one again (pass 2)
-            classify(blk, block_at(k + 1 < kRootBatch ? at + 1 : sblk * kRootBatch), s, e, pl, area, as_leaf, as_node);
+            classify(blk, block_at(k + 1 < kRootBatch ? at + 1 : sblk * kRootBatch), s, e, pl, area, as_leaf, as_node, bypassed);
+            if (bypassed) {
+                my_bypass += 1;
+                my_bypass_cand += pl.count;
+            }
             sum.n_leaf += e.n_leaf;
             sum.n_tile += e.n_tile;
             sum.n_big += e.n_big;
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
             const uint64_t at = sblk * kRootBatch + k, blk = block_at(at);
             // ... and after the last one of pass 2 the first sub-batch of this workgroup's next super-block
             const uint64_t next = block_at(k + 1 < kRootBatch ? at + 1 : (sblk + gridDim.x) * kRootBatch);
-            if (!classify(blk, next, s, e, pl, area, as_leaf, as_node)) continue;
+            if (!classify(blk, next, s, e, pl, area, as_leaf, as_node, bypassed)) continue;
             const uint32_t tri = (uint32_t) (blk * kBlock + threadIdx.x);
             if (as_leaf) {
                 if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, tri, 0u, area, pl);
@@ -367,6 +377,30 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         __syncthreads();
         if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
     }
+    if (p.root_bypass) {
+        // (one pair of global atomics per workgroup, not per super-block: they serialise at ~88 per us)
+        __syncthreads();
+        if (my_bypass) {
+            atomicAdd(&s_bypass[0], my_bypass);
+            atomicAdd(&s_bypass[1], my_bypass_cand);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_bypass[0]) {
+            atomicAdd(&c->n_bypass, s_bypass[0]);
+            atomicAdd(&c->n_candidates, s_bypass[1]);
+        }
+    }
+}
+
+// Params::root_bypass: the root triangles k_expand_roots leaves to k_voxelize_occ - those that are voxelized as they are
+// (voxelization.cpp:488-511: roughly axis-aligned, or a voxel AABB of fewer than 512 cells), touch the slab and fit one tile.
+// The same sequence of tests as k_expand_roots' classify(), on the same transformed vertices: both kernels decide alike.
+__device__ __forceinline__ bool root_leaf_of_one_tile(const Sub &s, const Params &p, LeafPlan &pl)
+{
+    if (misses_slab(s, p)) return false;
+    if (!(roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit)) return false;
+    pl = plan_leaf(s, p);
+    return !(pl.count >> 32) && pl.ntiles == 1u;
 }
 
 

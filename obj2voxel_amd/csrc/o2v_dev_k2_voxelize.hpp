@@ -313,112 +313,6 @@ __device__ __forceinline__ uint32_t row_span(V3 p0, V3 p1, V3 p2, float cy, floa
 }
 
 
-// The same test with everything that does not depend on the row taken out of it ("tile mode" of phase 1: a lane owns a tile
-// and walks its rows).  Every axis' interval of admissible x is linear in the row's (cy, cz): for the axis y x E the two
-// projections au, aw of row_clip_edge differ by a constant, so which one is the larger is a property of the leaf, and the
-// interval is [yl, yu] + ys cz with three numbers per edge; likewise z x E with cy, the plane axis with both, and the axes
-// x x E reject a row iff a linear form of (cy, cz) leaves [rlo, rhi].  Same inflation, radii, error bound of the plane axis and
-// slack as row_span; the products are grouped differently (and fused), which moves an interval's end by a few ulp of the
-// extent - four orders of magnitude below the 0.02-voxel inflation and the 0.01-voxel slack.  Infinite bounds switch an axis
-// off (a NaN anywhere compares false / is ignored by fmaxf and fminf: it rejects nothing).  34 registers per lane against
-// ~300 instructions per row.  Not reference arithmetic.
-struct RowPlan {
-    float ra[3], rb[3], rhi[3], rlo[3];                  // x x E_i: lin = ra cy + rb cz must stay within [rlo, rhi]
-    float yl[3], yu[3], ys[3], zl[3], zu[3], zs[3];      // y x E_i: [yl, yu] + ys cz;  z x E_i: [zl, zu] + zs cy
-    float pc, py, pz, pw;                                // plane axis: centre pc + py cy + pz cz, half width pw
-    __device__ __forceinline__ void edge(int i, V3 E, V3 U, V3 W, float slack, float h)
-    {
-        const float inf = __builtin_inff();
-        {
-            const float ku = E.z * U.y - E.y * U.z, kw = E.z * W.y - E.y * W.z;
-            const float rad = h * (abs_f(E.z) + abs_f(E.y));
-            ra[i] = -E.z;
-            rb[i] = E.y;
-            rhi[i] = rad - fminf(ku, kw);
-            rlo[i] = -rad - fmaxf(ku, kw);
-        }
-        {
-            const float gu = E.x * U.z - E.z * U.x, gw = E.x * W.z - E.z * W.x;
-            const float rad = h * (abs_f(E.x) + abs_f(E.z));
-            yl[i] = -inf;
-            yu[i] = inf;
-            ys[i] = 0.f;
-            if (abs_f(E.z) > 1e-20f) {
-                const float r = __builtin_amdgcn_rcpf(E.z);
-                const float a = (-rad - fmaxf(gu, gw)) * r, b = (rad - fminf(gu, gw)) * r;
-                yl[i] = fminf(a, b) - slack;
-                yu[i] = fmaxf(a, b) + slack;
-                ys[i] = E.x * r;
-            }
-        }
-        {
-            const float hu = E.y * U.x - E.x * U.y, hw = E.y * W.x - E.x * W.y;
-            const float rad = h * (abs_f(E.y) + abs_f(E.x));
-            zl[i] = -inf;
-            zu[i] = inf;
-            zs[i] = 0.f;
-            if (abs_f(E.y) > 1e-20f) {
-                const float r = __builtin_amdgcn_rcpf(-E.y);
-                const float a = (-rad - fmaxf(hu, hw)) * r, b = (rad - fminf(hu, hw)) * r;
-                zl[i] = fminf(a, b) - slack;
-                zu[i] = fmaxf(a, b) + slack;
-                zs[i] = -E.x * r;
-            }
-        }
-    }
-    // p0, p1, p2, extent, margin: as for row_span
-    __device__ __forceinline__ void prepare(V3 p0, V3 p1, V3 p2, float extent, float margin)
-    {
-        const float h = 0.5f + margin;
-        const float slack = 0.01f + 4e-6f * extent;
-        const V3 e0 = p1 - p0, e1 = p2 - p1, e2 = p0 - p2;
-        {
-            const V3 n = cross(e0, e1);
-            const float l0 = abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z), l1 = abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z);
-            const float far = extent + abs_f(p0.x) + abs_f(p0.y) + abs_f(p0.z);
-            const float rad = h * (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) + 1e-5f * l0 * l1 * (far + 1.0f);
-            pc = py = pz = 0.f;
-            pw = __builtin_inff();
-            if (abs_f(n.x) > 1e-20f) {
-                const float r = __builtin_amdgcn_rcpf(n.x);
-                pc = r * (n.x * p0.x + n.y * p0.y + n.z * p0.z);
-                py = -(r * n.y);
-                pz = -(r * n.z);
-                pw = rad * abs_f(r) + slack;
-            }
-        }
-        edge(0, e0, p0, p2, slack, h);
-        edge(1, e1, p1, p0, slack, h);
-        edge(2, e2, p2, p1, slack, h);
-    }
-    // the row at (cy, cz): the first admissible voxel of [xlo, xhi] and their number
-    __device__ __forceinline__ uint32_t span(float cy, float cz, uint32_t xlo, uint32_t xhi, uint32_t &first) const
-    {
-        float lo = (float) xlo + 0.5f, hi = (float) xhi + 0.5f;
-        bool any = true;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float lin = __builtin_fmaf(ra[i], cy, rb[i] * cz);
-            any = any && !(lin > rhi[i] || lin < rlo[i]);
-            lo = fmaxf(lo, __builtin_fmaf(ys[i], cz, yl[i]));
-            hi = fminf(hi, __builtin_fmaf(ys[i], cz, yu[i]));
-            lo = fmaxf(lo, __builtin_fmaf(zs[i], cy, zl[i]));
-            hi = fminf(hi, __builtin_fmaf(zs[i], cy, zu[i]));
-        }
-        const float c = __builtin_fmaf(py, cy, __builtin_fmaf(pz, cz, pc));
-        lo = fmaxf(lo, c - pw);
-        hi = fminf(hi, c + pw);
-        const float fa = ceilf(lo - 0.5f), fb = floorf(hi - 0.5f);
-        if (!any || !(fa <= fb)) {
-            first = xlo;
-            return 0u;
-        }
-        first = (uint32_t) fa;
-        return (uint32_t) fb - (uint32_t) fa + 1u;
-    }
-};
-
-
 // Early decisions about a piece from its bounding box (speed only, results unchanged).  For the planes in `planes` (bit =
 // level: lo x, y, z, hi x, y, z) of the voxel at (fx, fy, fz):
 //   fail  planes the piece does not pass whole.  A piece whose vertices all satisfy v >= plane (lo planes) or v < plane
@@ -656,7 +550,8 @@ __device__ __forceinline__ uint32_t vox_exscan(uint32_t v, uint32_t *s_wave /*[k
 template <bool UV, bool OCC>
 __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                               Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
-                                              uint2 *jobq_all, const Params &p)
+                                              uint2 *jobq_all, const Params &p, const float *__restrict__ verts = nullptr,
+                                              const uint32_t *__restrict__ block_list = nullptr, const uint32_t *block_count = nullptr)
 {
     static_assert(!(UV && OCC), "occupancy-only mode has no uv arithmetic");
     constexpr uint32_t kVoxBlock = VoxShape<UV>::block, kVoxTiles = VoxShape<UV>::tiles, kQueueCap = VoxShape<UV>::queue;
@@ -681,7 +576,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
     __shared__ uint2 s_ring[(kVoxBlock / 64) * kRing];
     __shared__ uint32_t s_trow0[kVoxTiles];       // first row (y + dy z of the leaf's AABB) the tile's candidates lie in
     __shared__ uint32_t s_rprefix[kVoxTiles + 6];  // rows before tile k (+ total + padding, as s_tprefix)
-    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct, s_certain, s_nlive, s_skipped, s_maxrows;
+    __shared__ uint32_t s_batch, s_nheavy, s_nlight, s_next, s_hits, s_direct, s_certain, s_nlive, s_skipped;
     // The job queue of this workgroup lives in global memory (it stays in L2): one 8-byte record per surviving candidate,
     // {x | y << 16, z | tile slot << 16 | plane mask << 24 | small << 30}.  Jobs whose leaf straddles many planes of their
     // voxel (the long ones) are filed from the front, the others from the back, and the queue is served front to back:
@@ -701,16 +596,30 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
     // large batches leave workgroups idle at the end of the kernel (and a 96^3 job, a few thousand tiles, would keep 3 %
     // of the machine busy); many small ones pay the per-batch staging and barriers too often.  Measured on seven
     // workload shapes.
-    uint32_t tiles_per_batch = (n_tiles + gridDim.x * kBatchesPerBlock - 1u) / (gridDim.x * kBatchesPerBlock);
+    // Params::root_bypass (occupancy only): the root triangles that are one leaf of one tile have no Leaf / Tile records;
+    // they are staged from the vertex array, a run of consecutive triangles per batch ("root batches", behind the batches of
+    // the tile list).  The sequence of blocks of 256 triangles is the one k_expand_roots walks: the listed blocks
+    // (k_list_blocks: those whose z extent meets the slab) or all of them.
+    const bool root_bypass = OCC && p.root_bypass != 0u;
+    const bool blocks_listed = root_bypass && block_list != nullptr && *block_count != 0xffffffffu;
+    const uint64_t n_seq_blocks = !root_bypass ? 0ull : (blocks_listed ? (uint64_t) *block_count : (p.n_tris + kTilesPerBatch - 1u) / kTilesPerBatch);
+    const uint64_t n_work = (uint64_t) n_tiles + n_seq_blocks * kTilesPerBatch;  // tiles + triangles that may become one
+    uint32_t tiles_per_batch = (uint32_t) std::min<uint64_t>((n_work + gridDim.x * kBatchesPerBlock - 1u) / (gridDim.x * kBatchesPerBlock), kVoxTiles);
     {
         // large jobs: half as many tiles again per workgroup's share, as long as a batch still fills the workgroup's lanes
         // twice over (shorter tail at the end of the kernel; measured -2 % on the bench mesh, -7 % on the low-poly sphere)
-        const uint32_t finer = (n_tiles + gridDim.x * kBatchesPerBlockLarge - 1u) / (gridDim.x * kBatchesPerBlockLarge);
-        if (finer >= kFinerBatchMinTiles) tiles_per_batch = finer;
+        const uint64_t finer = (n_work + gridDim.x * kBatchesPerBlockLarge - 1u) / (gridDim.x * kBatchesPerBlockLarge);
+        if (finer >= kFinerBatchMinTiles) tiles_per_batch = (uint32_t) std::min<uint64_t>(finer, kVoxTiles);
     }
     tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
                       : (tiles_per_batch > kVoxTiles ? kVoxTiles : tiles_per_batch);
-    const uint32_t n_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
+    const uint32_t n_list_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
+    // a root batch is 2^k consecutive triangles of one block (4 .. 256: the largest power of two a batch holds)
+    const uint32_t root_shift = 31u - (uint32_t) __clz((int) tiles_per_batch);
+    const uint32_t root_per_block_shift = 8u - root_shift;  // log2 of the root batches per block of 256 triangles
+    static_assert(kTilesPerBatch == 256u && kBlock == 256u, "blocks of 256 triangles");
+    const uint64_t n_root_batches64 = n_seq_blocks << root_per_block_shift;
+    const uint32_t n_batches = (uint32_t) std::min<uint64_t>((uint64_t) n_list_batches + n_root_batches64, 0xffffffffull);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
 #ifdef O2V_INSTRUMENT
@@ -740,27 +649,70 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
 
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            s_batch = atomicAdd(&c->batch_cursor, 1u);
-            s_maxrows = 0;
-        }
+        if (threadIdx.x == 0) s_batch = atomicAdd(&c->batch_cursor, 1u);
         __syncthreads();
         const uint32_t batch = s_batch;
         if (batch >= n_batches) break;
-        const uint32_t first = batch * tiles_per_batch;
-        const uint32_t nt = n_tiles - first < tiles_per_batch ? n_tiles - first : tiles_per_batch;
-        if (threadIdx.x < nt) {
-            const Tile t = tiles[first + threadIdx.x];
-            s_tleaf[threadIdx.x] = t.leaf;
-            s_tstart[threadIdx.x] = t.start;
+        uint32_t nt;
+        if (OCC && batch >= n_list_batches) {
+            // a root batch: the leaves are made here, from the vertex array, as k_expand_roots makes them (applyMeshTransform,
+            // obj2voxel.cpp:202-224; the head of voxelizeTriangleToUvBuffer, voxelization.cpp:488-511; write_leaf); a triangle
+            // that is not a leaf of one tile (k_expand_roots handled it, or it misses the slab) leaves its tile slot empty
+            const uint32_t rb = batch - n_list_batches;
+            const uint64_t seq = rb >> root_per_block_shift;
+            const uint64_t blk = blocks_listed ? (uint64_t) block_list[seq] : seq;
+            const uint64_t tri0 = blk * kTilesPerBatch + ((uint64_t) (rb & ((1u << root_per_block_shift) - 1u)) << root_shift);
+            nt = tri0 < p.n_tris ? (uint32_t) std::min<uint64_t>(1ull << root_shift, p.n_tris - tri0) : 0u;
+            // (coalesced: the batch's 9 nt floats as they lie in memory, then a lane picks its triangle's nine out of LDS)
+            for (uint32_t i = threadIdx.x; i < nt * 9u; i += kVoxBlock) s_leaf[i] = __float_as_uint(verts[tri0 * 9u + i]);
+            __syncthreads();
+            float q[9];
+#pragma unroll
+            for (uint32_t j = 0; j < 9; ++j) q[j] = threadIdx.x < nt ? __uint_as_float(s_leaf[threadIdx.x * 9u + j]) : 0.f;
+            __syncthreads();
+            if (threadIdx.x < nt) {
+                Affine xf;
+                xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
+                xf.m[1] = {c->xform[3], c->xform[4], c->xform[5]};
+                xf.m[2] = {c->xform[6], c->xform[7], c->xform[8]};
+                xf.t = {c->xform[9], c->xform[10], c->xform[11]};
+                Sub sb{};
+                sb.v0 = affine_apply(xf, V3{q[0], q[1], q[2]});
+                sb.v1 = affine_apply(xf, V3{q[3], q[4], q[5]});
+                sb.v2 = affine_apply(xf, V3{q[6], q[7], q[8]});
+                LeafPlan pl{};
+                const bool is_leaf = root_leaf_of_one_tile(sb, p, pl);
+                uint32_t *lw = &s_leaf[threadIdx.x * kLeafStride];
+                const V3 nrm = normalize(tri_normal(sb.v0, sb.v1, sb.v2));  // voxelization.cpp:438
+                const float vals[12] = {sb.v0.x, sb.v0.y, sb.v0.z, sb.v1.x, sb.v1.y, sb.v1.z, sb.v2.x, sb.v2.y, sb.v2.z, nrm.x, nrm.y, nrm.z};
+#pragma unroll
+                for (uint32_t j = 0; j < 12; ++j) lw[j] = is_leaf ? __float_as_uint(vals[j]) : 0u;
+                lw[18] = (uint32_t) (tri0 + threadIdx.x);
+                lw[19] = 0u;  // order key of an unsplit triangle
+                lw[20] = is_leaf ? pl.lo[0] | (pl.lo[1] << 16) : 0u;
+                lw[21] = is_leaf ? pl.lo[2] | (pl.d[0] << 16) : 0u;   // (an empty slot: a box of no cells)
+                lw[22] = is_leaf ? pl.d[1] | (pl.d[2] << 16) : 0u;
+                lw[23] = __float_as_uint(is_leaf ? tri_area(sb.v0, sb.v1, sb.v2) : 0.f);
+                s_tstart[threadIdx.x] = 0u;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // stage the leaves of this batch in LDS
-        for (uint32_t i = threadIdx.x; i < nt * 24u; i += kVoxBlock) {
-            const uint32_t k = i / 24u, j = i - k * 24u;
-            s_leaf[k * kLeafStride + j] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
+        else {
+            const uint32_t first = batch * tiles_per_batch;
+            nt = n_tiles - first < tiles_per_batch ? n_tiles - first : tiles_per_batch;
+            if (threadIdx.x < nt) {
+                const Tile t = tiles[first + threadIdx.x];
+                s_tleaf[threadIdx.x] = t.leaf;
+                s_tstart[threadIdx.x] = t.start;
+            }
+            __syncthreads();
+            // stage the leaves of this batch in LDS
+            for (uint32_t i = threadIdx.x; i < nt * 24u; i += kVoxBlock) {
+                const uint32_t k = i / 24u, j = i - k * 24u;
+                s_leaf[k * kLeafStride + j] = reinterpret_cast<const uint32_t *>(leaves + s_tleaf[k])[j];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         uint32_t my_count = 0, my_rows = 0;
         if (threadIdx.x < nt) {
             const uint32_t *lf = &s_leaf[threadIdx.x * kLeafStride];
@@ -807,7 +759,6 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                 const uint32_t r0 = start / dx;
                 s_trow0[threadIdx.x] = r0;
                 my_rows = (start + my_count - 1u) / dx - r0 + 1u;
-                atomicMax(&s_maxrows, my_rows);
             }
         }
         {
@@ -1012,58 +963,6 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                     ring_drain(64u);
                 }
             };
-#ifdef O2V_TILE_MODE
-            // Tile mode: many tiles of few rows each (a finely tessellated surface) - a lane owns a tile, works the row test's
-            // leaf-only part out once (RowPlan) and walks the tile's rows.  Taken when the tiles' row counts are even enough
-            // for the lanes to stay busy (at a third of the lanes it still issues fewer instructions than row mode); else, and
-            // for a batch of few tiles with many rows each, the rows are dealt out over all lanes (row mode, below).
-            const uint32_t n_sub = t_end - t_begin;
-            const bool tile_mode = !shared_rows && n_sub >= kVoxBlock / 4u && (uint64_t) s_maxrows * n_sub <= 3ull * n_rows;
-#else
-            const bool tile_mode = false;
-#endif
-            if (tile_mode) {
-                const uint32_t k = threadIdx.x;
-                const bool mine = k >= t_begin && k < t_end && my_count != 0u;
-                const uint32_t *lf = &s_leaf[k * kLeafStride];
-                const uint32_t dx = mine ? lf[21] >> 16 : 1u, dy = mine ? lf[22] & 0xffffu : 1u, dz = mine ? lf[22] >> 16 : 1u;
-                const uint32_t start = mine ? s_tstart[k] : 0u, row0 = mine ? s_trow0[k] : 0u;
-                const uint32_t rows_mine = mine ? my_rows : 0u;
-                const bool small = mine && (s_tcount[k] >> 31) != 0u;
-                RowPlan rp;
-                if (small) {
-                    const float ox = (float) (lf[20] & 0xffffu), oy = (float) (lf[20] >> 16), oz = (float) (lf[21] & 0xffffu);
-                    const V3 p0{__uint_as_float(lf[0]) - ox, __uint_as_float(lf[1]) - oy, __uint_as_float(lf[2]) - oz};
-                    const V3 p1{__uint_as_float(lf[3]) - ox, __uint_as_float(lf[4]) - oy, __uint_as_float(lf[5]) - oz};
-                    const V3 p2{__uint_as_float(lf[6]) - ox, __uint_as_float(lf[7]) - oy, __uint_as_float(lf[8]) - oz};
-                    rp.prepare(p0, p1, p2, (float) (dx + dy + dz), sat_margin(s_mcoord[k]));
-                }
-                uint32_t lz = row0 / dy, ly = row0 - lz * dy;
-                const uint32_t first_x = start - row0 * dx;                                      // the tile's first candidate in its first row
-                const uint32_t last_x = (start + my_count - 1u) - (row0 + rows_mine - 1u) * dx;  // ... and its last one in its last row
-                uint32_t max_rows = rows_mine;
-#pragma unroll
-                for (uint32_t d = 32; d >= 1; d >>= 1) {
-                    const uint32_t o = __shfl_xor(max_rows, d, 64);
-                    max_rows = o > max_rows ? o : max_rows;
-                }
-                for (uint32_t r = 0; r < max_rows; ++r) {
-                    uint32_t n_out = 0, x_first = 0;
-                    if (r < rows_mine) {
-                        const uint32_t xlo = r == 0u ? first_x : 0u, xhi = r + 1u == rows_mine ? last_x : dx - 1u;
-                        x_first = xlo;
-                        n_out = xhi - xlo + 1u;
-                        if (small) n_out = rp.span((float) ly + 0.5f, (float) lz + 0.5f, xlo, xhi, x_first);
-                    }
-                    ring_push(n_out, x_first | (k << 16), ly | (lz << 16));
-                    ly += 1u;
-                    if (ly == dy) {
-                        ly = 0u;
-                        lz += 1u;
-                    }
-                }
-            }
-            else
             for (uint32_t g0 = shared_rows ? 0u : wave * 64u; g0 < n_rows; g0 += shared_rows ? 64u : kVoxBlock) {
                 const uint32_t g = g0 + lane;
                 uint32_t k = s_chunk_tile[g0 / 64u];
@@ -1565,7 +1464,8 @@ __global__ __launch_bounds__(VoxShape<UV>::block, (UV ? O2V_K2_WAVES_UV : O2V_K2
 // as long: the second half holds the jobs that are left when the voxels marked already have been taken out.
 __global__ __launch_bounds__(VoxShape<false>::block, O2V_K2_WAVES) void k_voxelize_occ(const Leaf *__restrict__ leaves, const Tile *__restrict__ tiles,
                                                      Counters *c, uint32_t *grid, uint8_t *brick_dirty, HitRec *pool,
-                                                     uint2 *jobq_all, Params p)
+                                                     uint2 *jobq_all, const float *__restrict__ verts, const uint32_t *__restrict__ block_list,
+                                                     const uint32_t *block_count, Params p)
 {
-    voxelize_body<false, true>(leaves, tiles, c, grid, brick_dirty, pool, jobq_all, p);
+    voxelize_body<false, true>(leaves, tiles, c, grid, brick_dirty, pool, jobq_all, p, verts, block_list, block_count);
 }

@@ -370,7 +370,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         else if (p.occupancy_only) {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
             O2V_LAUNCH("k_voxelize_occ", s, k_voxelize_occ, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, ctx->d_verts, block_list, ctx->d_block_count, p);
         }
         else {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
@@ -986,6 +986,10 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     ctx->stats.grid_bytes = 0;
     const uint64_t brick_cap_want = (n_bricks + 15u) & ~15ull;
     p.occupancy_only = modes.occupancy_only ? 1u : 0u;
+    {
+        const char *no_bypass = std::getenv("O2V_NO_ROOT_BYPASS");  // (A/B: every leaf through its Leaf / Tile records)
+        p.root_bypass = (modes.occupancy_only && !(no_bypass && no_bypass[0] == '1')) ? 1u : 0u;
+    }
     p.direct_max = modes.direct_max ? 1u : 0u;
     p.pick_max = (p.direct_max && use_uv) ? 1u : 0u;  // textured: the winner's colour is picked afterwards (k_pick)
     p.mat = Materials{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
@@ -1016,6 +1020,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
                 p.direct_max = 0;
                 p.pick_max = 0;
                 p.occupancy_only = 0;
+                p.root_bypass = 0;
             }
             else {
                 ctx->maxgrid_bytes = want_bytes;
@@ -1256,8 +1261,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             const uint64_t n_final = direct ? h.n_out : h.n_vox;
             ctx->last_direct = direct;
             ctx->n_vox = n_final;
-            ctx->stats.leaves = h.n_leaves;
-            ctx->stats.tiles = h.n_tiles;
+            ctx->stats.leaves = h.n_leaves + h.n_bypass;  // (root_bypass: leaves of one tile that k_voxelize_occ made itself)
+            ctx->stats.tiles = h.n_tiles + h.n_bypass;
             ctx->stats.candidates = h.n_candidates;
             ctx->stats.hits = h.n_hits;
             ctx->stats.voxels = n_final;

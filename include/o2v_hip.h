@@ -107,6 +107,8 @@ typedef struct {
                              phase 2 of their batch began (which ones depends on the order the workgroups happen to run in, so
                              this number and `hits` - only hits that were established are counted - vary from run to run;
                              the voxels do not) */
+    uint64_t bypassed_leaves; /* occupancy-only mode: those of `leaves` (and `tiles`) that have no Leaf / Tile record - root triangles
+                                 of one tile, which the clip kernel stages from the vertex array itself */
 } o2v_hip_stats;
 
 int o2v_hip_device_count(void);

@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <string>
 #include <vector>
@@ -370,17 +371,29 @@ struct Session {
     // Page-locking the two read-back buffers takes ~2 ms: a new session does it on a thread of its own while the triangle
     // source is drained (wait_for_pinned() before the first use).
     std::thread pinning;
-    void start_pinning()
+    void pin_now()
     {
         // (on the session's first device: a new thread's current device is device 0, which this process may not be meant to touch)
-        pinning = std::thread{[this] {
-            for (uint32_t *&p : pinned) p = static_cast<uint32_t *>(o2v_hip_alloc_pinned_on(devices[0], kReadBackBatch * 16));
-            pinned_records = pinned[0] && pinned[1] ? kReadBackBatch : 0;
-        }};
+        for (uint32_t *&p : pinned)
+            if (!p) p = static_cast<uint32_t *>(o2v_hip_alloc_pinned_on(devices[0], kReadBackBatch * 16));
+        pinned_records = pinned[0] && pinned[1] ? kReadBackBatch : 0;
     }
-    void wait_for_pinned()
+    void start_pinning()
+    {
+        try {
+            pinning = std::thread{[this] { pin_now(); }};
+        }
+        catch (const std::system_error &) {
+            // (no thread to be had: the buffers are made when they are first needed, wait_for_pinned)
+        }
+    }
+    // true if both read-back buffers exist; a session whose buffers could not be made earlier (by the thread, or because the
+    // host was short of lockable memory at that time) tries again, here, every time they are needed
+    bool wait_for_pinned()
     {
         if (pinning.joinable()) pinning.join();
+        if (!pinned_records) pin_now();
+        return pinned_records != 0;
     }
 
     uint32_t ranks() const { return group ? o2v_hip_group_size(group) : 1u; }
@@ -388,7 +401,7 @@ struct Session {
     const char *last_error() const { return group ? o2v_hip_group_last_error(group) : o2v_hip_last_error(ctx); }
     ~Session()
     {
-        wait_for_pinned();
+        if (pinning.joinable()) pinning.join();
         for (uint32_t *p : pinned)
             if (p) o2v_hip_free_pinned(p);
         if (group) o2v_hip_group_destroy(group);
@@ -554,8 +567,12 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session,
             const Batch &b = batches[k];
             return o2v_hip_read_voxels_async(session->rank_ctx(b.rank), session->pinned[k & 1], b.first, b.n) == O2V_HIP_OK;
         };
-        session->wait_for_pinned();
-        if (!session->pinned_records) return device_error("allocating read-back staging failed");
+        if (!session->wait_for_pinned()) return device_error("allocating read-back staging failed");
+        {
+            uint64_t total = 0;
+            for (uint64_t cnt : counts) total += cnt;
+            inst.sink->expect(total);
+        }
         if (!batches.empty() && !start_read(0)) return device_error("reading voxels failed");
         for (size_t k = 0; k < batches.size(); ++k) {
             if (!inst.sink->can_write()) break;
@@ -922,10 +939,10 @@ const obj2voxel_byte_t *obj2voxel_get_output_memory(obj2voxel_instance *instance
     O2V_ASSERT(instance->sink != nullptr || instance->output_kind != IoKind::MEMORY,
                "accessing output memory before voxelization");
     if (instance->output_kind != IoKind::MEMORY) return nullptr;
-    const std::vector<uint8_t> *bytes = instance->sink->memory();
+    const ByteBuffer *bytes = instance->sink->memory();
     O2V_ASSERT(bytes != nullptr, "memory sink without buffer");
-    *out_size = bytes->size();
-    return bytes->data();
+    *out_size = bytes->size;
+    return bytes->bytes;
 }
 
 void obj2voxel_set_triangle_basic(obj2voxel_triangle *triangle, const float vertices[9])

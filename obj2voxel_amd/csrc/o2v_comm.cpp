@@ -6,9 +6,14 @@
 #include <cstdlib>
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -207,14 +212,84 @@ o2v_hip_comm *make_rccl_comm(const uint8_t id[O2V_HIP_COMM_ID_BYTES], int rank, 
     c->rank = rank;
     c->world = world;
     c->device = device;
-    const ncclResult_t r = api->CommInitRank(&c->comm, world, uid, rank);
-    if (r != ncclSuccess) {
-        err = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
+    // ncclCommInitRank returns when all `world` ranks have called it with the same id.  A node where one rank never does (a
+    // process that died, two ranks given the same GPU, another id) would leave the others waiting for ever: the call runs on a
+    // thread of its own and is given o2v::comm_timeout_seconds() to return; after that the rank fails with a message (the
+    // thread stays behind, blocked in RCCL, until the process ends).
+    struct Init {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t result = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    auto st = std::make_shared<Init>();
+    try {
+        std::thread([st, api, uid, world, rank, device] {
+            if (device >= 0) (void) hipSetDevice(device);  // (a new thread's current device is device 0)
+            ncclComm_t comm = nullptr;
+            const ncclResult_t r = api->CommInitRank(&comm, world, uid, rank);
+            std::lock_guard<std::mutex> lock(st->m);
+            st->result = r;
+            st->comm = comm;
+            st->done = true;
+            st->cv.notify_all();
+        }).detach();
+    }
+    catch (const std::system_error &) {
+        // (no thread to be had: call it here, without the guard)
+        st->result = api->CommInitRank(&st->comm, world, uid, rank);
+        st->done = true;
+    }
+    {
+        std::unique_lock<std::mutex> lock(st->m);
+        const double limit = o2v::comm_timeout_seconds();
+        if (!st->cv.wait_for(lock, std::chrono::duration<double>(limit), [&] { return st->done; })) {
+            err = "ncclCommInitRank did not return within " + std::to_string((int) limit) + " s (rank " + std::to_string(rank) + " of " + std::to_string(world) +
+                  "): is every rank of the job running, each on its own GPU, with rank 0's unique id?  (O2V_COMM_TIMEOUT_S sets the limit)";
+            delete c;
+            return nullptr;
+        }
+    }
+    if (st->result != ncclSuccess) {
+        err = std::string("ncclCommInitRank: ") + api->GetErrorString(st->result);
         c->comm = nullptr;
         delete c;
         return nullptr;
     }
+    c->comm = st->comm;
     return c;
+}
+
+double comm_timeout_seconds()
+{
+    if (const char *e = std::getenv("O2V_COMM_TIMEOUT_S")) {
+        const double v = std::atof(e);
+        if (v > 0.0) return v;
+    }
+    return 120.0;
+}
+
+// hipStreamSynchronize with a limit: false (and `err` set) if the stream's work - a collective that waits for a rank that never
+// arrives - is still pending after comm_timeout_seconds()
+bool stream_wait_limited(hipStream_t s, const char *what, std::string &err)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = comm_timeout_seconds();
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) {
+            err = std::string(what) + ": " + hipGetErrorString(q);
+            return false;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            err = std::string(what) + " did not complete within " + std::to_string((int) limit) +
+                  " s: a rank of the job has not reached it (O2V_COMM_TIMEOUT_S sets the limit)";
+            return false;
+        }
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));  // (the first ~ms is polled: the usual wait is microseconds)
+    }
 }
 
 o2v_hip_comm *make_callback_comm(const o2v_hip_comm_callbacks &cb, int rank, int world)

@@ -46,5 +46,9 @@ namespace o2v {
 o2v_hip_comm *make_rccl_comm(const uint8_t id[O2V_HIP_COMM_ID_BYTES], int rank, int world, int device, std::string &err);
 bool rccl_unique_id(uint8_t id[O2V_HIP_COMM_ID_BYTES], std::string &err);
 o2v_hip_comm *make_callback_comm(const o2v_hip_comm_callbacks &cb, int rank, int world);
+// What a rank waits for another rank at most (communicator creation, the readiness all-reduce of a sharded run) before it
+// fails with a message instead of hanging: O2V_COMM_TIMEOUT_S seconds, 120 by default.
+double comm_timeout_seconds();
+bool stream_wait_limited(hipStream_t s, const char *what, std::string &err);
 
 }  // namespace o2v

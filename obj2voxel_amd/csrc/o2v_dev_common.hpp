@@ -125,8 +125,11 @@ struct Counters {
     unsigned long long n_certain;   // occupancy-only mode: hits established without a voxel job (certain_prepare)
     unsigned long long n_jobs;      // candidate voxels that passed phase 1 of k_voxelize (= voxel jobs of phase 2)
     unsigned long long n_jobs_skipped;  // occupancy-only mode: jobs dropped before phase 2 because their voxel was marked already
+    uint32_t n_listed_hits, pad3;       // k_scan_bricks: the counters of the listed bricks' cells added up (modulo 2^32): must equal
+                                        // the hits k_voxelize counted into the grid (n_hits - n_direct), see o2v_hip_voxelize
     unsigned long long n_bypass;        // Params::root_bypass: root triangles that k_voxelize_occ stages itself (no Leaf, no Tile)
     unsigned long long dbg[16];  // event counts of an instrumented build (-DO2V_INSTRUMENT, tools/instrument.sh); else zero
+    uint32_t ext_hist[256];      // k_tri_extent (at upload time only): triangles by the binary exponent of their extent
 };
 
 enum : uint32_t {
@@ -145,6 +148,12 @@ struct Params {
     uint32_t ss_shift;     // 0, or 1 for 2x supersampling
     uint32_t zs0, zs1;     // slab in sample space
     uint32_t zo0;          // slab begin in output space
+    // The dense grids cover the mesh's voxel bounding box, not the G^3 cube ("crop", o2v_hip_voxelize): (xo0, yo0, zo0) is the
+    // grid's origin in output space (xo0, yo0 multiples of the brick edge), NBx / NBy its extent in bricks, and [cs_lo, cs_hi)
+    // the same box in sample space (z: cut to the slab), to which every leaf's box is clamped (plan_leaf) - no leaf reaches
+    // beyond it (the crop encloses every triangle), the clamp only keeps a wrong crop from writing outside the allocation.
+    uint32_t xo0, yo0;
+    uint32_t cs_lo[3], cs_hi[3];
     uint32_t blend;
     uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
     uint32_t n_bricks;     // bricks of this slab
@@ -270,22 +279,32 @@ constexpr uint32_t kLanesPerBrick = kBrickCells / 4u, kBricksPerLoad = 64u / kLa
 constexpr uint64_t kDirtyListMax = 1ull << 27;
 static_assert(kBrickShift >= 4 && kBrickShift <= 8, "a brick is 16 .. 256 cells (HitRec keeps the cell in 8 bits)");
 
-__device__ __forceinline__ uint64_t cell_index(uint32_t ox, uint32_t oy, uint32_t oz_rel, const Params &p, uint32_t &brick)
+// (ox, oy, oz: a voxel of the output grid inside the allocated box, see Params::xo0)
+__device__ __forceinline__ uint64_t cell_index(uint32_t ox, uint32_t oy, uint32_t oz, const Params &p, uint32_t &brick)
 {
-    brick = ((oz_rel >> kBrickZs) * p.NBy + (oy >> kBrickYs)) * p.NBx + (ox >> kBrickXs);
+    const uint32_t rx = ox - p.xo0, ry = oy - p.yo0, rz = oz - p.zo0;
+    brick = ((rz >> kBrickZs) * p.NBy + (ry >> kBrickYs)) * p.NBx + (rx >> kBrickXs);
     return (uint64_t) brick * kBrickCells +
-           ((((oz_rel & (kBrickZ - 1u)) << kBrickYs) + (oy & (kBrickY - 1u))) << kBrickXs) + (ox & (kBrickX - 1u));
+           ((((rz & (kBrickZ - 1u)) << kBrickYs) + (ry & (kBrickY - 1u))) << kBrickXs) + (rx & (kBrickX - 1u));
 }
-// position of a brick's cell `local` in a grid whose bricks are numbered x fastest (z relative to the slab)
-__device__ __forceinline__ void cell_position(uint32_t brick, uint32_t local, const Params &p, uint32_t &x, uint32_t &y, uint32_t &z_rel)
+// the first voxel (output grid) of a brick of a grid whose bricks are numbered x fastest
+__device__ __forceinline__ void brick_origin(uint32_t brick, const Params &p, uint32_t &x, uint32_t &y, uint32_t &z)
 {
     const uint32_t row = brick / p.NBx;
     const uint32_t bx = brick - row * p.NBx;
     const uint32_t bz = row / p.NBy;
     const uint32_t by = row - bz * p.NBy;
-    x = (bx << kBrickXs) + (local & (kBrickX - 1u));
-    y = (by << kBrickYs) + ((local >> kBrickXs) & (kBrickY - 1u));
-    z_rel = (bz << kBrickZs) + (local >> (kBrickXs + kBrickYs));
+    x = (bx << kBrickXs) + p.xo0;
+    y = (by << kBrickYs) + p.yo0;
+    z = (bz << kBrickZs) + p.zo0;
+}
+// position (output grid) of a brick's cell `local`
+__device__ __forceinline__ void cell_position(uint32_t brick, uint32_t local, const Params &p, uint32_t &x, uint32_t &y, uint32_t &z)
+{
+    brick_origin(brick, p, x, y, z);
+    x += local & (kBrickX - 1u);
+    y += (local >> kBrickXs) & (kBrickY - 1u);
+    z += local >> (kBrickXs + kBrickYs);
 }
 
 // exclusive scan of one uint32 per thread over a 256-thread block; returns the block total in `total`

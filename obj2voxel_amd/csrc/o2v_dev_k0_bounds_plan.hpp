@@ -72,20 +72,31 @@ __global__ __launch_bounds__(kBlock) void k_bounds(const float *__restrict__ ver
 
 // Largest triangle extent (L-infinity, mesh space), computed once per upload: with the mesh extent it bounds the
 // subdivision depth, i.e. how many k_expand_nodes rounds a voxelization has to launch (each is ~10 us even when empty).
-__global__ __launch_bounds__(kBlock) void k_tri_extent(const float *__restrict__ verts, uint64_t n_tris, uint32_t *out_enc)
+// (also: the triangles counted by the binary exponent of their extent - hist[biased exponent], 256 bins - from which the host
+// estimates, once the resolution is known, what share of the mesh will be subdivided: grid_modes)
+__global__ __launch_bounds__(kBlock) void k_tri_extent(const float *__restrict__ verts, uint64_t n_tris, uint32_t *out_enc, uint32_t *hist)
 {
     __shared__ float s_red[kBlock / 64];
+    __shared__ uint32_t s_hist[256];
+    s_hist[threadIdx.x] = 0;
+    static_assert(kBlock == 256, "one bin per thread");
+    __syncthreads();
     float ext = 0.f;
     for (uint64_t t = (uint64_t) blockIdx.x * kBlock + threadIdx.x; t < n_tris; t += (uint64_t) gridDim.x * kBlock) {
         const float *q = verts + t * 9;
+        float mine = 0.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float lo = fminf(q[a], fminf(q[3 + a], q[6 + a])), hi = fmaxf(q[a], fmaxf(q[3 + a], q[6 + a]));
             float e = hi - lo;
             if (!(e == e)) e = __builtin_inff();  // NaN: no bound
-            ext = fmaxf(ext, e);
+            mine = fmaxf(mine, e);
         }
+        ext = fmaxf(ext, mine);
+        atomicAdd(&s_hist[(__float_as_uint(mine) >> 23) & 255u], 1u);
     }
+    __syncthreads();
+    if (s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) ext = fmaxf(ext, __shfl_xor(ext, d, 64));
     if ((threadIdx.x & 63u) == 0) s_red[threadIdx.x >> 6] = ext;

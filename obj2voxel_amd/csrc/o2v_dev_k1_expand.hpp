@@ -23,7 +23,9 @@ __device__ __forceinline__ LeafPlan plan_leaf(const Sub &s, const Params &p)
     V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
     uint32_t lo[3] = {floor_u32(mn.x), floor_u32(mn.y), floor_u32(mn.z)};
     uint32_t hi[3] = {floor_u32(mx.x) + 1u, floor_u32(mx.y) + 1u, floor_u32(mx.z) + 1u};
-    uint32_t glo[3] = {0u, 0u, p.zs0}, ghi[3] = {p.S, p.S, p.zs1};
+    // (the grid's box in sample space: the [0, S)^2 x slab box of the reference's chunk, cut to the mesh's bounding box, which
+    // no leaf leaves - Params::cs_lo)
+    const uint32_t glo[3] = {p.cs_lo[0], p.cs_lo[1], p.cs_lo[2]}, ghi[3] = {p.cs_hi[0], p.cs_hi[1], p.cs_hi[2]};
     bool empty = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -545,12 +547,9 @@ __global__ __launch_bounds__(kBlock) void k_mark_bricks(const Leaf *__restrict__
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 if (d[a] == 0u) continue;
-                // output cells [lo >> ss, (lo + d - 1) >> ss]; z relative to the slab
-                uint32_t c0 = lo[a] >> p.ss_shift, c1 = (lo[a] + d[a] - 1u) >> p.ss_shift;
-                if (a == 2) {
-                    c0 -= p.zo0;
-                    c1 -= p.zo0;
-                }
+                // output cells [lo >> ss, (lo + d - 1) >> ss], relative to the grid's origin
+                const uint32_t org = a == 0 ? p.xo0 : (a == 1 ? p.yo0 : p.zo0);
+                const uint32_t c0 = (lo[a] >> p.ss_shift) - org, c1 = ((lo[a] + d[a] - 1u) >> p.ss_shift) - org;
                 b0[a] = c0 >> sh[a];
                 nb[a] = (c1 >> sh[a]) - b0[a] + 1u;
             }

@@ -879,7 +879,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                             keep = false;
                             const uint32_t ox = qx >> p.ss_shift, oy = qy >> p.ss_shift, oz = qz >> p.ss_shift;
                             uint32_t brick;
-                            const uint64_t cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                            const uint64_t cell = cell_index(ox, oy, oz, p, brick);
                             p.occgrid[cell] = 1;      // (plain stores; benign races: every writer stores the same value)
                             p.dirty_max[brick] = 1;
                         }
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                     for (uint32_t j = 0; j < kPerLane; ++j) {
                         uint32_t brick;
                         const uint64_t cell = cell_index((rec[j].x & 0xffffu) >> p.ss_shift, (rec[j].x >> 16) >> p.ss_shift,
-                                                         ((rec[j].y & 0xffffu) >> p.ss_shift) - p.zo0, p, brick);
+                                                         (rec[j].y & 0xffffu) >> p.ss_shift, p, brick);
                         seen[j] = ok[j] ? __hip_atomic_load(&p.occgrid[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t) 1;
                     }
 #pragma unroll
@@ -1150,7 +1150,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                     if (d_valid) {
                         const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
                         uint32_t brick;
-                        const uint64_t cell = cell_index(d_px >> p.ss_shift, d_py >> p.ss_shift, (d_pz >> p.ss_shift) - p.zo0, p, brick);
+                        const uint64_t cell = cell_index(d_px >> p.ss_shift, d_py >> p.ss_shift, d_pz >> p.ss_shift, p, brick);
                         p.occgrid[cell] = 1;
                         p.dirty_max[brick] = 1;
                     }
@@ -1175,7 +1175,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                 if (d_valid) {
                     const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
                     const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
-                    cell = cell_index(ox, oy, oz - p.zo0, p, brick);
+                    cell = cell_index(ox, oy, oz, p, brick);
                     const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
                     keyhi = (sub << 29) | lf[18];
                     if (!direct) {

@@ -57,7 +57,7 @@ __device__ __forceinline__ uint4 cell_record(const Occ &o, uint32_t argb, const 
     const uint64_t cell = o.cell();
     uint32_t x, y, z;
     cell_position((uint32_t) (cell >> kBrickShift), (uint32_t) cell & (kBrickCells - 1u), p, x, y, z);
-    return make_uint4(x, y, z + p.zo0, argb);
+    return make_uint4(x, y, z, argb);
 }
 
 // Where a resolved cell goes.  Normally its (x, y, z, argb) record is final.  On the direct MAX path (Params::direct_max)
@@ -900,10 +900,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
         for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
             const unsigned long long v4[4] = {lo[k].x, lo[k].y, hi[k].x, hi[k].y};
             if (v4[0] | v4[1] | v4[2] | v4[3]) {
-                const uint32_t row = brick[k] / p.NBx;
-                const uint32_t bx = brick[k] - row * p.NBx;
-                const uint32_t bz = row / p.NBy;
-                const uint32_t by = row - bz * p.NBy;
+                uint32_t x0, y0, z0;
+                brick_origin(brick[k], p, x0, y0, z0);
 #pragma unroll
                 for (uint32_t e = 0; e < 4; ++e) {
                     if (v4[e]) {
@@ -919,9 +917,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
                             argb = pack_argb(cr, cg, cb);
                         }
                         const uint32_t slot = atomicAdd(&s_n, 1u);
-                        s_rec[slot] = make_uint4((bx << kBrickXs) + (local & (kBrickX - 1u)),
-                                                 (by << kBrickYs) + ((local >> kBrickXs) & (kBrickY - 1u)),
-                                                 (bz << kBrickZs) + (local >> (kBrickXs + kBrickYs)) + p.zo0, argb);
+                        s_rec[slot] = make_uint4(x0 + (local & (kBrickX - 1u)), y0 + ((local >> kBrickXs) & (kBrickY - 1u)),
+                                                 z0 + (local >> (kBrickXs + kBrickYs)), argb);
                     }
                 }
                 // leave the cells clean for the next run
@@ -991,10 +988,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
         for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
             // (wavefront-uniform loop over the four cells of a lane: the staging slots are reserved with one LDS atomic per
             // wavefront and cell position, not one per voxel)
-            const uint32_t row = brick[k] == 0xffffffffu ? 0u : brick[k] / p.NBx;
-            const uint32_t bx = brick[k] - row * p.NBx;
-            const uint32_t bz = row / p.NBy;
-            const uint32_t by = row - bz * p.NBy;
+            uint32_t x0, y0, z0;
+            brick_origin(brick[k] == 0xffffffffu ? 0u : brick[k], p, x0, y0, z0);
 #pragma unroll
             for (uint32_t e = 0; e < 4; ++e) {
                 const bool set = ((cells4[k] >> (8u * e)) & 0xffu) != 0u;
@@ -1006,9 +1001,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
                     if (set) {
                         const uint32_t local = (lane % kLanesPerBrick) * 4u + e;
                         const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-                        s_rec[slot] = make_uint4((bx << kBrickXs) + (local & (kBrickX - 1u)),
-                                                 (by << kBrickYs) + ((local >> kBrickXs) & (kBrickY - 1u)),
-                                                 (bz << kBrickZs) + (local >> (kBrickXs + kBrickYs)) + p.zo0, white);
+                        s_rec[slot] = make_uint4(x0 + (local & (kBrickX - 1u)), y0 + ((local >> kBrickXs) & (kBrickY - 1u)),
+                                                 z0 + (local >> (kBrickXs + kBrickYs)), white);
                     }
                 }
             }

@@ -122,7 +122,7 @@ __device__ __forceinline__ uint32_t *class_counter(Counters *c, uint32_t k)
 __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, const uint32_t *s_hi /* cell >> 32 | slab << 5 */, uint32_t *s_cnt,
                                            uint32_t *s_wave, uint32_t *s_base, uint32_t *s_cls /*[7], zero*/,
                                            uint32_t *s_cls_base /*[7]*/, uint32_t *grid, Counters *c, Occ *occ,
-                                           const ResolveLists &lists, const Params &p)
+                                           const ResolveLists &lists, const Params &p, uint32_t &hits_seen)
 {
     // thread t owns the entries [t * per, (t + 1) * per)
     const uint32_t per = (n + kBlock - 1) / kBlock;
@@ -133,7 +133,10 @@ __device__ __forceinline__ void scan_flush(uint32_t n, const uint32_t *s_lo, con
         const bool has_slab = (s_hi[i] >> 5) < p.cap_slabs;
         return !has_slab ? s_cnt[i] : (s_cnt[i] > kInlineHits ? s_cnt[i] - kInlineHits : 0u);
     };
-    for (uint32_t i = lo; i < hi; ++i) sum += sorted_need(i);
+    for (uint32_t i = lo; i < hi; ++i) {
+        sum += sorted_need(i);
+        hits_seen += s_cnt[i];  // (this thread's share of Counters::n_listed_hits)
+    }
     uint32_t total;
     uint32_t run = block_exscan(sum, s_wave, total);
     __syncthreads();
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
     __syncthreads();
     const uint32_t n_dirty = c->n_dirty < p.cap_dirty ? c->n_dirty : p.cap_dirty;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t hits_seen = 0;
     const uint32_t n_rounds = (n_dirty + kScanBricksPerRound - 1) / kScanBricksPerRound;
     for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
         uint32_t brick[kScanBricksPerWave], slab[kScanBricksPerWave];
@@ -243,14 +247,21 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
         __syncthreads();
         const uint32_t n = s_n;
         if (n >= kScanFlushAt) {
-            scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
+            scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p, hits_seen);
             __syncthreads();
             if (threadIdx.x == 0) s_n = 0;
         }
         __syncthreads();
     }
     const uint32_t n = s_n;
-    if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p);
+    if (n) scan_flush(n, s_lo, s_hi, s_cnt, s_wave, s_base, s_cls, s_cls_base, grid, c, occ, lists, p, hits_seen);
+    // the hits this workgroup saw in the listed bricks: one global atomic per workgroup (Counters::n_listed_hits)
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (hits_seen) atomicAdd(&s_n, hits_seen);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(&c->n_listed_hits, s_n);
 }
 
 #ifndef O2V_SCATTER_UNROLL

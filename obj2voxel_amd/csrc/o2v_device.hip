@@ -110,6 +110,8 @@ struct o2v_hip_ctx {
     uint32_t cap_block_list = 0;
     float mesh_bounds_hint[6] = {0, 0, 0, 0, 0, 0};  // bounds and largest triangle extent of the uploaded mesh: only used to
     float max_tri_extent = -1.f;                     // bound the number of subdivision rounds (-1: unknown)
+    uint32_t ext_hist[256] = {};                     // k_tri_extent: the uploaded mesh's triangles by the binary exponent of their extent
+                                                     // (grid_modes: is the 64-bit max grid worth its memory?)
     uint64_t tri_generation = 0, zrange_generation = ~0ull;  // the extents belong to the triangles of that upload
     Leaf *d_leaves = nullptr;
     Tile *d_tiles = nullptr;
@@ -291,8 +293,77 @@ GridModes grid_modes(const o2v_hip_ctx *ctx, const o2v_hip_params *params)
     g.occupancy_only = !ctx->d_types && !g.use_uv && !g.exact_clip && !no_direct && !(no_occ && no_occ[0] == '1');
     // Direct MAX path: MAX strategy; with textured triangles in its "pick" variant
     g.direct_max = (params->strategy == 0u || g.occupancy_only) && !no_direct;
+    // ... unless most of the mesh will be subdivided anyway: the direct path then stays unused (direct_active() on the device:
+    // at most half of the triangles subdivided) while its 64-bit grid takes two thirds of the grids' memory - 29 GB of 43 for the
+    // reference README's 8192^3 showcase (19 k large triangles), allocated and zeroed for nothing.  Estimated from the
+    // triangles' extents, known since the upload (k_tri_extent): a triangle 16 voxels or more across is subdivided as a rule
+    // (a voxel box of 512 cells and more, voxelization.cpp:357-361, unless it is a sliver or axis-aligned).  Either way the
+    // result is the same; only which route computes it, and what it needs of the device, changes.
+    if (g.direct_max && !g.occupancy_only && ctx->max_tri_extent >= 0.f && ctx->n_tris) {
+        const float *b = params->bounds_known ? params->bounds : ctx->mesh_bounds_hint;
+        const float max_axis = std::max(b[3] - b[0], std::max(b[4] - b[1], b[5] - b[2]));
+        const uint32_t ss = params->supersampling ? params->supersampling : 1u;
+        float unit_norm = 0.f;
+        for (int i = 0; i < 3; ++i)
+            unit_norm = std::max(unit_norm, std::fabs((float) params->unit_transform[i * 3]) + std::fabs((float) params->unit_transform[i * 3 + 1]) +
+                                                std::fabs((float) params->unit_transform[i * 3 + 2]));
+        const float voxels_per_unit = unit_norm * (float) (params->resolution * ss) / max_axis;
+        if (max_axis > 0.f && std::isfinite(voxels_per_unit) && voxels_per_unit > 0.f) {
+            uint64_t large = 0;
+            for (uint32_t e = 1; e < 255; ++e)   // bin e: extents in [2^(e-127), 2^(e-126))
+                if (std::ldexp(1.0f, (int) e - 127) * voxels_per_unit >= 16.0f) large += ctx->ext_hist[e];
+            large += ctx->ext_hist[255];          // (infinite / NaN extents: such triangles are subdivided until they vanish)
+            if (large * 4 > ctx->n_tris * 3) g.direct_max = false;
+        }
+    }
     return g;
 }
+
+// The part of the output grid the dense grids are allocated for: the mesh's voxel bounding box, not the G^3 cube - the
+// reference's VoxelMap only ever holds the chunks the mesh touches (util.hpp:179-208), and a long thin model at a high
+// resolution (the reference README's showcase: r = 8192) fills a small fraction of the cube.  From the bounds of the
+// uploaded mesh (known since the upload: ctx->mesh_bounds_hint) and the same transform k_setup computes on the device
+// (compute_mesh_transform of the bounds in effect: the caller's, or the mesh's own): the eight corners of the mesh's box,
+// transformed, one voxel of margin either side, in output space rounded outwards to whole bricks in x and y and cut to
+// the slab in z.  A mesh whose bounds are unknown or not finite gets the whole cube.  O2V_NO_CROP=1: always the cube (A/B).
+struct GridBox {
+    uint32_t lo[3], hi[3];  // output space, [lo, hi); lo[0], lo[1] multiples of the brick edge
+    bool empty;             // the slab does not meet the mesh's box: nothing to voxelize
+};
+GridBox grid_box(const o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t ss, uint32_t z0, uint32_t z1)
+{
+    const uint32_t G = params->resolution, S = G * ss;
+    GridBox b{{0u, 0u, z0}, {G, G, z1}, false};
+    const char *off = std::getenv("O2V_NO_CROP");
+    if ((off && off[0] == '1') || ctx->max_tri_extent < 0.f || ctx->n_tris == 0) return b;
+    const float *h = ctx->mesh_bounds_hint;
+    for (int i = 0; i < 6; ++i)
+        if (!std::isfinite(h[i])) return b;
+    const float *e = params->bounds_known ? params->bounds : h;
+    const Affine a = compute_mesh_transform(V3{e[0], e[1], e[2]}, V3{e[3], e[4], e[5]}, S, params->unit_transform);
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int corner = 0; corner < 8; ++corner) {
+        const V3 t = affine_apply(a, V3{h[(corner & 1) ? 3 : 0], h[(corner & 2) ? 4 : 1], h[(corner & 4) ? 5 : 2]});
+        const float c[3] = {t.x, t.y, t.z};
+        for (int k = 0; k < 3; ++k) {
+            if (!std::isfinite(c[k])) return b;
+            mn[k] = std::min<double>(mn[k], c[k]);
+            mx[k] = std::max<double>(mx[k], c[k]);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        // sample space: [floor(min) - 1, floor(max) + 2), within [0, S) (a negative coordinate is voxel 0 on the device)
+        const double lo_s = std::min<double>(std::max<double>(std::floor(mn[k]) - 1.0, 0.0), (double) S);
+        const double hi_s = std::min<double>(std::max<double>(std::floor(mx[k]) + 2.0, 0.0), (double) S);
+        uint32_t lo_o = (uint32_t) lo_s / ss, hi_o = ((uint32_t) hi_s + ss - 1u) / ss;
+        if (k < 2) lo_o &= ~(kBrickX - 1u);  // (kBrickX == kBrickY)
+        b.lo[k] = std::max(b.lo[k], lo_o);
+        b.hi[k] = std::min(b.hi[k], hi_o);
+        if (b.lo[k] >= b.hi[k]) b.empty = true;
+    }
+    return b;
+}
+static_assert(kBrickX == kBrickY, "grid_box aligns x and y alike");
 
 // One pass of the pipeline with the current capacities.  Fills h_ctr; the caller checks for overflow.
 int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
@@ -578,6 +649,7 @@ TriHints ctx_tri_hints(const o2v_hip_ctx *ctx)
     h.any_textured = ctx->any_textured;
     for (int i = 0; i < 6; ++i) h.bounds[i] = ctx->mesh_bounds_hint[i];
     h.max_tri_extent = ctx->max_tri_extent;
+    std::memcpy(h.ext_hist, ctx->ext_hist, sizeof(h.ext_hist));
     return h;
 }
 
@@ -593,6 +665,7 @@ int ctx_finish_triangles(o2v_hip_ctx *ctx, bool any_textured, const TriHints *hi
     if (hints) {
         for (int i = 0; i < 6; ++i) ctx->mesh_bounds_hint[i] = hints->bounds[i];
         ctx->max_tri_extent = hints->max_tri_extent;
+        std::memcpy(ctx->ext_hist, hints->ext_hist, sizeof(ctx->ext_hist));
         ctx->any_textured = hints->any_textured;
     }
     else if (count) {
@@ -601,11 +674,12 @@ int ctx_finish_triangles(o2v_hip_ctx *ctx, bool any_textured, const TriHints *hi
         hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (count * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
         hipLaunchKernelGGL(k_tri_extent, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count + kBlock - 1) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_verts, count, &ctx->d_ctr->pad2);
+                           dim3(kBlock), 0, s, ctx->d_verts, count, &ctx->d_ctr->pad2, ctx->d_ctr->ext_hist);
         O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
         O2V_CHECK(hipStreamSynchronize(s));
         for (int i = 0; i < 6; ++i) ctx->mesh_bounds_hint[i] = ord2f_host(ctx->h_ctr->bounds_enc[i]);
         ctx->max_tri_extent = ord2f_host(ctx->h_ctr->pad2);
+        std::memcpy(ctx->ext_hist, ctx->h_ctr->ext_hist, sizeof(ctx->ext_hist));
         return O2V_HIP_OK;
     }
     O2V_CHECK(hipStreamSynchronize(s));
@@ -950,9 +1024,14 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     p.n_tris = ctx->n_tris;
     p.S = (uint32_t) S64;
     p.G = params->resolution;
-    p.NBx = (p.G + kBrickX - 1) / kBrickX;
-    p.NBy = (p.G + kBrickY - 1) / kBrickY;
-    const uint32_t NBz = (z1 - z0 + kBrickZ - 1) / kBrickZ;
+    // the dense grids cover the mesh's voxel bounding box within the slab (grid_box)
+    const GridBox box = grid_box(ctx, params, ss, z0, z1);
+    if (box.empty) return O2V_HIP_OK;  // the mesh does not reach this slab: no voxels
+    p.xo0 = box.lo[0];
+    p.yo0 = box.lo[1];
+    p.NBx = (box.hi[0] - box.lo[0] + kBrickX - 1) / kBrickX;
+    p.NBy = (box.hi[1] - box.lo[1] + kBrickY - 1) / kBrickY;
+    const uint32_t NBz = (box.hi[2] - box.lo[2] + kBrickZ - 1) / kBrickZ;
     const uint64_t n_bricks = (uint64_t) p.NBx * p.NBy * NBz;
     if (n_bricks >= (1ull << 32) / 2) {
         ctx->err = "slab has too many bricks for 32-bit brick ids; use more z-slabs";
@@ -963,7 +1042,14 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     p.ss_shift = ss == 2 ? 1u : 0u;
     p.zs0 = z0 * ss;
     p.zs1 = z1 * ss;
-    p.zo0 = z0;
+    p.zo0 = box.lo[2];
+    for (int k = 0; k < 3; ++k) {
+        // the same box in sample space, z cut to the slab: what a leaf's box is clamped to (plan_leaf)
+        p.cs_lo[k] = box.lo[k] * ss;
+        p.cs_hi[k] = (uint32_t) std::min<uint64_t>((uint64_t) box.hi[k] * ss, S64);
+    }
+    p.cs_lo[2] = std::max(p.cs_lo[2], p.zs0);
+    p.cs_hi[2] = std::min(p.cs_hi[2], p.zs1);
     p.blend = params->strategy;
     p.bounds_known = params->bounds_known;
     for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
@@ -1133,6 +1219,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         }
     }
     ctx->force_general = false;
+    ctx->mark_missing = false;  // (a call that ended early - an error, a failed allocation - must not leave it to the next one)
     if (!p.occupancy_only) ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
     if (p.direct_max) ctx->maxgrid_dirty = true;
     for (uint32_t pass = 1; pass <= 12; ++pass) {
@@ -1148,48 +1235,68 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
                 O2V_CHECK(hipMemsetAsync(ctx->d_dirty_max, 0, ctx->maxgrid_map_bytes, ctx->stream));
             }
         }
-        if ((rc = grow(ctx, ctx->d_leaves, ctx->cap_leaves, want_leaves))) return rc;
-        if ((rc = grow(ctx, ctx->d_tiles, ctx->cap_tiles, want_tiles))) return rc;
-        if ((rc = grow(ctx, ctx->d_big, ctx->cap_big, want_big))) return rc;
+        // The buffers a pass cannot do without come first; the hit slabs - a budget, the pass runs without them - take what is
+        // left afterwards, and give way (are freed, then the allocation is tried again) if one of the others does not fit.
+        auto grow_required = [&](auto *&ptr, uint32_t &cap, uint64_t want) -> int {
+            int rc_g = grow(ctx, ptr, cap, want);
+            if (rc_g == O2V_HIP_ERR_OUT_OF_MEMORY && ctx->d_slabs) {
+                (void) hipGetLastError();
+                (void) hipFree(ctx->d_slabs);
+                ctx->d_slabs = nullptr;
+                ctx->cap_slabs = 0;
+                want_slabs = 0;  // (this call goes on without slabs: every hit is pooled)
+                rc_g = grow(ctx, ptr, cap, want);
+            }
+            return rc_g;
+        };
+        if ((rc = grow_required(ctx->d_leaves, ctx->cap_leaves, want_leaves))) return rc;
+        if ((rc = grow_required(ctx->d_tiles, ctx->cap_tiles, want_tiles))) return rc;
+        if ((rc = grow_required(ctx->d_big, ctx->cap_big, want_big))) return rc;
         uint32_t cap_n0 = ctx->cap_nodes, cap_n1 = ctx->cap_nodes;
-        if ((rc = grow(ctx, ctx->d_nodes[0], cap_n0, want_nodes))) return rc;
-        if ((rc = grow(ctx, ctx->d_nodes[1], cap_n1, want_nodes))) return rc;
+        if ((rc = grow_required(ctx->d_nodes[0], cap_n0, want_nodes))) return rc;
+        if ((rc = grow_required(ctx->d_nodes[1], cap_n1, want_nodes))) return rc;
         ctx->cap_nodes = cap_n0;
         {
             uint32_t cap_p = ctx->cap_hits, cap_s = ctx->cap_hits;
-            if ((rc = grow(ctx, ctx->d_pool, cap_p, want_hits))) return rc;
-            if ((rc = grow(ctx, ctx->d_sorted, cap_s, want_hits))) return rc;
+            if ((rc = grow_required(ctx->d_pool, cap_p, want_hits))) return rc;
+            if ((rc = grow_required(ctx->d_sorted, cap_s, want_hits))) return rc;
             ctx->cap_hits = cap_p;
         }
-        if (want_slabs > ctx->cap_slabs) {
-            if (ctx->d_slabs) O2V_CHECK(hipFree(ctx->d_slabs));
-            ctx->d_slabs = nullptr;
-            ctx->cap_slabs = 0;
-            if (hipMalloc(reinterpret_cast<void **>(&ctx->d_slabs), want_slabs * kInlineHits * kBrickCells * slab_stride * sizeof(uint32_t)) == hipSuccess)
-                ctx->cap_slabs = (uint32_t) std::min<uint64_t>(want_slabs, 0xfffffff0ull);
-            else
-                (void) hipGetLastError();  // (no slabs: every hit is pooled)
-            want_slabs = ctx->cap_slabs;
-        }
         uint32_t cap_v0 = ctx->cap_vox, cap_v1 = ctx->cap_vox;
-        if ((rc = grow(ctx, ctx->d_occ, cap_v0, want_vox))) return rc;
-        if ((rc = grow(ctx, ctx->d_out, cap_v1, want_vox))) return rc;
+        if ((rc = grow_required(ctx->d_occ, cap_v0, want_vox))) return rc;
+        if ((rc = grow_required(ctx->d_out, cap_v1, want_vox))) return rc;
         if (p.pick_max) {
             uint32_t cap_px = ctx->cap_pick_extra;
-            if ((rc = grow(ctx, ctx->d_pick_extra, cap_px, want_vox))) return rc;
+            if ((rc = grow_required(ctx->d_pick_extra, cap_px, want_vox))) return rc;
             ctx->cap_pick_extra = cap_px;
             p.pick_extra = reinterpret_cast<uint32_t *>(ctx->d_pick_extra);
         }
         for (uint32_t **lp : {&ctx->d_list_lane8, &ctx->d_list_lane16, &ctx->d_list_w64, &ctx->d_list_lane, &ctx->d_list_mid, &ctx->d_list_long, &ctx->d_list_big, &ctx->d_list_huge}) {
             uint32_t cap_l = ctx->cap_vox;
-            if ((rc = grow(ctx, *lp, cap_l, want_vox))) return rc;
+            if ((rc = grow_required(*lp, cap_l, want_vox))) return rc;
         }
         ctx->cap_vox = cap_v0;
         if (want_scratch) {
             uint32_t cap_s0 = ctx->cap_scratch, cap_s1 = ctx->cap_scratch;
-            if ((rc = grow(ctx, ctx->d_scratch_key, cap_s0, want_scratch))) return rc;
-            if ((rc = grow(ctx, ctx->d_scratch_idx, cap_s1, want_scratch))) return rc;
+            if ((rc = grow_required(ctx->d_scratch_key, cap_s0, want_scratch))) return rc;
+            if ((rc = grow_required(ctx->d_scratch_idx, cap_s1, want_scratch))) return rc;
             ctx->cap_scratch = cap_s0;
+        }
+        if (want_slabs > ctx->cap_slabs) {
+            if (ctx->d_slabs) O2V_CHECK(hipFree(ctx->d_slabs));
+            ctx->d_slabs = nullptr;
+            ctx->cap_slabs = 0;
+            // (what is free now, every required buffer being in place, less 1 GiB for what a later pass may have to grow)
+            size_t free_now = 0, total_now = 0;
+            O2V_CHECK(hipMemGetInfo(&free_now, &total_now));
+            const uint64_t slab_bytes = (uint64_t) kInlineHits * kBrickCells * slab_stride * sizeof(uint32_t);
+            const uint64_t room = free_now > (1ull << 30) ? ((uint64_t) free_now - (1ull << 30)) / slab_bytes : 0ull;
+            const uint64_t n_slabs_now = std::min<uint64_t>(std::min<uint64_t>(want_slabs, room), 0xfffffff0ull);
+            if (n_slabs_now && hipMalloc(reinterpret_cast<void **>(&ctx->d_slabs), n_slabs_now * slab_bytes) == hipSuccess)
+                ctx->cap_slabs = (uint32_t) n_slabs_now;
+            else
+                (void) hipGetLastError();  // (no slabs: every hit is pooled)
+            want_slabs = ctx->cap_slabs;
         }
         p.cap_leaves = ctx->cap_leaves;
         p.cap_tiles = ctx->cap_tiles;
@@ -1207,7 +1314,9 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         ctx->timings.passes = pass;
         if (h.err_flags) {
             // (a dirty-list overflow leaves bricks behind that no list names: the grids stay marked for a full clear)
-            if (!(h.err_flags & kErrDirtyList) && !p.occupancy_only) ctx->grid_dirty = false;
+            // (nor does a pass that ran without a brick list - mark_missing - clean up behind itself)
+            if (!(h.err_flags & kErrDirtyList) && !p.occupancy_only && ctx->last_ran_general && ctx->marked_bricks) ctx->grid_dirty = false;
+            ctx->mark_missing = false;
             ctx->err = (h.err_flags & kErrLeafTooLarge) ? "a leaf's voxel AABB has 2^32 or more candidate voxels"
                        : (h.err_flags & kErrDepth)      ? "subdivision deeper than 15 levels"
                        : (h.err_flags & kErrDirtyList)  ? "more than 2^27 bricks of the slab hold voxels; use more z-slabs"
@@ -1254,6 +1363,16 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             want_scratch = std::max<uint64_t>(2ull * ctx->cap_hits, (uint64_t) h.scratch_used + 1024);
             again = true;
         }
+        if (!again && ctx->last_ran_general && (uint32_t) (h.n_hits - h.n_direct) != h.n_listed_hits) {
+            // k_voxelize counted a hit into a cell of a brick that k_mark_bricks did not list (the two must agree on the leaf's
+            // clamped box, supersampling shift and slab origin): its voxel would be missing and its counter would stay behind
+            // for the next run.  Never seen; checked because nothing else would notice.  The grids are cleared before the next call.
+            ctx->grid_dirty = true;
+            ctx->maxgrid_dirty = true;
+            ctx->err = "internal error: hits outside the listed bricks (" + std::to_string(h.n_hits - h.n_direct) + " counted, " +
+                       std::to_string(h.n_listed_hits) + " listed)";
+            return O2V_HIP_ERR_HIP;
+        }
         if (!again) {
             if (!p.occupancy_only) ctx->grid_dirty = false;
             ctx->maxgrid_dirty = false;
@@ -1270,6 +1389,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->stats.jobs = h.n_jobs;
             ctx->stats.certain_hits = h.n_certain;
             ctx->stats.skipped_jobs = h.n_jobs_skipped;
+            ctx->stats.bypassed_leaves = h.n_bypass;
             ctx->stats.bricks = p.n_bricks;
             ctx->stats.dirty_bricks = direct ? h.n_dirty_max : h.n_dirty;
             ctx->stats.pool_slots = h.n_hits_reserved;
@@ -1547,7 +1667,9 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
         }
         if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s0));
         O2V_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s0));
-        O2V_CHECK(hipStreamSynchronize(s0));
+        // (the first collective of the run: if a rank of the job never gets here - it died, or the node is set up wrongly - the
+        // others say so after o2v::comm_timeout_seconds() instead of waiting for ever)
+        if (!o2v::stream_wait_limited(s0, "the readiness all-reduce of the sharded run", ctx->err)) return O2V_HIP_ERR_HIP;
         if (time_it) O2V_CHECK(hipEventElapsedTime(&parts_ms[0], ctx->ev_coll[0], ctx->ev_coll[1]));
         if (rc_prepare) {
             ctx->err = prepare_err;
@@ -1625,7 +1747,11 @@ int o2v_hip_max_slab_layers(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint
     size_t free_b = 0, total_b = 0;
     O2V_CHECK(hipMemGetInfo(&free_b, &total_b));
     const uint64_t G = params->resolution;
-    const uint64_t per_layer_bricks = ((G + kBrickX - 1) / kBrickX) * ((G + kBrickY - 1) / kBrickY);
+    // (a layer of the grids is as wide as the mesh's voxel bounding box, grid_box)
+    const uint32_t ss_l = params->supersampling ? params->supersampling : 1u;
+    const GridBox box = grid_box(ctx, params, ss_l, 0u, params->resolution);
+    const uint64_t per_layer_bricks = box.empty ? 1ull
+                                                : (uint64_t) ((box.hi[0] - box.lo[0] + kBrickX - 1) / kBrickX) * ((box.hi[1] - box.lo[1] + kBrickY - 1) / kBrickY);
     // per brick: occupancy only (no triangle of the uploaded mesh has a material) one byte per cell; else the 32-bit counter
     // grid and, for the MAX strategy, the 64-bit grid; each with a dirty flag and a dirty-list entry
     const GridModes modes = grid_modes(ctx, params);  // (the same decision o2v_hip_voxelize takes, flags and environment included)
@@ -1637,12 +1763,17 @@ int o2v_hip_max_slab_layers(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint
     const uint64_t held = (occupancy_only ? 0ull : ctx->grid_cells * 4ull + ctx->brick_cap * 5ull) + ctx->maxgrid_bytes + ctx->maxgrid_brick_cap * 5ull;
     // the work buffers (leaves, tiles, hit pool, sorted records, output) scale with the mesh, not with the grid: a quarter of
     // the device, at least 8 GiB, stays free for them
+    // (the hit slabs - at most a sixth of the device, o2v_hip_voxelize - are part of that reserve: what the context holds of
+    // them already counts towards it, and they give way if a required buffer does not fit)
     const uint64_t reserve = std::max<uint64_t>(8ull << 30, total_b / 4);
-    const uint64_t avail = (uint64_t) free_b + held > reserve ? (uint64_t) free_b + held - reserve : 0;
+    const uint64_t held_slabs = (uint64_t) ctx->cap_slabs * kInlineHits * kBrickCells * ctx->slabs_stride * sizeof(uint32_t);
+    const uint64_t avail = (uint64_t) free_b + held + held_slabs > reserve ? (uint64_t) free_b + held + held_slabs - reserve : 0;
     uint64_t brick_layers = avail / (per_layer_bricks * per_brick);
     brick_layers = std::min<uint64_t>(brick_layers, ((1ull << 31) - 1) / per_layer_bricks);  // 32-bit brick ids
     const uint64_t layers = brick_layers * kBrickZ;
-    *out_layers = layers >= G ? (uint32_t) G : (uint32_t) layers;
+    // (the grids only span the mesh's box in z as well: if that many layers fit, the whole resolution is one slab)
+    const uint64_t box_layers = box.empty ? 0ull : (uint64_t) (box.hi[2] - box.lo[2]) + kBrickZ;
+    *out_layers = (layers >= G || layers >= box_layers) ? (uint32_t) G : (uint32_t) layers;
     return O2V_HIP_OK;
 }
 

@@ -21,6 +21,7 @@ struct TriHints {
     bool any_textured;
     float bounds[6];
     float max_tri_extent;
+    uint32_t ext_hist[256];  // triangles by the binary (biased) exponent of their extent
 };
 
 hipStream_t ctx_stream(o2v_hip_ctx *ctx);

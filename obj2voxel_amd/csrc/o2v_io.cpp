@@ -3,6 +3,8 @@
 // README.adoc:210-264 and, for the two palette formats, in their publishers' specifications.
 #include "o2v_io.hpp"
 
+#include <sys/mman.h>
+
 #include <zlib.h>
 
 #include <algorithm>
@@ -450,12 +452,39 @@ std::unique_ptr<TriangleSource> open_obj_file(const char *path, const obj2voxel_
 
 // ---- sinks ---------------------------------------------------------------------------------------------------
 
+ByteBuffer::~ByteBuffer() { std::free(bytes); }
+bool ByteBuffer::reserve(size_t more)
+{
+    if (size + more <= capacity) return true;
+    // (large blocks are moved by remapping their pages, not by copying: growth is cheap; a grown block of 2 MiB or more asks
+    // for huge pages - a fresh gigabyte is a quarter of a million page faults otherwise)
+    const size_t want = std::max<size_t>(size + more, capacity + capacity / 2);
+    void *p = std::realloc(bytes, want);
+    if (!p) return false;
+    bytes = static_cast<uint8_t *>(p);
+    capacity = want;
+#ifdef MADV_HUGEPAGE
+    if (want >= (2u << 20)) {
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(bytes) + 4095u) & ~(uintptr_t) 4095u, e = (reinterpret_cast<uintptr_t>(bytes) + want) & ~(uintptr_t) 4095u;
+        if (e > a) (void) madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+    }
+#endif
+    return true;
+}
+uint8_t *ByteBuffer::append(size_t n)
+{
+    if (!reserve(n)) return nullptr;
+    uint8_t *at = bytes + size;
+    size += n;
+    return at;
+}
+
 namespace {
 
-// Writes through a FILE* or into a byte vector.
+// Writes through a FILE* or into a byte buffer.
 struct ByteOut {
     std::FILE *file = nullptr;
-    std::vector<uint8_t> mem;
+    ByteBuffer mem;
     bool ok = true;
     ~ByteOut()
     {
@@ -466,8 +495,9 @@ struct ByteOut {
         if (!ok || !n) return;
         if (file) ok = std::fwrite(p, 1, n, file) == n;
         else {
-            const uint8_t *b = static_cast<const uint8_t *>(p);
-            mem.insert(mem.end(), b, b + n);
+            uint8_t *dst = mem.append(n);
+            ok = dst != nullptr;
+            if (dst) std::memcpy(dst, p, n);
         }
     }
     void patch(size_t offset, const void *p, size_t n)
@@ -478,7 +508,7 @@ struct ByteOut {
             ok = std::fseek(file, (long) offset, SEEK_SET) == 0 && std::fwrite(p, 1, n, file) == n &&
                  std::fseek(file, cur, SEEK_SET) == 0;
         }
-        else std::memcpy(mem.data() + offset, p, n);
+        else std::memcpy(mem.bytes + offset, p, n);
     }
     void flush()
     {
@@ -503,8 +533,6 @@ struct ListSink final : VoxelSink {
     bool finalized = false;
     static constexpr size_t kPlyHeader = 300;
     size_t count_offset = 0;
-    std::vector<uint8_t> scratch;
-
     ListSink(FileFormat f, bool memory) : format{f}, is_memory{memory} {}
 
     void begin()
@@ -539,9 +567,20 @@ struct ListSink final : VoxelSink {
             out.put(s.data(), s.size());
             return;
         }
-        scratch.resize(count * 16);
-        for (size_t i = 0; i < count * 4; ++i) put_be32(&scratch[i * 4], voxels[i]);
-        out.put(scratch.data(), scratch.size());
+        // big-endian words: into the memory sink's buffer directly, or in place (a sink may modify the batch) and out to the file
+        if (out.file) {
+            for (size_t i = 0; i < count * 4; ++i) voxels[i] = __builtin_bswap32(voxels[i]);
+            out.put(voxels, count * 16);
+            return;
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out.mem.append(count * 16));  // (16-byte records after a 0- or 300-byte header: 4-byte aligned)
+        out.ok = out.ok && dst != nullptr;
+        if (!dst) return;
+        for (size_t i = 0; i < count * 4; ++i) dst[i] = __builtin_bswap32(voxels[i]);
+    }
+    void expect(size_t voxels) override
+    {
+        if (!out.file && format != FileFormat::XYZRGB) out.ok = out.ok && out.mem.reserve(voxels * 16);
     }
     void finalize() override
     {
@@ -554,7 +593,7 @@ struct ListSink final : VoxelSink {
         }
         out.flush();
     }
-    const std::vector<uint8_t> *memory() const override { return is_memory ? &out.mem : nullptr; }
+    const ByteBuffer *memory() const override { return is_memory ? &out.mem : nullptr; }
 };
 
 // ---- palette formats -----------------------------------------------------------------
@@ -658,7 +697,7 @@ struct PaletteSink final : VoxelSink {
         written += count;
         voxels.insert(voxels.end(), v, v + count * 4);
     }
-    const std::vector<uint8_t> *memory() const override { return is_memory ? &out.mem : nullptr; }
+    const ByteBuffer *memory() const override { return is_memory ? &out.mem : nullptr; }
 
     // distinct colours (ascending) with their voxel counts; index[i] = position of voxel i's colour
     void collect_colors(std::vector<uint32_t> &colors, std::vector<uint64_t> &weight, std::vector<uint32_t> &index) const

@@ -38,6 +38,21 @@ struct TriangleSource {  // reference io.hpp:29-67
     virtual bool is_callback() const { return false; }
 };
 
+/// The bytes of a memory sink (obj2voxel_get_output_memory, include/obj2voxel.h): grown with realloc, never zero-filled - a
+/// 8192^3 model is hundreds of megabytes of VL32 records, and value-initialising them (std::vector) costs as much as writing them.
+struct ByteBuffer {
+    uint8_t *bytes = nullptr;
+    size_t size = 0, capacity = 0;
+    ByteBuffer() = default;
+    ByteBuffer(const ByteBuffer &) = delete;
+    ByteBuffer &operator=(const ByteBuffer &) = delete;
+    ~ByteBuffer();
+    /// room for `more` further bytes (false: out of memory)
+    bool reserve(size_t more);
+    /// `n` uninitialised bytes at the end, to be written by the caller; null if out of memory
+    uint8_t *append(size_t n);
+};
+
 struct VoxelSink {  // reference io.hpp:69-92
     size_t written = 0;
     virtual ~VoxelSink() = default;
@@ -46,7 +61,9 @@ struct VoxelSink {  // reference io.hpp:69-92
     virtual void write(uint32_t *voxels, size_t count) = 0;
     virtual void finalize() = 0;
     /// The in-memory bytes of a memory sink, else null.
-    virtual const std::vector<uint8_t> *memory() const { return nullptr; }
+    virtual const ByteBuffer *memory() const { return nullptr; }
+    /// Announces that about `voxels` more voxels are on their way (a memory sink makes room for them at once).
+    virtual void expect(size_t voxels) { (void) voxels; }
 };
 
 std::unique_ptr<TriangleSource> open_stl_file(const char *path);

@@ -38,7 +38,7 @@ class Timings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("triangles", "leaves", "tiles", "candidates", "hits", "voxels",
                                           "grid_cells", "grid_bytes", "bricks", "dirty_bricks", "pool_slots", "direct_hits", "jobs",
-                                          "certain_hits", "skipped_jobs")]
+                                          "certain_hits", "skipped_jobs", "bypassed_leaves")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

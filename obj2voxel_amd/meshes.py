@@ -82,6 +82,17 @@ def uv_sphere(nv, nu=None, radius=1.0, center=(0.0, 0.0, 0.0), with_uv=False):
     return verts
 
 
+def readme_blade(with_uv=True):
+    """Stand-in for the only workload the reference publishes a number for (README.adoc:177-178, img/terminal_screenshot.png:
+    a 19 392-triangle textured model - a sword - at resolution 8192: 20.3 M voxels): a prolate ellipsoid, 19 320 triangles
+    (uv_sphere(70) with two axes scaled by 0.0806), whose surface at 8192^3 is ~13 M voxel faces wide - some 20 M voxels in a
+    long thin box of the grid, which is what makes that workload the worst case of a dense grid and the best of a sparse map."""
+    v, uv = uv_sphere(70, with_uv=True)
+    v = v.reshape(-1, 3, 3) * np.array([0.0806, 1.0, 0.0806], dtype=np.float32)
+    v = np.ascontiguousarray(v.reshape(-1, 9), dtype=np.float32)
+    return (v, uv) if with_uv else v
+
+
 def triangle_colors(T):
     """Per-triangle colours ((37i)%256, (91i)%256, (13i)%256)/255."""
     i = np.arange(T, dtype=np.int64)

@@ -38,6 +38,12 @@ def _textured(nv):
     return make
 
 
+def _blade():
+    v, uv = meshes.readme_blade()
+    T = len(v)
+    return v, dict(uvs=uv, types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32)), [(meshes.checker_texture(1024, 32), 1)]
+
+
 def _sponza():
     room = meshes.box_room(16)
     sph, suv = meshes.uv_sphere(255, radius=0.3, center=(0.5, 0.45, 0.55), with_uv=True)
@@ -58,13 +64,15 @@ WORKLOADS = {
     "config1": (_textured(39), 512, dict(strategy=1), "BASELINE configs[1] stand-in: uv-sphere nv=39 (5 928 tris) @512^3, textured, BLEND"),
     "config3": (_sponza, 2048, dict(strategy=1, supersampling=2), "BASELINE configs[3] stand-in: box room + sphere (262 092 textured tris) @2048^3 x2 supersampling, BLEND"),
     "config3_max": (_sponza, 2048, dict(strategy=0, supersampling=2), "configs[3] stand-in with MAX"),
+    "readme8192": (_blade, 8192, dict(strategy=0), "stand-in of the reference README's showcase run: 19 320 textured triangles (a long thin ellipsoid) @8192^3, MAX - "
+                   "the dense grids cover the mesh's voxel bounding box (8192 x ~670 x ~670 cells), not the cube"),
     "cube1024": (lambda: (meshes.unit_cube(), {}, None), 1024, dict(strategy=0), "unit cube @1024^3 (12 aligned triangles)"),
     "room2048": (lambda: (meshes.box_room(8), {}, None), 2048, dict(strategy=0), "box room 8x8 quads per wall @2048^3"),
     "lowpoly1024": (_sphere(12), 1024, dict(strategy=0), "sphere nv=12 @1024^3 (subdivision heavy)"),
 }
 
 # the routes bench.py times after its headline (N = 1), in this order
-BENCH_ROUTES = ("config2_colored_max", "config2_blend", "config2_textured_max", "scan_colored_max", "config1", "config3")
+BENCH_ROUTES = ("config2_colored_max", "config2_blend", "config2_textured_max", "scan_colored_max", "config1", "config3", "readme8192")
 
 # real assets: file stem under $O2V_ASSETS -> (BASELINE configuration it belongs to, resolution, voxelize keywords)
 ASSETS = {
@@ -177,9 +185,14 @@ def kernel_algorithmic_bytes(stats, textured, strategy_blend):
         out["k_scatter"] = (32 + 4 + rec) * slots
         out["k_reset_bricks"] = 4 * cpb * D
         out["k_resolve<6>" if textured else "k_resolve<4>"] = 16 * V + rec * Hp + 16 * V   # (all tiers together: cells + records + output)
-    if direct and stats.get("certain_hits"):
-        # occupancy-only mode: a job record per remaining voxel job, a byte and a flag per hit; 64 bytes per dirty brick
-        out["k_voxelize<false>"] = 96 * L + 8 * tiles + 16 * jobs + 2 * H
+    if direct and (stats.get("certain_hits") or stats.get("bypassed_leaves")):
+        # occupancy-only mode: root triangles of one tile have no Leaf / Tile record (both kernels read their 36 bytes); a job
+        # record per voxel job, written, read by the filter, the live ones written and read once more; a byte and a flag per
+        # hit; 64 bytes per dirty brick
+        Lb = stats.get("bypassed_leaves", 0)
+        out.pop("k_voxelize<false>", None)
+        out["k_expand_roots"] = 36 * T + 96 * (L - Lb) + 8 * (tiles - Lb)
+        out["k_voxelize_occ"] = 36 * T + 96 * (L - Lb) + 8 * (tiles - Lb) + 16 * jobs + 16 * (jobs - stats.get("skipped_jobs", 0)) + 2 * H
         out["k_emit_occ"] = 2 * cpb * D + 16 * V
     elif direct:
         out["k_emit_max"] = 8 * cpb * D + 32 * V + 16 * V

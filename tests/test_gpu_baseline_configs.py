@@ -128,6 +128,11 @@ def test_config3_sponza_standin_2048_ss2_textured(dv, all_cores, strategy):
     assert len(got) > 30_000_000
 
 
+def _timed(d, res, zslab, bnd):
+    d.voxelize(res, zslab=zslab, bounds=bnd, read=False)
+    return d.timings()["total_ms"]
+
+
 def test_config4_50m_sphere_4096_eight_planned_slabs(dv, all_cores):
     """configs[4]: every one of the 8 work-balanced z-slabs (what each GPU of the node computes) equals the oracle's
     voxels of that slab; the slabs tile the grid, so their union is the whole model."""
@@ -140,7 +145,7 @@ def test_config4_50m_sphere_4096_eight_planned_slabs(dv, all_cores):
     d.set_triangles(v)
     cuts, bnd = d.plan_slabs(res, n)
     assert cuts[0] == 0 and cuts[-1] == res and all(a < b for a, b in zip(cuts, cuts[1:]))
-    hits, leaves, total = [], [], 0
+    hits, leaves, total, slab_ms = [], [], 0, []
     for r in range(n):
         got = meshes.sorted_voxels(d.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd))
         hits.append(d.stats()["hits"] + d.stats()["skipped_jobs"])   # (skipped: jobs of voxels that were marked already)
@@ -151,9 +156,47 @@ def test_config4_50m_sphere_4096_eight_planned_slabs(dv, all_cores):
         assert np.array_equal(got, want[lo:hi]), f"slab {r} differs from the oracle"
         total += len(got)
         del got
+        # the slab once more, timed (buffers sized, nothing read back): what the plan is for - see below
+        d.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False)
+        slab_ms.append(min(d.timings()["total_ms"], _timed(d, res, (cuts[r], cuts[r + 1]), bnd)))
     assert total == len(want) > 70_000_000
+    # ... and a check that does not use the planner's own cost model: the measured device time of the eight slabs (the 8-GPU
+    # job's critical path is the slowest one) is balanced
+    assert max(slab_ms) < 1.10 * sum(slab_ms) / n, (cuts, slab_ms)
     # the plan balances predicted TIME: hits + 4 hit equivalents per leaf (k_zhist: measured on these very slabs in round 3,
     # where equal hits left the equatorial slabs, with 1.5 x the leaves, 7 % slower than the mean)
     work = [h + 4.0 * l for h, l in zip(hits, leaves)]
     assert max(work) < 1.03 * sum(work) / n, (cuts, hits, leaves)
     assert max(hits) < 1.15 * sum(hits) / n, (cuts, hits)
+
+
+def test_readme_showcase_standin_8192_through_the_c_api(all_cores):
+    """The one workload the reference publishes a number for (README.adoc:177-178, img/terminal_screenshot.png: 19 392 textured
+    triangles at r = 8192, MAX, VL32 -> 20.3 M voxels): its stand-in (meshes.readme_blade: 19 320 textured triangles) at full
+    size through obj2voxel_voxelize() with the VL32 memory sink, every record against the oracle.  The dense grids cover the
+    mesh's voxel bounding box (8192 x ~670 x ~670 cells), so the run needs one pass where the 8192^3 cube would take dozens of
+    z-slabs."""
+    import ctypes as C
+    from obj2voxel_amd import capi
+    a = capi.api()
+    v, uv = meshes.readme_blade()
+    pix = meshes.checker_texture(1024, 32)
+    tex = a.obj2voxel_texture_alloc()
+    assert a.obj2voxel_texture_load_pixels(tex, pix.ctypes.data, 1024, 1024, 3)
+    inst = a.obj2voxel_alloc()
+    inp = capi.TriangleInput(v, uvs=uv, texture=tex)
+    a.obj2voxel_set_input_callback(inst, inp.callback, None)
+    a.obj2voxel_set_output_memory(inst, b"vl32")
+    a.obj2voxel_set_resolution(inst, 8192)
+    a.obj2voxel_set_color_strategy(inst, capi.MAX_STRATEGY)
+    assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
+    size = C.c_size_t(0)
+    ptr = a.obj2voxel_get_output_memory(inst, C.byref(size))
+    assert bool(ptr) and size.value % 16 == 0
+    rec = np.ctypeslib.as_array(ptr, shape=(size.value,)).copy().view(">u4").reshape(-1, 4).astype(np.uint32)  # VL32: big-endian x, y, z, argb
+    a.obj2voxel_free(inst)
+    a.obj2voxel_texture_free(tex)
+    T = len(v)
+    want = all_cores.voxelize(v, 8192, uvs=uv, types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32), textures=[(pix, 1)], strategy=0)
+    assert 15_000_000 < len(want) < 25_000_000
+    _equal(rec, want)

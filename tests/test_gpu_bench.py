@@ -52,7 +52,7 @@ def test_bench_line_routes_and_assets(tmp_path):
     assert "dragon.obj" in line["config"]["workload"] and line["config"]["triangles"] == len(meshes.uv_sphere(40))
     names = [x["workload"] for x in line["routes"]]
     assert names[0] == "config2" and "asset:spot" in names and "asset:sponza" not in names
-    for want in ("config2_colored_max", "config2_blend", "config2_textured_max", "config1", "config3"):
+    for want in ("config2_colored_max", "config2_blend", "config2_textured_max", "config1", "config3", "readme8192"):
         assert want in names
     for x in line["routes"]:
         assert "error" not in x, x
@@ -81,3 +81,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert sum(col["per_collective_ms_rank0"].values()) > 0
     up = line["config"]["upload"]
     assert up["h2d_per_rank_ms"] > 0 and "h2d_rank0_plus_rccl_broadcast_ms" not in up
+    # both curves: the weak-scaling series' value, and what the two "GPUs" gain on this very job (here they share one device,
+    # so the figure itself means nothing; the job's slabs run one after the other must give the same voxels)
+    assert line["scaling"] == "weak" and col["rccl_world_size"] is None
+    ss = line["strong_scaling_same_job"]
+    assert ss["voxels_match"] is True and ss["one_gpu_ms"] > 0 and ss["n_gpu_ms"] > 0 and abs(ss["speedup"] - ss["one_gpu_ms"] / ss["n_gpu_ms"]) < 0.01

@@ -131,6 +131,57 @@ def test_unit_transform_and_bounds(dv, oracle):
     _compare(got, want)
 
 
+@pytest.mark.parametrize("unit", [[1, 0, 0, 0, 1, 0, 0, 0, 1], [0, -1, 0, 0, 0, -1, -1, 0, 0], [0, 0, 1, -1, 0, 0, 0, 1, 0], [-1, 0, 0, 0, -1, 0, 0, 0, -1]])
+@pytest.mark.parametrize("mode", ["blend_ss2", "max", "occupancy"])
+def test_grid_covers_the_mesh_box_wherever_it_lies(dv, oracle, unit, mode):
+    """The dense grids are allocated for the mesh's voxel bounding box, not the cube (o2v_hip_voxelize: grid_box).  A long thin
+    mesh, turned and mirrored by the unit transform so that its box lies along every axis and at either end of the grid (mirrored
+    axes put it at the far end: a grid origin above zero in x, y and z), whole and in z-slabs that cut the box or miss it."""
+    from obj2voxel_amd import hip
+    v, uv = meshes.readme_blade()
+    v, uv = v[::3], uv[::3]
+    T = len(v)
+    res = 300
+    if mode == "blend_ss2":
+        kw = dict(uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32), texids=np.zeros(T, np.int32),
+                  textures=[(meshes.checker_texture(64, 8), 1)], strategy=1, supersampling=2)
+    elif mode == "max":
+        kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=0)
+    else:
+        kw = {}
+    got, want = _run_both(dv, oracle, v, res, unit_transform=unit, **kw)
+    _compare(got, want)
+    assert len(want) > 3000
+    st = dv.stats()
+    assert st["grid_cells"] < res ** 3 // 20, st        # a twelfth of the cube's width in two axes
+    # slabs: one inside the box, one cutting its end, one that misses it (no voxels, no error)
+    zs = np.sort(meshes.sorted_voxels(want)[:, 2])
+    zmid = int(zs[len(zs) // 2])
+    parts = []
+    for zslab in ((0, max(zmid - 5, 1)), (max(zmid - 5, 1), zmid + 7), (zmid + 7, res)):
+        g, w = _run_both(dv, oracle, v, res, unit_transform=unit, zslab=zslab, **kw)
+        _compare(g, w)
+        parts.append(g)
+    assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), meshes.sorted_voxels(got))
+
+
+def test_no_max_grid_for_a_mesh_of_large_triangles(dv, oracle):
+    """MAX strategy: the direct path's 64-bit grid (two thirds of the grids' memory) is not allocated when three quarters of
+    the triangles are large enough to be subdivided anyway (grid_modes: the triangles' extents are known since the upload) -
+    the sort-and-replay route computes the same voxels.  A fine mesh keeps it."""
+    from obj2voxel_amd import hip
+    for nv, res, direct in ((12, 384, False), (60, 96, True)):
+        v = meshes.uv_sphere(nv)
+        T = len(v)
+        kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=0)
+        got, want = _run_both(dv, oracle, v, res, **kw)
+        _compare(got, want)
+        st = dv.stats()
+        assert (st["direct_hits"] > 0) == direct, st
+        per_cell = st["grid_bytes"] / st["grid_cells"]
+        assert (per_cell > 12.0) == direct and per_cell > 4.0, (per_cell, st)   # 4 + 8 bytes per cell (+ flags), or 4
+
+
 def test_non_multiple_of_four_resolution(dv, oracle):
     got, want = _run_both(dv, oracle, meshes.uv_sphere(8), 77)
     _compare(got, want)

@@ -80,3 +80,25 @@ def test_rccl_selftest_reports_a_missing_library():
     )
     r = _run(code, O2V_RCCL_LIB="/nonexistent/librccl-missing.so")
     assert r.returncode == 0 and r.stdout.strip() == "100", (r.returncode, r.stdout, r.stderr)
+
+
+def test_a_rank_that_never_arrives_fails_the_others_with_a_message(tmp_path):
+    """ncclCommInitRank blocks until every rank of the job has called it; on a node that is set up wrongly (a process that
+    died, two ranks on one GPU, another unique id) the ranks that did arrive used to wait for ever.  With the mock librccl:
+    rank 0 of a world of two is alone, O2V_COMM_TIMEOUT_S = 1 - the call returns an error, with the reason, after a second."""
+    code = (
+        "import ctypes as C, time\n"
+        "from obj2voxel_amd import hip\n"
+        "L = hip._bind()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "assert L.o2v_hip_comm_unique_id(buf) == 0\n"
+        "h = C.c_void_p()\n"
+        "t0 = time.time()\n"
+        "rc = L.o2v_hip_comm_create_rccl(buf, 0, 2, -1, C.byref(h))\n"
+        "dt = time.time() - t0\n"
+        "assert rc != 0 and not h.value and 0.9 < dt < 20, (rc, h.value, dt)\n"
+        "print('ok')\n"
+    )
+    r = _run(code, O2V_RCCL_LIB=_mock_rccl(tmp_path), O2V_COMM_TIMEOUT_S="1")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout, r.stderr)
+    assert "ncclCommInitRank did not return within 1 s (rank 0 of 2)" in r.stderr

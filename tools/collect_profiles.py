@@ -11,7 +11,8 @@ import re
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+N_SIMDS, CLOCK_GHZ = 256 * 4, 2.4   # as bench.py
 src = "gpurun_out/prof"
 out_dir = os.path.join("profiles", rnd)
 os.makedirs(out_dir, exist_ok=True)
@@ -42,7 +43,7 @@ def counters(path):
 
 
 summary = {}
-for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_max", "scan_colored_max", "config1", "config3"):
+for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_max", "scan_colored_max", "config1", "config3", "readme8192"):
     stats = find(f"{src}/{w}_stats/**/s_kernel_stats.csv")
     if not stats:
         continue
@@ -69,8 +70,17 @@ for w in ("config2", "config2_colored_max", "config2_blend", "config2_textured_m
             sq.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in d.items()})
     for k, d in sq.items():
         if k in kernels and d.get("SQ_INSTS_VALU", 0) > 1e6:
-            d["derived"] = {"active_lanes_per_valu_instruction": round(d["SQ_THREAD_CYCLES_VALU"] / d["SQ_INSTS_VALU"], 1),
-                            "valu_issue_fraction_of_peak_at_2_cycles": None}
+            us = kernels[k]["avg_us"]
+            d["derived"] = {
+                # every figure from the counters of this file and the kernel's average duration (avg_us), one formula each:
+                "active_lanes_per_valu_instruction": round(d["SQ_THREAD_CYCLES_VALU"] / d["SQ_INSTS_VALU"], 1),
+                "active_lane_fraction": round(d["SQ_THREAD_CYCLES_VALU"] / d["SQ_INSTS_VALU"] / 64.0, 3),
+                # SQ_INSTS_VALU / avg_us against one wave64 VALU instruction per 2 cycles per SIMD (1024 SIMDs x 2.4 GHz / 2)
+                "valu_issue_fraction_of_peak_at_2_cycles": round(d["SQ_INSTS_VALU"] / (us * 1e-6) / (N_SIMDS * CLOCK_GHZ * 1e9 / 2.0), 4),
+                # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD's VALU is executing, summed over the SIMDs:
+                # x 4 / 1024 SIMDs / (avg_us x 2.4 GHz) = the fraction of the kernel's duration the VALUs are busy
+                "valu_busy": round(d["SQ_ACTIVE_INST_VALU"] * 4.0 / N_SIMDS / (us * 1e-6 * CLOCK_GHZ * 1e9), 3) if d.get("SQ_ACTIVE_INST_VALU") else None,
+                "simd_cycles_per_valu_instruction": round(us * 1e-6 * CLOCK_GHZ * 1e9 * N_SIMDS / d["SQ_INSTS_VALU"], 2)}
             kernels[k]["sq"] = d
     line = None
     lp = os.path.join(src, f"{w}_line.json")
@@ -114,7 +124,7 @@ if "config2" in summary:
         for k, v in doc["kernels"].items():
             e = {f: v[f] for f in keep if f in v}
             if "sq" in v:
-                e["sq"] = {c: v["sq"][c] for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY") if c in v["sq"]}
+                e["sq"] = {c: v["sq"][c] for c in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "derived") if c in v["sq"]}
             ks[k] = e
         cur["workloads"][w] = {"source": f"profiles/{rnd}/{w}_profile.json", "kernels": ks,
                                "workload_stats": (doc.get("result_line") or {}).get("stats")}

@@ -75,8 +75,9 @@ def compile_asm(extra=()):
 
 
 def kernel_body(lines, variant):
-    """variant: 'Lb0E' = k_voxelize<false>, 'Lb1E' = k_voxelize<true>"""
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN\S*k_voxelizeI" + variant + r"\S*:", l))
+    """variant: 'Lb0E' = k_voxelize<false>, 'Lb1E' = k_voxelize<true>, '_occ' = k_voxelize_occ"""
+    pat = r"^_ZN\S*k_voxelize_occ\S*:" if variant == "_occ" else r"^_ZN\S*k_voxelizeI" + variant + r"\S*:"
+    start = next(i for i, l in enumerate(lines) if re.match(pat, l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     return [l.strip() for l in lines[start + 1:end]]
 
@@ -165,7 +166,7 @@ def summarize(ops, rates):
 def analyze(asm_path, rates):
     lines = open(asm_path).read().splitlines()
     out = {}
-    for variant, name in (("Lb0E", "k_voxelize<false>"), ("Lb1E", "k_voxelize<true>")):
+    for variant, name in (("Lb0E", "k_voxelize<false>"), ("Lb1E", "k_voxelize<true>"), ("_occ", "k_voxelize_occ")):
         body = kernel_body(lines, variant)
         s = summarize(histogram(body, clip_loop(body)), rates)
         whole = summarize(histogram(body, range(len(body))), rates)
@@ -187,7 +188,7 @@ def source_build_id():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r03", "valu_rates.json"))
+    ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r04", "valu_rates.json"))
     ap.add_argument("--asm")
     ap.add_argument("--json")
     ap.add_argument("-v", action="store_true")
@@ -198,10 +199,13 @@ def main():
     res["rates_file"] = os.path.relpath(a.rates, ROOT)
     res["build_id"] = source_build_id()
     res["note"] = ("static histogram of the clip loop (phase 2 of k_voxelize), priced with the w4 column of the rates file; "
-                   "mix_cycles_per_valu x (VALU instructions of a launch) / (SIMDs x clock) is the mix-weighted minimum issue time")
+                   "mix_cycles_per_valu x (VALU instructions of a launch) / (SIMDs x clock) is the mix-weighted minimum issue time. "
+                   "A model: the histogram is static (every instruction of the loop counted once, whatever its branch executes "
+                   "how often), and k_voxelize_occ spends most of its time outside this loop (phase 1): for it use "
+                   "whole_kernel_mix_cycles_per_valu, with the same caveat")
     if a.json:
         json.dump(res, open(a.json, "w"), indent=1)
-    for k in ("k_voxelize<false>", "k_voxelize<true>"):
+    for k in ("k_voxelize<false>", "k_voxelize<true>", "k_voxelize_occ"):
         s = res[k]
         print(f"{k}: clip loop {s['valu']} VALU ({s['valu_classes']}), {s['salu']} SALU, {s['branch']} branches, {s['lds']} LDS, "
               f"{s['vmem']} VMEM; mix {s['mix_cycles_per_valu']:.2f} cycles per VALU instruction (whole kernel: {s['whole_kernel_valu']} VALU, "

@@ -127,6 +127,8 @@ struct Counters {
     unsigned long long n_jobs_skipped;  // occupancy-only mode: jobs dropped before phase 2 because their voxel was marked already
     uint32_t n_listed_hits, pad3;       // k_scan_bricks: the counters of the listed bricks' cells added up (modulo 2^32): must equal
                                         // the hits k_voxelize counted into the grid (n_hits - n_direct), see o2v_hip_voxelize
+    unsigned long long n_candidates_sq; // sum over the leaves of (candidates of the leaf)^2: with n_candidates and the number of leaves, how
+                                        // unequal the leaves are (k_voxelize sizes the batches of its last quarter by it)
     unsigned long long n_bypass;        // Params::root_bypass: root triangles that k_voxelize_occ stages itself (no Leaf, no Tile)
     unsigned long long dbg[16];  // event counts of an instrumented build (-DO2V_INSTRUMENT, tools/instrument.sh); else zero
     uint32_t ext_hist[256];      // k_tri_extent (at upload time only): triangles by the binary exponent of their extent

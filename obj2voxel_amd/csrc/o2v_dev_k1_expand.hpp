@@ -91,6 +91,13 @@ __device__ __forceinline__ void write_tiles(Tile *tiles, BigLeaf *big, uint32_t 
     }
 }
 
+// (for Counters::n_candidates_sq: how unequal the leaves are - a leaf of more than 65 535 candidates counts as one of 65 535)
+__device__ __forceinline__ unsigned long long leaf_size_squared(uint64_t count)
+{
+    const unsigned long long n = count < 65535ull ? count : 65535ull;
+    return n * n;
+}
+
 struct Emit {  // what one lane wants to append this round
     uint32_t n_leaf, n_tile, n_big, n_node;
 };
@@ -202,10 +209,10 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
     __shared__ uint32_t s_base[4];
     __shared__ float s_v[kBlock * 9];
     __shared__ float s_t[kBlock * 6];
-    __shared__ unsigned long long s_cand;
-    __shared__ unsigned long long s_bypass[2];  // Params::root_bypass: this workgroup's bypassed triangles and their candidates
-    unsigned long long my_bypass = 0, my_bypass_cand = 0;
-    if (threadIdx.x < 2) s_bypass[threadIdx.x] = 0;
+    __shared__ unsigned long long s_cand, s_cand_sq;
+    __shared__ unsigned long long s_bypass[3];  // Params::root_bypass: this workgroup's bypassed triangles, their candidates, the squares
+    unsigned long long my_bypass = 0, my_bypass_cand = 0, my_bypass_sq = 0;
+    if (threadIdx.x < 3) s_bypass[threadIdx.x] = 0;
 
     Affine xf;
     xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
@@ -333,6 +340,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
             if (bypassed) {
                 my_bypass += 1;
                 my_bypass_cand += pl.count;
+                my_bypass_sq += leaf_size_squared(pl.count);
             }
             sum.n_leaf += e.n_leaf;
             sum.n_tile += e.n_tile;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         // ranks of a multi-GPU run, where every rank filters the whole triangle list)
         if (!__syncthreads_or((int) (sum.n_leaf | sum.n_node))) continue;
         BlockSlots slot = reserve_slots(sum, c, 0, s_wave, s_base);
-        if (threadIdx.x == 0) s_cand = 0;
+        if (threadIdx.x == 0) s_cand = s_cand_sq = 0;
         // pass 2: the same triangles again, now written to their slots
         for (uint32_t k = 0; k < kRootBatch; ++k) {
             const uint64_t at = sblk * kRootBatch + k, blk = block_at(at);
@@ -355,6 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
                 if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, s, tri, 0u, area, pl);
                 write_tiles(tiles, big, slot.leaf, slot.tile, pl.ntiles, slot.big, p);
                 atomicAdd(&s_cand, pl.count);
+                atomicAdd(&s_cand_sq, leaf_size_squared(pl.count));
                 slot.leaf += 1;
                 slot.tile += pl.ntiles;
                 slot.big += e.n_big;
@@ -377,7 +386,10 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
+        if (threadIdx.x == 0 && s_cand) {
+            atomicAdd(&c->n_candidates, s_cand);
+            atomicAdd(&c->n_candidates_sq, s_cand_sq);
+        }
     }
     if (p.root_bypass) {
         // (one pair of global atomics per workgroup, not per super-block: they serialise at ~88 per us)
@@ -385,11 +397,13 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         if (my_bypass) {
             atomicAdd(&s_bypass[0], my_bypass);
             atomicAdd(&s_bypass[1], my_bypass_cand);
+            atomicAdd(&s_bypass[2], my_bypass_sq);
         }
         __syncthreads();
         if (threadIdx.x == 0 && s_bypass[0]) {
             atomicAdd(&c->n_bypass, s_bypass[0]);
             atomicAdd(&c->n_candidates, s_bypass[1]);
+            atomicAdd(&c->n_candidates_sq, s_bypass[2]);
         }
     }
 }
@@ -417,14 +431,14 @@ __global__ __launch_bounds__(kBlock) void k_expand_nodes(const Node *__restrict_
 {
     __shared__ __align__(8) uint32_t s_wave[2 * (kBlock / 64)];
     __shared__ uint32_t s_base[4];
-    __shared__ unsigned long long s_cand;
+    __shared__ unsigned long long s_cand, s_cand_sq;
     const uint32_t n_in = c->n_nodes[round] < p.cap_nodes ? c->n_nodes[round] : p.cap_nodes;
     const uint32_t n_blocks = (n_in + kBlock - 1) / kBlock;
     for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint32_t i = blk * kBlock + threadIdx.x;
         const bool live = i < n_in;
         __syncthreads();
-        if (threadIdx.x == 0) s_cand = 0;
+        if (threadIdx.x == 0) s_cand = s_cand_sq = 0;
         Sub ch[4];
         LeafPlan pl[4];
         uint32_t kind[4] = {0, 0, 0, 0};  // 0 drop, 1 leaf, 2 node
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_nodes(const Node *__restrict_
         }
         BlockSlots slot = reserve_slots(e, c, round + 1, s_wave, s_base);
         if (live) {
-            unsigned long long cand = 0;
+            unsigned long long cand = 0, cand_sq = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 // child digit at this level, then the terminator bit one position below it
@@ -483,6 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_nodes(const Node *__restrict_
                     if (slot.leaf < p.cap_leaves) write_leaf(leaves, slot.leaf, ch[k], tri, key, area, pl[k]);
                     write_tiles(tiles, big, slot.leaf, slot.tile, pl[k].ntiles, slot.big, p);
                     cand += pl[k].count;
+                    cand_sq += leaf_size_squared(pl[k].count);
                     slot.leaf += 1;
                     slot.tile += pl[k].ntiles;
                     slot.big += pl[k].ntiles > kInlineTiles ? 1u : 0u;
@@ -505,10 +520,16 @@ __global__ __launch_bounds__(kBlock) void k_expand_nodes(const Node *__restrict_
                     slot.node += 1;
                 }
             }
-            if (cand) atomicAdd(&s_cand, cand);
+            if (cand) {
+                atomicAdd(&s_cand, cand);
+                atomicAdd(&s_cand_sq, cand_sq);
+            }
         }
         __syncthreads();
-        if (threadIdx.x == 0 && s_cand) atomicAdd(&c->n_candidates, s_cand);
+        if (threadIdx.x == 0 && s_cand) {
+            atomicAdd(&c->n_candidates, s_cand);
+            atomicAdd(&c->n_candidates_sq, s_cand_sq);
+        }
     }
 }
 

@@ -613,13 +613,53 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
     }
     tiles_per_batch = tiles_per_batch < kMinTilesPerBatch ? kMinTilesPerBatch
                       : (tiles_per_batch > kVoxTiles ? kVoxTiles : tiles_per_batch);
-    const uint32_t n_list_batches = (n_tiles + tiles_per_batch - 1) / tiles_per_batch;
-    // a root batch is 2^k consecutive triangles of one block (4 .. 256: the largest power of two a batch holds)
-    const uint32_t root_shift = 31u - (uint32_t) __clz((int) tiles_per_batch);
-    const uint32_t root_per_block_shift = 8u - root_shift;  // log2 of the root batches per block of 256 triangles
+    // The kernel ends when its last batch does, and a workgroup gets only a few batches: where the batches' costs differ a lot -
+    // leaves of very unequal sizes - the last ones decide how long most of the machine waits.  The batches of the last quarter
+    // of the work are then a quarter as large (measured on the irregular bench mesh, leaf areas 380 : 1: k_voxelize<false> 1.13 ->
+    // 0.92 ms; on a uniform tessellation the smaller batches only cost their fixed part again: 0.94 -> 1.01 ms, occupancy only 0.38
+    // -> 0.45 - so it depends on the spread of the leaves' candidate counts, which k_expand_* leave in the counters).  The
+    // one-wavefront workgroups of the uv variant always do it (their batches are a quarter as large to begin with; uniform
+    // sphere 1.59 -> 1.53 ms, configs[3] 14.1 -> 13.8).
+    // A work list of n items (the tile list; the sequence of root triangles) is cut into `full` batches of `size` items and,
+    // behind them, batches of `small` items.
+    bool taper = UV;
+    {
+        const double n_l = (double) c->n_leaves + (double) c->n_bypass, sum = (double) c->n_candidates, sq = (double) c->n_candidates_sq;
+        // (variance of the leaves' candidate counts against their squared mean: above 1/2 the leaves are "very unequal")
+        if (n_l > 0.0 && sq * n_l > 1.5 * sum * sum) taper = true;
+    }
+#ifdef O2V_NO_TAPER
+    taper = false;
+#endif
+    struct BatchPlan {
+        uint64_t n;
+        uint32_t size, small, full;
+        uint64_t count;  // batches in all
+        __device__ __forceinline__ void make(uint64_t items, uint32_t batch_size, bool taper)
+        {
+            n = items;
+            size = batch_size;
+            small = (taper && batch_size >= 4u * kMinTilesPerBatch) ? batch_size / 4u : batch_size;
+            full = taper ? (uint32_t) std::min<uint64_t>((items - items / 4u) / batch_size, 0x7fffffffull) : 0u;
+            const uint64_t rest = items - (uint64_t) full * size;
+            count = full + (rest + small - 1u) / small;
+        }
+        // batch b: its first item and the number of its items
+        __device__ __forceinline__ uint64_t at(uint64_t b, uint32_t &items) const
+        {
+            const uint64_t start = b < full ? b * size : (uint64_t) full * size + (b - full) * small;
+            const uint32_t want = b < full ? size : small;
+            items = start >= n ? 0u : (uint32_t) std::min<uint64_t>(want, n - start);
+            return start;
+        }
+    };
+    BatchPlan list_plan, root_plan;
+    list_plan.make(n_tiles, tiles_per_batch, taper);
     static_assert(kTilesPerBatch == 256u && kBlock == 256u, "blocks of 256 triangles");
-    const uint64_t n_root_batches64 = n_seq_blocks << root_per_block_shift;
-    const uint32_t n_batches = (uint32_t) std::min<uint64_t>((uint64_t) n_list_batches + n_root_batches64, 0xffffffffull);
+    // (the root triangles: the positions 0 .. 256 n_seq_blocks of the block sequence; the last block may be partly filled)
+    root_plan.make(n_seq_blocks * kTilesPerBatch, tiles_per_batch, taper);
+    const uint32_t n_list_batches = (uint32_t) std::min<uint64_t>(list_plan.count, 0xffffffffull);
+    const uint32_t n_batches = (uint32_t) std::min<uint64_t>(list_plan.count + root_plan.count, 0xffffffffull);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t chunk_base = 0, chunk_used = kHitChunk;  // wave-uniform; forces a reservation at first use
 #ifdef O2V_INSTRUMENT
@@ -658,18 +698,15 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
             // a root batch: the leaves are made here, from the vertex array, as k_expand_roots makes them (applyMeshTransform,
             // obj2voxel.cpp:202-224; the head of voxelizeTriangleToUvBuffer, voxelization.cpp:488-511; write_leaf); a triangle
             // that is not a leaf of one tile (k_expand_roots handled it, or it misses the slab) leaves its tile slot empty
-            const uint32_t rb = batch - n_list_batches;
-            const uint64_t seq = rb >> root_per_block_shift;
-            const uint64_t blk = blocks_listed ? (uint64_t) block_list[seq] : seq;
-            const uint64_t tri0 = blk * kTilesPerBatch + ((uint64_t) (rb & ((1u << root_per_block_shift) - 1u)) << root_shift);
-            nt = tri0 < p.n_tris ? (uint32_t) std::min<uint64_t>(1ull << root_shift, p.n_tris - tri0) : 0u;
-            // (coalesced: the batch's 9 nt floats as they lie in memory, then a lane picks its triangle's nine out of LDS)
-            for (uint32_t i = threadIdx.x; i < nt * 9u; i += kVoxBlock) s_leaf[i] = __float_as_uint(verts[tri0 * 9u + i]);
-            __syncthreads();
+            // (a run of positions of the block sequence: consecutive triangles, except where the run crosses from one listed
+            // block into the next)
+            const uint64_t pos0 = root_plan.at(batch - n_list_batches, nt);
+            const uint64_t pos = pos0 + threadIdx.x;
+            const uint64_t tri = blocks_listed ? (uint64_t) block_list[pos >> 8] * kTilesPerBatch + (pos & 255u) : pos;
+            const bool have = threadIdx.x < nt && tri < p.n_tris;
             float q[9];
 #pragma unroll
-            for (uint32_t j = 0; j < 9; ++j) q[j] = threadIdx.x < nt ? __uint_as_float(s_leaf[threadIdx.x * 9u + j]) : 0.f;
-            __syncthreads();
+            for (uint32_t j = 0; j < 9; ++j) q[j] = have ? verts[tri * 9u + j] : 0.f;
             if (threadIdx.x < nt) {
                 Affine xf;
                 xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
@@ -681,13 +718,13 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                 sb.v1 = affine_apply(xf, V3{q[3], q[4], q[5]});
                 sb.v2 = affine_apply(xf, V3{q[6], q[7], q[8]});
                 LeafPlan pl{};
-                const bool is_leaf = root_leaf_of_one_tile(sb, p, pl);
+                const bool is_leaf = have && root_leaf_of_one_tile(sb, p, pl);
                 uint32_t *lw = &s_leaf[threadIdx.x * kLeafStride];
                 const V3 nrm = normalize(tri_normal(sb.v0, sb.v1, sb.v2));  // voxelization.cpp:438
                 const float vals[12] = {sb.v0.x, sb.v0.y, sb.v0.z, sb.v1.x, sb.v1.y, sb.v1.z, sb.v2.x, sb.v2.y, sb.v2.z, nrm.x, nrm.y, nrm.z};
 #pragma unroll
                 for (uint32_t j = 0; j < 12; ++j) lw[j] = is_leaf ? __float_as_uint(vals[j]) : 0u;
-                lw[18] = (uint32_t) (tri0 + threadIdx.x);
+                lw[18] = (uint32_t) tri;
                 lw[19] = 0u;  // order key of an unsplit triangle
                 lw[20] = is_leaf ? pl.lo[0] | (pl.lo[1] << 16) : 0u;
                 lw[21] = is_leaf ? pl.lo[2] | (pl.d[0] << 16) : 0u;   // (an empty slot: a box of no cells)
@@ -698,8 +735,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
             __syncthreads();
         }
         else {
-            const uint32_t first = batch * tiles_per_batch;
-            nt = n_tiles - first < tiles_per_batch ? n_tiles - first : tiles_per_batch;
+            const uint32_t first = (uint32_t) list_plan.at(batch, nt);
             if (threadIdx.x < nt) {
                 const Tile t = tiles[first + threadIdx.x];
                 s_tleaf[threadIdx.x] = t.leaf;

@@ -147,6 +147,34 @@ KERNEL_SEQ(seq_cnd_vcc_and_sgpr_masks, "v_cmp_lt_f32 vcc, %0, %8\n v_cmp_gt_f32 
            "v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, s[22:23]\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cndmask_b32_e64 %4, %4, %8, s[22:23]\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e64 %6, %6, %8, s[22:23]\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
            "v_cndmask_b32_e64 %1, %1, %8, s[22:23]\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, s[22:23]\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e64 %5, %5, %8, s[22:23]\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e64 %7, %7, %8, s[22:23]\n")
 
+// ---- operand banks -------------------------------------------------------------------------------------------------
+// The loops above let the compiler pick the registers.  These name them: a VGPR's bank is its number modulo 4, and an
+// instruction whose source operands sit in one bank could need extra read cycles.  If the 4-cycle class (v_fma, v_max, compares,
+// selects) were an artefact of such conflicts in the loops above, the "distinct banks" form would run at the 2-cycle rate of
+// v_mul / v_add; if it is the hardware's rate for these opcodes, both forms read the same.
+#define BANK_REGS "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35"
+#define KERNEL_BANK(NAME, A0, A1, A2, A3)                                                                        \
+    __global__ void NAME(float *out, int iters)                                                                \
+    {                                                                                                          \
+        float r = out[threadIdx.x & 1] + 1.5f;                                                                  \
+        asm volatile("v_mov_b32 v20, %0\n v_mov_b32 v21, 1.0\n v_mov_b32 v22, 0.5\n v_mov_b32 v23, 1.0\n v_mov_b32 v24, %0\n v_mov_b32 v25, 1.0\n" \
+                     "v_mov_b32 v26, 0.5\n v_mov_b32 v27, 1.0\n v_mov_b32 v28, %0\n v_mov_b32 v29, 1.0\n v_mov_b32 v30, 0.5\n v_mov_b32 v31, 1.0\n"  \
+                     "v_mov_b32 v32, %0\n v_mov_b32 v33, 1.0\n v_mov_b32 v34, 0.5\n v_mov_b32 v35, 1.0\n" : : "v"(r) : BANK_REGS);               \
+        for (int i = 0; i < iters; ++i) { asm volatile(REP8(REP8(A0 A1 A2 A3)) : : : BANK_REGS, "vcc", "s20", "s21", "s22", "s23"); }               \
+        asm volatile("v_add_f32 %0, v20, v24\n v_add_f32 %0, %0, v28\n v_add_f32 %0, %0, v32\n" : "=v"(r) : : BANK_REGS);                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                                        \
+    }
+// (destination = first source, as in the loops above; the other sources: banks 1 and 2 / the destination's own bank 0)
+KERNEL_BANK(bank_fma_distinct, "v_fma_f32 v20, v20, v21, v22\n", "v_fma_f32 v24, v24, v25, v26\n", "v_fma_f32 v28, v28, v29, v30\n", "v_fma_f32 v32, v32, v33, v34\n")
+KERNEL_BANK(bank_fma_same, "v_fma_f32 v20, v20, v24, v28\n", "v_fma_f32 v24, v24, v28, v32\n", "v_fma_f32 v28, v28, v32, v20\n", "v_fma_f32 v32, v32, v20, v24\n")
+KERNEL_BANK(bank_max_distinct, "v_max_f32 v20, v20, v21\n", "v_max_f32 v24, v24, v25\n", "v_max_f32 v28, v28, v29\n", "v_max_f32 v32, v32, v33\n")
+KERNEL_BANK(bank_max_same, "v_max_f32 v20, v20, v24\n", "v_max_f32 v24, v24, v28\n", "v_max_f32 v28, v28, v32\n", "v_max_f32 v32, v32, v20\n")
+KERNEL_BANK(bank_mul_distinct, "v_mul_f32 v20, v20, v21\n", "v_mul_f32 v24, v24, v25\n", "v_mul_f32 v28, v28, v29\n", "v_mul_f32 v32, v32, v33\n")
+KERNEL_BANK(bank_mul_same, "v_mul_f32 v20, v20, v24\n", "v_mul_f32 v24, v24, v28\n", "v_mul_f32 v28, v28, v32\n", "v_mul_f32 v32, v32, v20\n")
+KERNEL_BANK(bank_cmp_distinct, "v_cmp_lt_f32 s[20:21], v20, v21\n", "v_cmp_lt_f32 s[22:23], v24, v25\n", "v_cmp_lt_f32 s[20:21], v28, v29\n", "v_cmp_lt_f32 s[22:23], v32, v33\n")
+KERNEL_BANK(bank_cndmask_distinct, "v_cndmask_b32_e64 v20, v20, v21, s[20:21]\n", "v_cndmask_b32_e64 v24, v24, v25, s[22:23]\n", "v_cndmask_b32_e64 v28, v28, v29, s[20:21]\n", "v_cndmask_b32_e64 v32, v32, v33, s[22:23]\n")
+KERNEL_BANK(bank_pk_fma_distinct, "v_pk_fma_f32 v[20:21], v[20:21], v[22:23], v[26:27]\n", "v_pk_fma_f32 v[24:25], v[24:25], v[22:23], v[26:27]\n", "v_pk_fma_f32 v[28:29], v[28:29], v[30:31], v[34:35]\n", "v_pk_fma_f32 v[32:33], v[32:33], v[30:31], v[34:35]\n")
+
 struct Case { const char *name; void (*fn)(float *, int); int per_rep; };
 #define C1(n) {#n, n, 64}
 #define C2(n) {#n, n, 128}
@@ -172,14 +200,18 @@ int main()
                           {"ind_or_b32", ind_or_b32, 256}, {"ind_lshlrev_b32", ind_lshlrev_b32, 256}, {"ind_lshrrev_b32", ind_lshrrev_b32, 256},
                           {"ind_or3_b32", ind_or3_b32, 256}, {"ind_and_or_b32", ind_and_or_b32, 256}, {"ind_bfe_u32", ind_bfe_u32, 256},
                           {"ind_max3_f32", ind_max3_f32, 256}, {"ind_cvt_f32_u32", ind_cvt_f32_u32, 256}, {"ind_mul_u32_u24", ind_mul_u32_u24, 256},
-                          {"ind_mbcnt", ind_mbcnt, 256}, {"ind_lshl_add_u64", ind_lshl_add_u64, 256}, {"ind_cmp_u32", ind_cmp_u32, 256}};
+                          {"ind_mbcnt", ind_mbcnt, 256}, {"ind_lshl_add_u64", ind_lshl_add_u64, 256}, {"ind_cmp_u32", ind_cmp_u32, 256},
+                          {"bank_fma_distinct", bank_fma_distinct, 256}, {"bank_fma_same", bank_fma_same, 256}, {"bank_max_distinct", bank_max_distinct, 256},
+                          {"bank_max_same", bank_max_same, 256}, {"bank_mul_distinct", bank_mul_distinct, 256}, {"bank_mul_same", bank_mul_same, 256},
+                          {"bank_cmp_distinct", bank_cmp_distinct, 256}, {"bank_cndmask_distinct", bank_cndmask_distinct, 256},
+                          {"bank_pk_fma_distinct", bank_pk_fma_distinct, 256}};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     const double ghz = 2.4;
     float *out;
-    hipMalloc(&out, (size_t) cus * 4 * 8 * 64 * sizeof(float));
-    hipMemset(out, 0, (size_t) cus * 4 * 8 * 64 * sizeof(float));
+    hipMalloc(&out, (size_t) cus * 4 * 16 * 64 * sizeof(float));
+    hipMemset(out, 0, (size_t) cus * 4 * 16 * 64 * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -190,9 +222,10 @@ int main()
         printf("%s  \"%s\": {", first ? "" : ",\n", c.name);
         first = false;
         bool f2 = true;
-        for (int w : {1, 4}) {
-            // one workgroup of 4 * w wavefronts per CU: w per SIMD
-            const dim3 grid(cus), block(64 * 4 * w);
+        for (int w : {1, 4, 8}) {
+            // 4 * w wavefronts per CU, w per SIMD: one workgroup per CU, two of 16 wavefronts each for w = 8 (all kernels use few
+            // registers, so eight wavefronts fit a SIMD)
+            const dim3 grid(w == 8 ? 2 * cus : cus), block(w == 8 ? 1024 : 64 * 4 * w);
             hipLaunchKernelGGL(c.fn, grid, block, 0, 0, out, 10);
             hipDeviceSynchronize();
             hipEventRecord(e0);

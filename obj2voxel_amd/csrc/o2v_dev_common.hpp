@@ -309,16 +309,36 @@ __device__ __forceinline__ void cell_position(uint32_t brick, uint32_t local, co
     z += local >> (kBrickXs + kBrickYs);
 }
 
+// Inclusive prefix sum of one uint32 per lane over the wavefront, with DPP adds: four row_shr steps inside each row of 16 lanes,
+// then row_bcast:15 / row_bcast:31 carry the rows' totals on (gfx9 wave64).  Six dependent VALU instructions; the same scan
+// with __shfl_up is six dependent LDS-crossbar round trips (ds_bpermute), and k_voxelize's phase 1 - one scan per 64 candidate
+// rows - waits on such chains rather than on instruction issue (profiles/r05/NOTES.md).
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+#ifndef O2V_NO_DPP_SCAN
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true);   // row_shr:1 (lanes without a source add 0)
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+#else
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+#endif
+}
+
 // exclusive scan of one uint32 per thread over a 256-thread block; returns the block total in `total`
 __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *s_wave /*[4]*/, uint32_t &total)
 {
     uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
+    const uint32_t inc = wave_inclusive_scan(v);
     __syncthreads();
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();

@@ -525,12 +525,7 @@ template <uint32_t kVoxBlock>
 __device__ __forceinline__ uint32_t vox_exscan(uint32_t v, uint32_t *s_wave /*[kVoxBlock / 64]*/, uint32_t &total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
+    const uint32_t inc = wave_inclusive_scan(v);
     __syncthreads();
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
@@ -980,12 +975,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
             // a row's survivors - voxels x_first .. x_first + n_out - 1 of the row yz of tile slot k (xk = x_first | k << 16) - go
             // into the ring, as many at a time as it has room for; full groups of 64 leave it (wave-uniform call)
             auto ring_push = [&](uint32_t n_out, uint32_t xk, uint32_t yz) {
-                uint32_t inc = n_out;
-#pragma unroll
-                for (uint32_t d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc += o;
-                }
+                const uint32_t inc = wave_inclusive_scan(n_out);
                 const uint32_t total = __shfl(inc, 63, 64), exc = inc - n_out;
                 uint32_t pushed = 0;  // wave-uniform: survivors of these 64 rows (in prefix order) already in the ring
                 while (pushed < total) {
@@ -1045,12 +1035,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                     continue;
                 }
                 // inclusive prefix of the rows' survivor counts over the wavefront
-                uint32_t inc = n_out;
-#pragma unroll
-                for (uint32_t d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc += o;
-                }
+                const uint32_t inc = wave_inclusive_scan(n_out);
                 const uint32_t total = __shfl(inc, 63, 64);
                 const uint32_t exc = inc - n_out;
                 // (long rows - large axis-aligned leaves - are followed with a wave-uniform cursor instead of the search:

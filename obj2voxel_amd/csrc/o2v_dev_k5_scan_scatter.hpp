@@ -220,12 +220,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_bricks(uint32_t *grid, const ui
             // voxels fall into the same few lines.  One LDS atomic per wavefront and load.
             const uint32_t hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w};
             const uint32_t mine = (hv[0] ? 1u : 0u) + (hv[1] ? 1u : 0u) + (hv[2] ? 1u : 0u) + (hv[3] ? 1u : 0u);
-            uint32_t inc = mine;
-#pragma unroll
-            for (uint32_t d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += o;
-            }
+            const uint32_t inc = wave_inclusive_scan(mine);
             const uint32_t total = __shfl(inc, 63, 64);
             if (total) {
                 uint32_t base = 0;

@@ -171,6 +171,7 @@ struct Params {
     // Occupancy-only mode: a root triangle that is one leaf of one tile (the usual triangle of a tessellated surface) gets no
     // Leaf and no Tile record; k_voxelize_occ makes its leaf from the vertex array (k_expand_roots only counts it).
     uint32_t root_bypass;
+    float plan_leaf_cost;  // slab planning (k_zhist): what a leaf costs beside its hits, in hit equivalents
     uint32_t exact_clip;   // O2V_HIP_FLAG_EXACT_CLIP: no work-removal shortcuts in k_voxelize (every leaf is treated as not `small`)
     // Direct MAX path (MAX strategy, no textured triangle; section 4 of DESIGN.md): one 64-bit cell per output voxel that
     // holds max over {weight bits << 32 | ~(sub-voxel << 29 | triangle)}, and its own dirty-brick map.

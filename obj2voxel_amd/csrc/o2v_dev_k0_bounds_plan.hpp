@@ -142,6 +142,15 @@ constexpr uint32_t kPlanBins = 2048;
 #define O2V_PLAN_LEAF_COST 4.0f
 #endif
 constexpr float kPlanLeafCost = O2V_PLAN_LEAF_COST;  // what a leaf costs beside its hits, in hits (see k_zhist)
+// ... in occupancy-only mode, where most hits need no voxel job (and most of the jobs that remain are dropped), a hit is cheaper
+// and the leaf's own cost - its transform, its candidate rows - weighs more.  Round 5's kernels on the eight slabs of configs[4]
+// (sub-voxel triangles; polar slab 42.3 M hits / 5.63 M leaves 1.94 ms, equatorial 36.0 M / 7.20 M 2.25 ms) fit 19 hits per leaf,
+// on those of the weak-scaling job (triangles 3.4 voxels across) 7; slowest slab / mean with 4, 16: configs[4] 1.069, 1.022, weak
+// job 1.025, 1.050 (profiles/r05/NOTES.md).  10 serves both.
+#ifndef O2V_PLAN_LEAF_COST_OCC
+#define O2V_PLAN_LEAF_COST_OCC 10.0f
+#endif
+constexpr float kPlanLeafCostOccupancy = O2V_PLAN_LEAF_COST_OCC;
 __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ verts, const Counters *__restrict__ c,
                                                    unsigned long long *hist, float2 *zrange, float *zrange_xform,
                                                    Params p, uint32_t bin_h, uint64_t tri_begin, uint64_t tri_end)
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_zhist(const float *__restrict__ vert
         const float leaves_est = boxes > 1.0f ? __builtin_exp2f(__builtin_log2f(boxes) * (2.0f / 3.0f)) : 1.0f;
         float est = (abs_f(n.x) + abs_f(n.y) + abs_f(n.z)) * 0.5f +
                     (abs_f(e0.x) + abs_f(e0.y) + abs_f(e0.z) + abs_f(e1.x) + abs_f(e1.y) + abs_f(e1.z) + abs_f(e2.x) +
-                     abs_f(e2.y) + abs_f(e2.z)) * 0.5f + 1.0f + kPlanLeafCost * leaves_est;
+                     abs_f(e2.y) + abs_f(e2.z)) * 0.5f + 1.0f + p.plan_leaf_cost * leaves_est;
         if (!(est < 1e12f)) est = 1e12f;  // also catches NaN
         const float zlo = fmin2(v0.z, fmin2(v1.z, v2.z)), zhi = fmax2(v0.z, fmax2(v1.z, v2.z));
         if (!(zhi >= 0.f) || !(zlo < (float) p.S)) continue;

@@ -1438,6 +1438,8 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
     p.bounds_known = params->bounds_known;
     for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
     for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];
+    // (what a leaf costs beside its hits, in hit equivalents: k_zhist)
+    p.plan_leaf_cost = grid_modes(ctx, params).occupancy_only ? kPlanLeafCostOccupancy : kPlanLeafCost;
     // sample layers per bin: a whole number of output layers, at most kPlanBins bins
     bin_out = (G + kPlanBins - 1) / kPlanBins;
     n_bins = (G + bin_out - 1) / bin_out;

@@ -163,11 +163,12 @@ def test_config4_50m_sphere_4096_eight_planned_slabs(dv, all_cores):
     # ... and a check that does not use the planner's own cost model: the measured device time of the eight slabs (the 8-GPU
     # job's critical path is the slowest one) is balanced
     assert max(slab_ms) < 1.10 * sum(slab_ms) / n, (cuts, slab_ms)
-    # the plan balances predicted TIME: hits + 4 hit equivalents per leaf (k_zhist: measured on these very slabs in round 3,
-    # where equal hits left the equatorial slabs, with 1.5 x the leaves, 7 % slower than the mean)
-    work = [h + 4.0 * l for h, l in zip(hits, leaves)]
-    assert max(work) < 1.03 * sum(work) / n, (cuts, hits, leaves)
-    assert max(hits) < 1.15 * sum(hits) / n, (cuts, hits)
+    # the plan balances predicted TIME: hits + 10 hit equivalents per leaf in occupancy-only mode (k_zhist: fitted on these very
+    # slabs and on the weak-scaling job's - a polar slab has more hits, an equatorial one more leaves).  `hits` here are the
+    # established hits + the skipped jobs: an upper bound of the true hits that the job filter moves by a few percent, so 6 %
+    work = [h + 10.0 * l for h, l in zip(hits, leaves)]
+    assert max(work) < 1.06 * sum(work) / n, (cuts, hits, leaves)
+    assert max(hits) < 1.35 * sum(hits) / n, (cuts, hits)
 
 
 def test_readme_showcase_standin_8192_through_the_c_api(all_cores):

@@ -335,8 +335,10 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
         // pass 1: what this lane's (up to) four triangles emit
         for (uint32_t k = 0; k < kRootBatch; ++k) {
             const uint64_t at = sblk * kRootBatch + k, blk = block_at(at);
-            // after the last sub-batch of this pass comes the first one again (pass 2)
-            classify(blk, block_at(k + 1 < kRootBatch ? at + 1 : sblk * kRootBatch), s, e, pl, area, as_leaf, as_node, bypassed);
+            // after the last sub-batch of this pass comes the first one again (pass 2) - or, where most triangles are left to
+            // k_voxelize_occ (root_bypass) and pass 2 has nothing to write as a rule, the workgroup's next super-block
+            const uint64_t after = p.root_bypass ? (sblk + gridDim.x) * kRootBatch : sblk * kRootBatch;
+            classify(blk, block_at(k + 1 < kRootBatch ? at + 1 : after), s, e, pl, area, as_leaf, as_node, bypassed);
             if (bypassed) {
                 my_bypass += 1;
                 my_bypass_cand += pl.count;

@@ -99,6 +99,7 @@ struct o2v_hip_ctx {
     Counters *h_ctr = nullptr;  // pinned
     uint64_t no_pool_key = 0;   // (key + 1 of) the mesh and settings whose last pass pooled no hits (run_pass: k_mark_bricks left out)
     bool marked_bricks = false, mark_missing = false; // the current pass listed its bricks before k_voxelize
+    bool skip_big = false;      // no leaf of the uploaded mesh can have more than four tiles (its largest triangle's extent): k_expand_big left out
     bool ctr_clean = false;     // d_ctr was zeroed (k_init) behind the last pass and nothing has touched it since
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the cooperative resolve tiers run beside tier 1
     hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -398,7 +399,10 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         O2V_LAUNCH("k_list_blocks", s, k_list_blocks, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (n_tri_blocks + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_zrange, ctx->d_zrange_xform, ctx->d_ctr, ctx->d_block_list, ctx->d_block_count, p);
     }
-    O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, (p.n_tris + kBlock - 1) / kBlock)),
+    // (root_bypass: most super-blocks of three sub-batches are only read and counted - fewer workgroups with several super-blocks
+    // each keep the loads of the next one in flight behind the current one's arithmetic)
+    const uint64_t root_wgs = p.root_bypass ? std::max<uint64_t>((uint64_t) ctx->num_cus * 2u, (p.n_tris + kBlock - 1) / kBlock / 6u) : (p.n_tris + kBlock - 1) / kBlock;
+    O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, std::max<uint64_t>(root_wgs, 1))),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
                        ctx->d_big, ctx->d_nodes[0], have_zrange ? ctx->d_zrange : nullptr,
                        ctx->d_zrange_xform, block_list, ctx->d_block_count, p);
@@ -407,7 +411,9 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         O2V_LAUNCH("k_expand_nodes", s, k_expand_nodes, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
     }
-    O2V_LAUNCH("k_expand_big", s, k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
+    // (left out if no leaf of this mesh can have more than four tiles, o2v_hip_voxelize; should one turn up, the pass is repeated)
+    if (!ctx->skip_big)
+        O2V_LAUNCH("k_expand_big", s, k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
     // (a mesh that pooled no hits in its last pass with these settings - every triangle whole and on the direct MAX path - will
     // not pool any now: the two launches are left out; should K1's counters say otherwise, the pass is repeated with them)
     const uint64_t mark_key = ctx->tri_generation * 1000003ull + p.blend * 7u + p.S * 131ull + p.zs0 * 31ull + p.zs1 + p.exact_clip * 3u;
@@ -1203,6 +1209,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     // last round the pass is repeated with the full kMaxRounds (nothing is lost, only re-run).
     uint32_t n_rounds = 4;
     while ((1u << n_rounds) < p.S && n_rounds < kMaxRounds) ++n_rounds;
+    ctx->skip_big = false;
     if (ctx->max_tri_extent >= 0.f) {
         // tighter: a (sub-)triangle whose extent is at most 5 voxels has a voxel AABB of at most 7^3 < 512 cells and is
         // a leaf; every round halves the extents.  Scale = the mesh transform's (obj2voxel.cpp:370-402).
@@ -1211,12 +1218,23 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         float unit_norm = 0.f;
         for (int i = 0; i < 3; ++i)
             unit_norm = std::max(unit_norm, std::fabs((float) p.unit[i * 3]) + std::fabs((float) p.unit[i * 3 + 1]) + std::fabs((float) p.unit[i * 3 + 2]));
-        const float ext_vox = ctx->max_tri_extent * unit_norm * ((float) p.S / max_axis) + 1.0f;
+        // (the largest triangle's extent in voxels, rounded up a little; its voxel box has at most extent + 2 cells per axis)
+        const float ext_vox = ctx->max_tri_extent * unit_norm * ((float) p.S / max_axis) * 1.0001f + 1e-3f;
         if (max_axis > 0.f && ext_vox == ext_vox && ext_vox < 3.0e9f) {
+            // a (sub-)triangle less than 6 voxels across has a box of fewer than 8^3 = 512 cells and is a leaf: a mesh of such
+            // triangles needs no subdivision round at all (most tessellated surfaces at their resolution), one `depth` halvings
+            // larger needs `depth` rounds
             uint32_t depth = 0;
-            for (float e = ext_vox; e > 5.0f; e *= 0.5f) ++depth;
-            n_rounds = std::min<uint32_t>(n_rounds, depth + 1u);
+            for (float e = ext_vox; e > 5.9f; e *= 0.5f) ++depth;
+            n_rounds = std::min<uint32_t>(n_rounds, depth);
+            // ... and a leaf less than 7.9 voxels across has fewer than 10^3 cells = four tiles: none for k_expand_big (a larger
+            // one can only be an axis-aligned triangle, voxelization.cpp:335-347)
+            ctx->skip_big = ext_vox < 7.9f;
         }
+    }
+    if (const char *all = std::getenv("O2V_ALL_LAUNCHES"); all && all[0] == '1') {  // (A/B: no launch left out on the strength of the hints)
+        n_rounds = std::max<uint32_t>(n_rounds, 1u);
+        ctx->skip_big = false;
     }
     ctx->force_general = false;
     ctx->mark_missing = false;  // (a call that ended early - an error, a failed allocation - must not leave it to the next one)
@@ -1343,7 +1361,11 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         need(h.n_vox, ctx->cap_vox, want_vox);
         if (p.direct_max) need(h.n_out, ctx->cap_vox, want_vox);
         if (n_rounds < kMaxRounds && h.n_nodes[n_rounds] != 0) {
-            n_rounds = kMaxRounds;  // unusually deep subdivision
+            n_rounds = kMaxRounds;  // unusually deep subdivision (or the hint about the largest triangle did not hold)
+            again = true;
+        }
+        if (ctx->skip_big && h.n_big != 0) {
+            ctx->skip_big = false;  // a leaf of more than four tiles although the hint ruled that out: with k_expand_big, then
             again = true;
         }
         if (ctx->mark_missing) {

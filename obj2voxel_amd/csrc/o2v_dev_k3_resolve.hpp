@@ -854,14 +854,21 @@ __global__ __launch_bounds__(kBlock) void k_pick(const HitRec *__restrict__ pool
 
 constexpr uint32_t kEmitBricksPerWave = 2;
 constexpr uint32_t kEmitBricksPerRound = (kBlock / 64) * kEmitBricksPerWave * kBricksPerLoad;
-constexpr uint32_t kEmitFlushAt = 1024;  // 48 KiB of staging: three workgroups per CU keep enough brick loads (2 KiB per wavefront) in flight
-                                         // (2048 / two workgroups: 0.15 ms on the bench mesh, this: 0.12; 512 / four: 0.16)
+// 48 KiB of staging: three workgroups per CU keep enough brick loads (2 KiB per wavefront) in flight (64 KiB / two workgroups: 0.15 ms
+// on the bench mesh, this: 0.12; 32 KiB / four: 0.16).  A staged record is 12 bytes (x | y << 16, z, argb) and becomes the 16-byte
+// (x, y, z, argb) when it is written out: a flush - one serialising atomic on Counters::n_out each - then takes 2 048 records
+// or more instead of 1 024 (see k_emit_occ).
+#ifndef O2V_EMIT_FLUSH
+#define O2V_EMIT_FLUSH 2048
+#endif
+constexpr uint32_t kEmitFlushAt = O2V_EMIT_FLUSH;
 constexpr uint32_t kEmitCap = kEmitFlushAt + kEmitBricksPerRound * kBrickCells;
 
 __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict__ dirty_list, Counters *c, Materials m, uint4 *out,
                                                      Params p)
 {
-    __shared__ uint4 s_rec[kEmitCap];
+    __shared__ uint2 s_rec[kEmitCap];
+    __shared__ uint32_t s_argb[kEmitCap];
     __shared__ uint32_t s_n, s_base;
     if (!direct_active(c, p)) return;
     if (threadIdx.x == 0) s_n = 0;
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
         __syncthreads();
         const uint32_t base = s_base;
         for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-            if (base + i < p.cap_vox) out[base + i] = s_rec[i];
+            if (base + i < p.cap_vox) out[base + i] = make_uint4(s_rec[i].x & 0xffffu, s_rec[i].x >> 16, s_rec[i].y, s_argb[i]);
         __syncthreads();
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -917,8 +924,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
                             argb = pack_argb(cr, cg, cb);
                         }
                         const uint32_t slot = atomicAdd(&s_n, 1u);
-                        s_rec[slot] = make_uint4(x0 + (local & (kBrickX - 1u)), y0 + ((local >> kBrickXs) & (kBrickY - 1u)),
-                                                 z0 + (local >> (kBrickXs + kBrickYs)), argb);
+                        s_rec[slot] = make_uint2((x0 + (local & (kBrickX - 1u))) | ((y0 + ((local >> kBrickXs) & (kBrickY - 1u))) << 16),
+                                                 z0 + (local >> (kBrickXs + kBrickYs)));  // (output coordinates are below 2^16)
+                        s_argb[slot] = argb;
                     }
                 }
                 // leave the cells clean for the next run
@@ -941,12 +949,19 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
 // per lane, four bricks per wavefront load) become white (x, y, z, argb) records and are zeroed again.
 constexpr uint32_t kOccBricksPerWave = 2;  // (the staging buffer then takes 48 KiB: three workgroups per CU)
 constexpr uint32_t kOccBricksPerRound = (kBlock / 64) * kOccBricksPerWave * kBricksPerLoad;
-constexpr uint32_t kOccFlushAt = 1024;
+// A flush reserves its records with one atomic on Counters::n_out, and those serialise (~5 ns each: with 1 024 records per
+// flush they were a third of this kernel - 512: 0.088 ms, 1 024: 0.062).  The staged record is therefore 8 bytes (x | y << 16,
+// z; the colour is white) and becomes the 16-byte (x, y, z, argb) when it is written out: the same 48 KiB hold 6 144 of them, a
+// flush takes 4 096 or more.
+#ifndef O2V_OCC_FLUSH
+#define O2V_OCC_FLUSH 4096
+#endif
+constexpr uint32_t kOccFlushAt = O2V_OCC_FLUSH;
 constexpr uint32_t kOccCap = kOccFlushAt + kOccBricksPerRound * kBrickCells;
 __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict__ dirty_list, Counters *c, uint4 *out, Params p)
 {
     static_assert(kLanesPerBrick * 4u == kBrickCells, "one 4-byte load per lane covers four cells");
-    __shared__ uint4 s_rec[kOccCap];
+    __shared__ uint2 s_rec[kOccCap];
     __shared__ uint32_t s_n, s_base;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -959,7 +974,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
         __syncthreads();
         const uint32_t base = s_base;
         for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-            if (base + i < p.cap_vox) out[base + i] = s_rec[i];
+            if (base + i < p.cap_vox) out[base + i] = make_uint4(s_rec[i].x & 0xffffu, s_rec[i].x >> 16, s_rec[i].y, white);
         __syncthreads();
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -1001,8 +1016,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
                     if (set) {
                         const uint32_t local = (lane % kLanesPerBrick) * 4u + e;
                         const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
-                        s_rec[slot] = make_uint4(x0 + (local & (kBrickX - 1u)), y0 + ((local >> kBrickXs) & (kBrickY - 1u)),
-                                                 z0 + (local >> (kBrickXs + kBrickYs)), white);
+                        s_rec[slot] = make_uint2((x0 + (local & (kBrickX - 1u))) | ((y0 + ((local >> kBrickXs) & (kBrickY - 1u))) << 16),
+                                                 z0 + (local >> (kBrickXs + kBrickYs)));  // (output coordinates are below 2^16)
                     }
                 }
             }

@@ -29,9 +29,15 @@ def device_asm(tmp_path_factory):
     return out.read_text().splitlines()
 
 
-@pytest.mark.parametrize("variant", ["Lb0E", "Lb1E"])  # k_voxelize<false>, k_voxelize<true>
+def _kernel_start(device_asm, variant):
+    """variant: 'Lb0E' = k_voxelize<false>, 'Lb1E' = k_voxelize<true>, '_occ' = k_voxelize_occ (the occupancy-only route's kernel)"""
+    pat = r"^_ZN\S*k_voxelize_occ\S*:" if variant == "_occ" else r"^_ZN\S*k_voxelizeI" + variant + r"\S*:"
+    return next(i for i, l in enumerate(device_asm) if re.match(pat, l))
+
+
+@pytest.mark.parametrize("variant", ["Lb0E", "Lb1E", "_occ"])
 def test_job_prefetch_is_lds_dma_with_an_explicit_wait(device_asm, variant):
-    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_ZN\S*k_voxelizeI" + variant + r"\S*:", l))
+    start = _kernel_start(device_asm, variant)
     end = next(i for i in range(start, len(device_asm)) if device_asm[i].startswith(".Lfunc_end"))
     body = [l.strip() for l in device_asm[start:end]]
     dma = [i for i, l in enumerate(body) if l.startswith("global_load_lds_dword")]
@@ -49,11 +55,11 @@ def test_job_prefetch_is_lds_dma_with_an_explicit_wait(device_asm, variant):
     assert len(reads) >= 2, rest[:stop]
 
 
-@pytest.mark.parametrize("variant", ["Lb0E", "Lb1E"])
+@pytest.mark.parametrize("variant", ["Lb0E", "Lb1E", "_occ"])
 def test_no_runs_of_two_operand_selects(device_asm, variant):
     """A VOP2 v_cndmask directly after another costs 16+ cycles of its SIMD on gfx950 (profiles/r03/valu_rates.json); the
     pieces of the clip loop are selected with the three-operand encoding (vsel), so no run of more than two remains."""
-    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_ZN\S*k_voxelizeI" + variant + r"\S*:", l))
+    start = _kernel_start(device_asm, variant)
     end = next(i for i in range(start, len(device_asm)) if device_asm[i].startswith(".Lfunc_end"))
     ops = [l.split()[0] for l in (x.strip() for x in device_asm[start:end]) if l and not l.startswith((";", ".")) and not l.endswith(":")]
     longest = run = 0
@@ -63,12 +69,23 @@ def test_no_runs_of_two_operand_selects(device_asm, variant):
     assert longest <= 2, longest
 
 
-@pytest.mark.parametrize("variant,min_alignbit", [("Lb0E", 20), ("Lb1E", 12)])
+@pytest.mark.parametrize("variant,min_alignbit", [("Lb0E", 20), ("Lb1E", 12), ("_occ", 20)])
 def test_piece_masks_are_built_from_sign_bits(device_asm, variant, min_alignbit):
     """piece_masks reads its conditions off the sign bits of differences: one v_alignbit_b32 per condition instead of a
     compare and a select (profiles/r04/NOTES.md: -4 .. -7 % on the clip kernel).  If the compiler turns that back into
     compares, the instruction mix the bench line's mix ceiling is priced with changes: this pins the form."""
-    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_ZN\S*k_voxelizeI" + variant + r"\S*:", l))
+    start = _kernel_start(device_asm, variant)
     end = next(i for i in range(start, len(device_asm)) if device_asm[i].startswith(".Lfunc_end"))
     ops = [l.split()[0] for l in (x.strip() for x in device_asm[start:end]) if l and not l.startswith((";", ".")) and not l.endswith(":")]
     assert sum(op == "v_alignbit_b32" for op in ops) >= min_alignbit, sum(op == "v_alignbit_b32" for op in ops)
+
+
+def test_wavefront_prefix_sums_use_dpp(device_asm):
+    """wave_inclusive_scan (o2v_dev_common.hpp): four row_shr adds and the two row broadcasts instead of six ds_bpermute steps -
+    phase 1 of the clip kernels runs one such scan per 64 candidate rows and waits on its dependent chains
+    (profiles/r05/NOTES.md).  Pins that the compiler emits the DPP forms on gfx950."""
+    start = _kernel_start(device_asm, "_occ")
+    end = next(i for i in range(start, len(device_asm)) if device_asm[i].startswith(".Lfunc_end"))
+    body = [l.strip() for l in device_asm[start:end]]
+    assert sum("row_bcast:15" in l for l in body) >= 1 and sum("row_bcast:31" in l for l in body) >= 1
+    assert sum("row_shr:8" in l for l in body) >= 1

@@ -36,9 +36,9 @@ int main(int argc, char **argv)
     sink->finalize();
     if (!sink->can_write() || sink->written != n) return 5;
     std::FILE *out = std::fopen(argv[4], "wb");
-    const std::vector<uint8_t> *mem = sink->memory();
+    const o2v::ByteBuffer *mem = sink->memory();
     if (!out || !mem) return 6;
-    std::fwrite(mem->data(), 1, mem->size(), out);
+    std::fwrite(mem->bytes, 1, mem->size, out);
     std::fclose(out);
     return 0;
 }

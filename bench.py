@@ -209,10 +209,10 @@ def main():
             verts = meshes.uv_sphere(nv)
             dv.set_triangles(verts)
         if n == 1:
-            step = lambda: (dv.voxelize(res, read=False, **kw), None)            # noqa: E731
+            step = lambda **t: (dv.voxelize(res, read=False, **kw, **t), None)   # noqa: E731
         else:
-            def step():
-                count, counts, cuts = dv.voxelize_sharded(comm, res, read=False)
+            def step(**t):
+                count, counts, cuts = dv.voxelize_sharded(comm, res, read=False, **t)
                 return count, counts
         for _ in range(warmup):
             step()
@@ -226,20 +226,24 @@ def main():
         elapsed = time.perf_counter() - t0
         total_voxels, max_elapsed = slabs.reduce_job(dist, count, elapsed,
                                                       device="cuda" if (dist is not None and args.backend == "nccl") else None)
-        # per-stage device times (hipEvent pairs the library records in every step) and, for N > 1, the collectives' shares:
-        # read in a few further steps outside the timed region (reading them is a library call and a dictionary per step)
+        # the clip kernel's duration in the timed steps (two hipEvents on the kernel's own dispatch, recorded in every step: read
+        # here for the last one; the roofline's kernel_ms)
+        k2_ms_timed = dv.timings()["voxelize_ms"]
+        # per-stage device times and, for N > 1, the collectives' shares: a few further steps outside the timed region with
+        # O2V_HIP_FLAG_STAGE_TIMES (an event between the stages costs ~4 us of device time each: not in the timed steps)
         stage_steps = min(5, max(steps, 1))
         acc = {k: 0.0 for k in names}
         parts = [0.0] * 5
         for _ in range(stage_steps):
-            step()
+            step(stage_times=True)
             tm = dv.timings()
             for k in names:
                 acc[k] += tm[k]
             parts = [a + b for a, b in zip(parts, tm["collective_parts_ms"])]
         run = {"name": name, "res": res, "nv": nv, "T": len(verts), "verts": verts, "voxels": total_voxels, "text": text, "kw": kw,
                "collective_parts_ms": [x / stage_steps for x in parts],
-               "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / stage_steps for k in names}, "stats": dv.stats()}
+               "seconds_per_step": max_elapsed / steps, "stages_ms": {k: acc[k] / stage_steps for k in names}, "stats": dv.stats(),
+               "k2_ms_timed": k2_ms_timed}
         if n == 1:
             # per-kernel times: two further steps with an event pair around every launch (outside the timed region: the
             # brackets cost a few microseconds per launch)
@@ -498,6 +502,8 @@ def report(args, n, run, dv, comm):
     stages = []
     for name in ("bounds", "expand", "voxelize", "scan", "resolve"):
         ms = stages_ms[name + "_ms"]
+        if name == "voxelize" and run.get("k2_ms_timed"):
+            ms = run["k2_ms_timed"]   # the kernel's own duration in the last timed step (not the stage interval of the extra steps)
         traffic = sum(kern[k]["hbm_bytes"] * kern[k].get("launches_per_step", 1) for k in stage_kernels[name] if k in kern) if kern else None
         row = {"stage": name, "kernels": [k for k in stage_kernels[name] if not kern or k in kern], "ms": round(ms, 4), "bound": bound_of[name],
                "algorithmic_bytes": int(alg[name]), "traffic_bytes": traffic,
@@ -553,7 +559,7 @@ def report(args, n, run, dv, comm):
                     "formulas": {"achieved": "SQ_INSTS_VALU / kernel_ms", "peak": "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction",
                                  "active_lane_fraction": "SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64",
                                  "valu_busy": "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (profiled_kernel_us x 2.4 GHz)",
-                                 "counters": "profiles/current.json -> kernels[kernel].sq (rocprofv3 --pmc passes of this command); kernel_ms: live hipEvent time of the stage"},
+                                 "counters": "profiles/current.json -> kernels[kernel].sq (rocprofv3 --pmc passes of this command); kernel_ms: two hipEvents on the kernel's own dispatch (hipExtLaunchKernelGGL), last timed step"},
                     "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: " + (prof or {}).get("source", "profiles/current.json")}
         mc = mix_ceiling(dom_kernel)
         if mc:
@@ -591,9 +597,11 @@ def report(args, n, run, dv, comm):
                        "plan_ms_rank0": round(stages_ms["plan_ms"], 4),
                        "collective_ms_rank0": round(stages_ms["collective_ms"], 4),
                        # device time of each collective on rank 0 (it includes waiting for the slowest rank to arrive)
-                       "per_collective_ms_rank0": dict(zip(("ready_allreduce_4B", "bounds_allreduce_24B", "histogram_allreduce_16KiB",
+                       # (measured in the extra steps made with O2V_HIP_FLAG_STAGE_TIMES: timing a collective is a wait on the host;
+                       # the ranks' readiness words and the mesh bounds travel in one max-reduce)
+                       "per_collective_ms_rank0": dict(zip(("ready_and_bounds_allreduce_28B", "histogram_allreduce_16KiB",
                                                             "block_extents_allgather", "slab_counts_allgather"),
-                                                           [round(x, 4) for x in run.get("collective_parts_ms", [0.0] * 5)]))}},
+                                                           (lambda q: [round(q[0] + q[1], 4)] + [round(x, 4) for x in q[2:]])(run.get("collective_parts_ms", [0.0] * 5))))}},
         "roofline": roofline, "roofline_hbm_view": hbm_view if roofline is not hbm_view else None, "stages": stages, "pipeline": pipeline,
         "steady_state": "steps 2.. of one uploaded mesh: buffers sized, counters zeroed behind the previous step, and the coloured-MAX routes reuse "
                         "the previous step's finding that no hit is pooled (two launches left out); a single-use obj2voxel_instance pays the first "

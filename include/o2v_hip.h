@@ -62,10 +62,17 @@ typedef struct {
  * tests run both on the device and compare (tests/test_gpu_exact_ab.py).  Also forced by O2V_EXACT_CLIP=1 in the
  * environment.
  * KERNEL_TIMES: brackets every kernel launch of the pipeline with two HIP events on the stream it is launched on;
- * o2v_hip_get_kernel_times then returns the per-kernel device times of the call (summed over the launches of one kernel). */
-enum { O2V_HIP_FLAG_EXACT_CLIP = 1u, O2V_HIP_FLAG_KERNEL_TIMES = 2u };
+ * o2v_hip_get_kernel_times then returns the per-kernel device times of the call (summed over the launches of one kernel).
+ * Implies STAGE_TIMES.
+ * STAGE_TIMES: records a HIP event before, between and behind the stages of a pass, for o2v_hip_timings' stage times and
+ * total_ms.  Not the default because an event between two kernels is a command of its own in the queue and costs about 4 us
+ * of device time (six of them: 3 % of the bench headline's step, profiles/r05/NOTES.md). */
+enum { O2V_HIP_FLAG_EXACT_CLIP = 1u, O2V_HIP_FLAG_KERNEL_TIMES = 2u, O2V_HIP_FLAG_STAGE_TIMES = 4u };
 
-/* Per-stage device times of the last o2v_hip_voxelize call, measured with hipEvents on the pipeline's stream. */
+/* Device times of the last o2v_hip_voxelize call.  voxelize_ms is measured in every call (two hipEvents that ride on the clip
+ * kernel's own dispatch), passes and plan_ms likewise; the other stage times, total_ms and the collectives' times only in a call
+ * made with O2V_HIP_FLAG_STAGE_TIMES (else 0) - then voxelize_ms, too, is the time between two events on the stream, and every
+ * timed collective of a sharded run is followed by a wait on the host (three more round trips per call). */
 typedef struct {
     float bounds_ms;     /* K0  mesh bounds reduce + transform setup */
     float expand_ms;     /* K1  transform, classify, exact subdivision into leaves and tiles */
@@ -80,10 +87,11 @@ typedef struct {
                             (host wall time; not part of total_ms) */
     float collective_ms; /* ... of which inside the collectives (all-reduce of bounds and histogram, all-gather of the
                             block extents and of the slab counts) */
-    float collective_parts_ms[5]; /* the same by collective, device time on the context's stream: [0] readiness word
-                            (all-reduce max of 4 bytes), [1] mesh bounds (all-reduce min + max of 3 x u32), [2] z histogram of
-                            predicted work (all-reduce sum of 2048 x u64), [3] block z extents (all-gather, 8 bytes per 256
-                            triangles), [4] slab voxel counts (all-gather, 8 bytes per rank) */
+    float collective_parts_ms[5]; /* the same by collective, device time on the context's stream: [0] the ranks' readiness words
+                            and the mesh bounds in one all-reduce (max of 7 x u32: the minima travel as their complements),
+                            [1] unused (0) by the sharded run, [2] z histogram of predicted work (all-reduce sum of 2048 x
+                            u64), [3] block z extents (all-gather, 8 bytes per 256 triangles), [4] slab voxel counts
+                            (all-gather, 8 bytes per rank) */
 } o2v_hip_timings;
 
 /* Work counters of the last o2v_hip_voxelize call. */
@@ -224,8 +232,8 @@ int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32);
  * src/voxelization.cpp:440-444).  Voxel data never crosses GPUs: each output voxel is owned by exactly one slab and the
  * union of the slabs is bit-identical to the single-GPU result.  What the ranks exchange is planning data, with RCCL over
  * xGMI: the passes over the triangle list that find the mesh bounds and the z histogram of predicted work are SHARDED
- * (rank r streams triangles [r, r+1) * T / N only) and combined with an all-reduce (min/max of 6 floats; sum of 2048 u64),
- * the z extent of every block of 256 triangles is all-gathered (so that each rank can skip the blocks that miss its slab
+ * (rank r streams triangles [r, r+1) * T / N only) and combined with an all-reduce (max of 7 words: the six bounds - the
+ * minima as complements - and a "this rank cannot go ahead" word; sum of 2048 u64), the z extent of every block of 256 triangles is all-gathered (so that each rank can skip the blocks that miss its slab
  * without reading them), and the per-slab voxel counts are all-gathered (output offsets for the sink).
  *
  * Two ways to use it:

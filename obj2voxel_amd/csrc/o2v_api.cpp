@@ -546,6 +546,7 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session,
     params.bounds_known = inst.bounds_known ? 1u : 0u;
     for (int i = 0; i < 6; ++i) params.bounds[i] = inst.mesh_bounds[i];
     params.z_begin = params.z_end = 0;
+    if (g_log_level >= OBJ2VOXEL_LOG_LEVEL_DEBUG) params.flags |= O2V_HIP_FLAG_STAGE_TIMES;  // (log_pipeline prints the device time)
 
     const uint32_t n_ranks = session->ranks();
     std::vector<uint64_t> counts(n_ranks, 0);

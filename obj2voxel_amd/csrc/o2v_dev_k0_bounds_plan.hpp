@@ -15,6 +15,24 @@ __global__ void k_init(Counters *c)
     else if (i < 6) c->bounds_enc[i] = f2ord(-__builtin_inff());
 }
 
+// Sharded runs: the six bounds of this rank's triangles and its "not ready" word travel in ONE max-reduce over the ranks (the
+// minima as their complements: the encoding is order preserving, so min x = ~max ~x).
+constexpr uint32_t kReadyWords = 8;  // 3 complemented minima, 3 maxima, the status word, one spare
+__global__ void k_pack_ready(const Counters *__restrict__ c, uint32_t *__restrict__ words, uint32_t status)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < 3) words[i] = ~c->bounds_enc[i];
+    else if (i < 6) words[i] = c->bounds_enc[i];
+    else if (i == 6) words[i] = status;
+    else if (i == 7) words[i] = 0u;
+}
+__global__ void k_unpack_ready(const uint32_t *__restrict__ words, Counters *__restrict__ c)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < 3) c->bounds_enc[i] = ~words[i];
+    else if (i < 6) c->bounds_enc[i] = words[i];
+}
+
 // findMeshBounds (obj2voxel.cpp:180-200): min/max are exact and order-free, so one reduce replaces the batches.
 // The vertex array is streamed as float4 triples (12 floats = 4 vertices, so the axis of every element is static);
 // one set of six atomics per workgroup.

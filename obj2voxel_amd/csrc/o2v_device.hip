@@ -38,6 +38,7 @@
 #endif
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -97,6 +98,7 @@ struct o2v_hip_ctx {
     // work buffers (grown on demand)
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;  // pinned
+    bool stage_events = false;  // this call records an event between the stages of a pass (O2V_HIP_FLAG_STAGE_TIMES)
     uint64_t no_pool_key = 0;   // (key + 1 of) the mesh and settings whose last pass pooled no hits (run_pass: k_mark_bricks left out)
     bool marked_bricks = false, mark_missing = false; // the current pass listed its bricks before k_voxelize
     bool skip_big = false;      // no leaf of the uploaded mesh can have more than four tiles (its largest triangle's extent): k_expand_big left out
@@ -253,6 +255,19 @@ bool debug_sync_enabled() { return debug_sync_level() != 0; }
         O2V_STAGE(name);                                                         \
     } while (0)
 
+// k_voxelize's launch: without the stage events (the default) its duration is still measured, by two events that ride on the
+// kernel's own dispatch (hipExtLaunchKernelGGL: the start and end times of that dispatch).  Measured on the bench headline, per
+// step: these two 0.004 - 0.006 ms together, an event recorded on the stream between two kernels ~0.004 ms each - the six of
+// O2V_HIP_FLAG_STAGE_TIMES 0.02 - 0.025 ms of a 0.5 ms step (profiles/r05/NOTES.md).
+#define O2V_LAUNCH_K2(name, kernel, grid, block, ...)                                                               \
+    do {                                                                                                            \
+        if (ctx->stage_events || ctx->ktimes_on) O2V_LAUNCH(name, s, kernel, grid, block, 0, s, __VA_ARGS__);       \
+        else {                                                                                                      \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, s, ctx->ev[2], ctx->ev[3], 0, __VA_ARGS__);               \
+            O2V_STAGE(name);                                                                                        \
+        }                                                                                                           \
+    } while (0)
+
 int ktime_begin(o2v_hip_ctx *ctx, const char *name, hipStream_t stream)
 {
     if (!ctx->ktimes_on) return -1;
@@ -372,7 +387,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     hipStream_t s = ctx->stream;
     const uint32_t persistent = (uint32_t) ctx->num_cus * 8u;
     ctx->ktimes_used = 0;
-    O2V_CHECK(hipEventRecord(ctx->ev[0], s));
+    if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[0], s));
     // (the counters were zeroed behind the previous pass, off its critical path, unless something else used them since)
     if (!ctx->ctr_clean) O2V_LAUNCH("k_init", s, k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
     ctx->ctr_clean = false;
@@ -384,7 +399,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
     // (letting the last workgroup of k_bounds compute the transform - one launch less - was measured: the stage 0.021 -> 0.027 ms)
     O2V_LAUNCH("k_setup", s, k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
-    O2V_CHECK(hipEventRecord(ctx->ev[1], s));
+    if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[1], s));
 
     // After a slab plan the z extent of every block of 256 triangles is known: a slab that is not the whole grid visits only
     // the blocks that meet it (on N GPUs ~1/N of the list, compacted by k_list_blocks).
@@ -429,8 +444,10 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
                            dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, ctx->d_ctr, ctx->d_brick_slab, ctx->force_general ? 1u : 0u, p);
     }
-    O2V_CHECK(hipEventRecord(ctx->ev[2], s));
-    if (p.direct_max) {
+    if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[2], s));
+    // (occupancy only: every hit takes the direct path whatever K1 counted - nothing to decide)
+    const bool decide_from_k1 = p.direct_max && !(p.occupancy_only && !ctx->force_general);
+    if (decide_from_k1) {
         // K1's counters go to the host on an auxiliary stream while k_voxelize runs (see below)
         O2V_CHECK(hipEventRecord(ctx->ev_k1, s));
         O2V_CHECK(hipStreamWaitEvent(ctx->aux[0], ctx->ev_k1, 0));
@@ -441,21 +458,21 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         // persistent workgroups: four wavefronts per SIMD, in workgroups of VoxShape<UV>::block threads
         if (use_uv) {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES_UV * (kBlock / VoxShape<true>::block);
-            O2V_LAUNCH("k_voxelize<true>", s, k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+            O2V_LAUNCH_K2("k_voxelize<true>", k_voxelize<true>, dim3(blocks), dim3(VoxShape<true>::block), ctx->d_leaves, ctx->d_tiles,
+                          ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
         else if (p.occupancy_only) {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
-            O2V_LAUNCH("k_voxelize_occ", s, k_voxelize_occ, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, ctx->d_verts, block_list, ctx->d_block_count, p);
+            O2V_LAUNCH_K2("k_voxelize_occ", k_voxelize_occ, dim3(blocks), dim3(VoxShape<false>::block), ctx->d_leaves, ctx->d_tiles,
+                          ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, ctx->d_verts, block_list, ctx->d_block_count, p);
         }
         else {
             const uint32_t blocks = (uint32_t) ctx->num_cus * (uint32_t) O2V_K2_WAVES * (kBlock / VoxShape<false>::block);
-            O2V_LAUNCH("k_voxelize<false>", s, k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), 0, s, ctx->d_leaves, ctx->d_tiles,
-                               ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
+            O2V_LAUNCH_K2("k_voxelize<false>", k_voxelize<false>, dim3(blocks), dim3(VoxShape<false>::block), ctx->d_leaves, ctx->d_tiles,
+                          ctx->d_ctr, ctx->d_grid, ctx->d_brick_dirty, ctx->d_pool, ctx->d_jobq, p);
         }
     }
-    O2V_CHECK(hipEventRecord(ctx->ev[3], s));
+    if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[3], s));
 
     // With the direct MAX path the rest of the pass depends on the mesh: one whose triangles are all voxelized whole needs
     // neither the counting sort nor the replay (a dozen launches that would each find nothing), one whose triangles are
@@ -463,12 +480,18 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     // while k_voxelize was running: the follow-up stages are enqueued behind it without the stream ever draining.
     bool run_general = true, run_emit = false;
     if (p.direct_max) {
-        O2V_CHECK(hipStreamSynchronize(ctx->aux[0]));
-        const Counters &h = *ctx->h_ctr;
-        run_emit = p.occupancy_only || h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
-        // hits are pooled only for leaves of subdivided triangles: without any, every hit goes straight into the 64-bit grid
-        // (occupancy-only mode: those too)
-        run_general = !run_emit || (h.n_nodes[0] != 0 && !p.occupancy_only) || ctx->force_general;
+        if (decide_from_k1) {
+            O2V_CHECK(hipStreamSynchronize(ctx->aux[0]));
+            const Counters &h = *ctx->h_ctr;
+            run_emit = p.occupancy_only || h.n_nodes[0] <= h.n_root_leaves;  // direct_active() on the device
+            // hits are pooled only for leaves of subdivided triangles: without any, every hit goes straight into the 64-bit grid
+            // (occupancy-only mode: those too)
+            run_general = !run_emit || (h.n_nodes[0] != 0 && !p.occupancy_only) || ctx->force_general;
+        }
+        else {
+            run_emit = true;
+            run_general = false;
+        }
         if (run_emit) {
             const uint32_t groups = (p.n_bricks + 15u) / 16u;
             O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
@@ -493,7 +516,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                            ctx->d_dirty_list, ctx->d_ctr, ctx->d_occ, lists, p);
     }
     ctx->last_ran_general = run_general;
-    O2V_CHECK(hipEventRecord(ctx->ev[4], s));
+    if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[4], s));
 
     Materials m{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
     if (run_general) {
@@ -590,7 +613,8 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
                                ctx->d_out, p);
         }
     }
-    O2V_CHECK(hipEventRecord(ctx->ev[5], s));
+    if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[5], s));
+    // (a kernel that writes the counters into the page-locked copy instead of this copy command was measured: the same step time)
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipStreamSynchronize(s));
     O2V_CHECK(hipGetLastError());
@@ -1064,6 +1088,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     const GridModes modes = grid_modes(ctx, params);
     p.exact_clip = modes.exact_clip ? 1u : 0u;
     ctx->ktimes_on = (params->flags & O2V_HIP_FLAG_KERNEL_TIMES) != 0;
+    ctx->stage_events = (params->flags & (O2V_HIP_FLAG_STAGE_TIMES | O2V_HIP_FLAG_KERNEL_TIMES)) != 0;
     ctx->kernel_times.clear();
     const bool use_uv = modes.use_uv;
     ctx->sorted_stride = use_uv ? 6u : 4u;
@@ -1417,14 +1442,17 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             ctx->stats.pool_slots = h.n_hits_reserved;
             std::memcpy(ctx->xform, h.xform, sizeof(ctx->xform));
             for (int i = 0; i < 16; ++i) ctx->dbg[i] = h.dbg[i];
-            float ms[5];
-            for (int i = 0; i < 5; ++i) O2V_CHECK(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+            float ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ctx->stage_events) {
+                for (int i = 0; i < 5; ++i) O2V_CHECK(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+                O2V_CHECK(hipEventElapsedTime(&ctx->timings.total_ms, ctx->ev[0], ctx->ev[5]));
+            }
+            else O2V_CHECK(hipEventElapsedTime(&ms[2], ctx->ev[2], ctx->ev[3]));  // (k_voxelize's own dispatch: O2V_LAUNCH_K2)
             ctx->timings.bounds_ms = ms[0];
             ctx->timings.expand_ms = ms[1];
             ctx->timings.voxelize_ms = ms[2];
             ctx->timings.scan_ms = ms[3];
             ctx->timings.resolve_ms = ms[4];
-            O2V_CHECK(hipEventElapsedTime(&ctx->timings.total_ms, ctx->ev[0], ctx->ev[5]));
             if (out_voxel_count) *out_voxel_count = ctx->n_vox;
             return O2V_HIP_OK;
         }
@@ -1442,8 +1470,13 @@ namespace {
 // histogram of predicted work and the z extent of every block of 256 triangles.  With a communicator the partial results
 // are combined over the ranks: min / max of the bounds, sum of the histogram, all-gather of the block extents
 // (`blocks_per_rank` blocks each).  Afterwards the histogram is in ctx->h_zhist and the counters in ctx->h_ctr.
+// `bounds_reduced`: the counters already hold the bounds of the whole mesh (o2v_hip_voxelize_sharded reduces them together with
+// the ranks' readiness word); else they are computed - and, with a communicator, reduced - here.
+// The collectives are timed (collective_ms, parts_ms: two events and a wait for each) only in a call with
+// O2V_HIP_FLAG_STAGE_TIMES: each wait is a round trip to the host that the step otherwise does not make.
 int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_begin, uint64_t tri_end, o2v_hip_comm *comm,
-                uint64_t blocks_per_rank, uint32_t &n_bins, uint32_t &bin_out, float *collective_ms, float *parts_ms = nullptr)
+                uint64_t blocks_per_rank, uint32_t &n_bins, uint32_t &bin_out, float *collective_ms, float *parts_ms = nullptr,
+                bool bounds_reduced = false)
 {
     const uint32_t ss = params->supersampling ? params->supersampling : 1u;
     const uint32_t G = params->resolution;
@@ -1469,7 +1502,9 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
 
     hipStream_t s = ctx->stream;
     float coll_ms = 0.f;
+    const bool measure = (params->flags & (O2V_HIP_FLAG_STAGE_TIMES | O2V_HIP_FLAG_KERNEL_TIMES)) != 0 && ctx->ev_coll[0] && ctx->ev_coll[1];
     auto timed = [&](int part, auto &&collectives) -> int {
+        if (!measure) return collectives();
         O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s));
         const int rc = collectives();
         if (rc) return rc;
@@ -1486,8 +1521,8 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
         return rc;
     };
     ctx->ctr_clean = false;
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
-    if (!p.bounds_known) {
+    if (!bounds_reduced) hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    if (!p.bounds_known && !bounds_reduced) {
         if (n_range)
             hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_range * 9 / 12 + kBlock) / kBlock)),
                                dim3(kBlock), 0, s, ctx->d_verts + tri_begin * 9, n_range * 9, ctx->d_ctr);
@@ -1632,7 +1667,7 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
         return O2V_HIP_ERR_HIP;  // (nothing can be communicated from a rank without its device)
     }
     if (!ctx->d_status) {
-        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_status), sizeof(uint32_t)) != hipSuccess ||
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_status), kReadyWords * sizeof(uint32_t)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
             ctx->err = "allocating the status word failed";
             return O2V_HIP_ERR_OUT_OF_MEMORY;
@@ -1641,6 +1676,7 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
     const uint64_t T = ctx->n_tris, n_blocks = (T + kBlock - 1) / kBlock;
     const uint64_t bpr = std::max<uint64_t>(1, (n_blocks + world - 1) / world);
     float parts_ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool measure_collectives = (params->flags & (O2V_HIP_FLAG_STAGE_TIMES | O2V_HIP_FLAG_KERNEL_TIMES)) != 0;
     int rc_prepare = O2V_HIP_OK;
     {
         auto prepare = [&]() -> int {
@@ -1674,23 +1710,28 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
             ctx->err = "O2V_TEST_FAIL_RANK: simulated failure of this rank before the collectives";  // test hook
             rc_prepare = O2V_HIP_ERR_OUT_OF_MEMORY;
         }
+        // One max-reduce carries the ranks' "not ready" words and - unless the caller gave the bounds - the bounds of every rank's
+        // share of the triangles (k_pack_ready): the first collective of the step, and the only one before the histogram.
         hipStream_t s0 = ctx->stream;
-        *ctx->h_status = rc_prepare ? 1u : 0u;
-        // (a HIP error here must not skip the all-reduce either: it is noted and returned once every rank has been through it)
-        hipError_t e_local = hipMemcpyAsync(ctx->d_status, ctx->h_status, sizeof(uint32_t), hipMemcpyHostToDevice, s0);
-        bool time_it = ctx->ev_coll[0] && ctx->ev_coll[1];
-        if (time_it && hipEventRecord(ctx->ev_coll[0], s0) != hipSuccess) time_it = false;
-        if (e_local != hipSuccess && !rc_prepare) {
-            ctx->err = std::string("hipMemcpyAsync(status word): ") + hipGetErrorString(e_local);
-            rc_prepare = O2V_HIP_ERR_HIP;
-        }
+        const uint64_t b0r = std::min<uint64_t>(n_blocks, (uint64_t) rank * bpr), b1r = std::min<uint64_t>(n_blocks, (uint64_t) (rank + 1) * bpr);
+        const uint64_t share_begin = b0r * kBlock, share_end = std::min<uint64_t>(T, b1r * kBlock);
+        const uint64_t n_share = share_end > share_begin ? share_end - share_begin : 0;
+        ctx->ctr_clean = false;
+        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s0, ctx->d_ctr);
+        if (!params->bounds_known && !rc_prepare && n_share)
+            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_share * 9 / 12 + kBlock) / kBlock)),
+                               dim3(kBlock), 0, s0, ctx->d_verts + share_begin * 9, n_share * 9, ctx->d_ctr);
+        hipLaunchKernelGGL(k_pack_ready, dim3(1), dim3(64), 0, s0, ctx->d_ctr, ctx->d_status, rc_prepare ? 1u : 0u);
+        const bool time_it = measure_collectives && ctx->ev_coll[0] && ctx->ev_coll[1];
+        if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s0));
         const std::string prepare_err = ctx->err;
-        if (comm->allreduce_max_u32(ctx->d_status, 1, s0)) {
+        if (comm->allreduce_max_u32(ctx->d_status, 7, s0)) {
             ctx->err = std::string("collective failed: ") + comm->err;
             return O2V_HIP_ERR_HIP;
         }
         if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s0));
-        O2V_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, s0));
+        hipLaunchKernelGGL(k_unpack_ready, dim3(1), dim3(64), 0, s0, ctx->d_status, ctx->d_ctr);
+        O2V_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, s0));
         // (the first collective of the run: if a rank of the job never gets here - it died, or the node is set up wrongly - the
         // others say so after o2v::comm_timeout_seconds() instead of waiting for ever)
         if (!o2v::stream_wait_limited(s0, "the readiness all-reduce of the sharded run", ctx->err)) return O2V_HIP_ERR_HIP;
@@ -1710,7 +1751,7 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
     const uint64_t tri_begin = b0 * kBlock, tri_end = std::min<uint64_t>(T, b1 * kBlock);
     uint32_t n_bins = 0, bin_out = 0;
     float coll_ms = 0.f;
-    int rc = plan_passes(ctx, params, tri_begin, tri_end, comm, bpr, n_bins, bin_out, &coll_ms, parts_ms);
+    int rc = plan_passes(ctx, params, tri_begin, tri_end, comm, bpr, n_bins, bin_out, &coll_ms, parts_ms, /*bounds_reduced=*/true);
     if (rc) return rc;
     std::vector<uint32_t> cuts(world + 1);
     cuts_from_histogram(ctx->h_zhist, n_bins, bin_out, params->resolution, world, cuts.data());
@@ -1731,17 +1772,18 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
     ctx->h_counts[rank] = rc_vox ? ~0ull : n;
     const std::string vox_err = ctx->err;
     O2V_CHECK(hipMemcpyAsync(ctx->d_counts + rank, ctx->h_counts + rank, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-    O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s));
+    const bool time_counts = measure_collectives && ctx->ev_coll[0] && ctx->ev_coll[1];
+    if (time_counts) O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s));
     rc = comm->allgather(ctx->d_counts, sizeof(unsigned long long), s);
     if (rc) {
         ctx->err = std::string("collective failed: ") + comm->err;
         return rc;
     }
-    O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s));
+    if (time_counts) O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, world * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipStreamSynchronize(s));
     float ms = 0.f;
-    O2V_CHECK(hipEventElapsedTime(&ms, ctx->ev_coll[0], ctx->ev_coll[1]));
+    if (time_counts) O2V_CHECK(hipEventElapsedTime(&ms, ctx->ev_coll[0], ctx->ev_coll[1]));
     parts_ms[4] = ms;
     ctx->timings.plan_ms = plan_ms;
     ctx->timings.collective_ms = coll_ms + ms + parts_ms[0];

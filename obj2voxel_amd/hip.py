@@ -16,6 +16,7 @@ class _Params(C.Structure):
 
 
 FLAG_KERNEL_TIMES = 2  # ... every launch bracketed by events: DeviceVoxelizer.kernel_times()
+FLAG_STAGE_TIMES = 4   # ... an event between the stages of a pass: the stage times and total_ms of DeviceVoxelizer.timings()
 FLAG_EXACT_CLIP = 1  # o2v_hip_params::flags: the clip kernel without its work-removal shortcuts (include/o2v_hip.h)
 
 
@@ -31,7 +32,7 @@ class Timings(C.Structure):
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
-        d["collective_parts_ms"] = [float(x) for x in self.collective_parts_ms]   # status, bounds, histogram, block extents, counts
+        d["collective_parts_ms"] = [float(x) for x in self.collective_parts_ms]   # status + bounds (one reduce), bounds alone (o2v_hip_plan_slabs), histogram, block extents, counts
         return d
 
 
@@ -226,9 +227,10 @@ class DeviceVoxelizer:
         return [int(z) for z in cuts], bnd
 
     def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
-                 zslab=(0, 0), read=True, exact_clip=False, kernel_times=False):
+                 zslab=(0, 0), read=True, exact_clip=False, kernel_times=False, stage_times=False):
         p = self._params(resolution, supersampling, strategy, unit_transform, bounds, zslab,
-                         (FLAG_EXACT_CLIP if exact_clip else 0) | (FLAG_KERNEL_TIMES if kernel_times else 0))
+                         (FLAG_EXACT_CLIP if exact_clip else 0) | (FLAG_KERNEL_TIMES if kernel_times else 0) |
+                         (FLAG_STAGE_TIMES if stage_times else 0))
         n = C.c_uint64(0)
         self._check(self._L.o2v_hip_voxelize(self._ctx, C.byref(p), C.byref(n)), "o2v_hip_voxelize")
         self.count = n.value
@@ -237,10 +239,10 @@ class DeviceVoxelizer:
         return self.read_voxels()
 
     def voxelize_sharded(self, comm, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
-                         read=True):
+                         read=True, stage_times=False):
         """o2v_hip_voxelize_sharded: collective over `comm` (a Comm); this rank voxelizes its planned z-slab.
         Returns (voxels or count of this rank, counts of all ranks, z cuts)."""
-        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0))
+        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0), FLAG_STAGE_TIMES if stage_times else 0)
         n = C.c_uint64(0)
         counts = np.zeros(comm.world, dtype=np.uint64)
         cuts = np.zeros(comm.world + 1, dtype=np.uint32)
@@ -455,9 +457,10 @@ class DeviceGroup:
             arr[i] = _Texture(pix.ctypes.data, w, h, c, int(wrap))
         self._check(self._L.o2v_hip_group_set_textures(self._g, C.cast(arr, C.c_void_p), len(textures)), "o2v_hip_group_set_textures")
 
-    def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None, read=True):
+    def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None, read=True,
+                 stage_times=False):
         """Returns (list of per-rank voxel arrays, or the per-rank counts if read=False; z cuts)."""
-        p = DeviceVoxelizer._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0))
+        p = DeviceVoxelizer._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0), FLAG_STAGE_TIMES if stage_times else 0)
         counts = np.zeros(self.size, dtype=np.uint64)
         cuts = np.zeros(self.size + 1, dtype=np.uint32)
         self._check(self._L.o2v_hip_group_voxelize(self._g, C.byref(p), _ptr(counts), _ptr(cuts)), "o2v_hip_group_voxelize")

@@ -41,6 +41,28 @@ def test_kernel_times_cover_the_pipeline():
     assert abs(kt["k_voxelize<false>"][0] - tm["voxelize_ms"]) < 0.05 + 0.2 * tm["voxelize_ms"]
 
 
+def test_stage_times_only_on_request():
+    """o2v_hip_timings: the clip kernel's duration is measured in every call (events on its own dispatch), the stage intervals and
+    total_ms only with O2V_HIP_FLAG_STAGE_TIMES (an event between two kernels costs device time)."""
+    from obj2voxel_amd import hip
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_triangles(meshes.uv_sphere(120))
+        d.voxelize(512, read=False)
+        d.voxelize(512, read=False)
+        plain = d.timings()
+        d.voxelize(512, read=False, stage_times=True)
+        staged = d.timings()
+    finally:
+        d.close()
+    assert plain["total_ms"] == 0 and plain["bounds_ms"] == 0 and plain["resolve_ms"] == 0
+    assert plain["voxelize_ms"] > 0
+    assert all(staged[k] > 0 for k in ("bounds_ms", "expand_ms", "voxelize_ms", "scan_ms", "resolve_ms", "total_ms"))
+    assert staged["total_ms"] >= staged["voxelize_ms"]
+    # the same kernel on the same input, measured both ways
+    assert abs(plain["voxelize_ms"] - staged["voxelize_ms"]) < 0.02 + 0.25 * staged["voxelize_ms"], (plain, staged)
+
+
 def test_bench_line_routes_and_assets(tmp_path):
     _write_obj(tmp_path / "dragon.obj", meshes.uv_sphere(40))
     _write_obj(tmp_path / "spot.obj", meshes.uv_sphere(16))
@@ -76,8 +98,9 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "zslab2" and line["value"] > 0
     col = line["config"]["collectives"]
     assert col["world"] == 2 and col["backend"] == "callbacks"
-    assert set(col["per_collective_ms_rank0"]) == {"ready_allreduce_4B", "bounds_allreduce_24B", "histogram_allreduce_16KiB",
+    assert set(col["per_collective_ms_rank0"]) == {"ready_and_bounds_allreduce_28B", "histogram_allreduce_16KiB",
                                                    "block_extents_allgather", "slab_counts_allgather"}
+    assert all(v > 0 for v in col["per_collective_ms_rank0"].values()), col
     assert sum(col["per_collective_ms_rank0"].values()) > 0
     up = line["config"]["upload"]
     assert up["h2d_per_rank_ms"] > 0 and "h2d_rank0_plus_rccl_broadcast_ms" not in up

@@ -55,7 +55,7 @@ def test_group_union_equals_single_gpu_and_oracle(oracle, n_ranks, upload):
         assert g.comm_kind == ("rccl" if hip.device_count() >= n_ranks else "callbacks")
         v = meshes.uv_sphere(70)
         g.set_triangles(v, upload=upload)
-        parts, cuts = g.voxelize(160)
+        parts, cuts = g.voxelize(160, stage_times=True)
         assert cuts[0] == 0 and cuts[-1] == 160 and all(a < b for a, b in zip(cuts, cuts[1:]))
         for r, p in enumerate(parts):
             assert ((p[:, 2] >= cuts[r]) & (p[:, 2] < cuts[r + 1])).all()
@@ -125,7 +125,9 @@ def test_rccl_collectives_run_on_this_box(oracle, monkeypatch):
         d.set_triangles(v)
         got, counts, cuts = d.voxelize_sharded(comm, 100)
         assert counts == [len(got)] and cuts == [0, 100]
-        assert d.timings()["collective_ms"] > 0
+        assert d.timings()["collective_ms"] == 0        # timing a collective is a wait on the host: only on request
+        got, counts, cuts = d.voxelize_sharded(comm, 100, stage_times=True)
+        assert d.timings()["collective_ms"] > 0 and all(x > 0 for x in d.timings()["collective_parts_ms"][:1] + d.timings()["collective_parts_ms"][2:])
         assert np.array_equal(meshes.sorted_voxels(got), meshes.sorted_voxels(oracle.voxelize(v, 100)))
     finally:
         d.close()

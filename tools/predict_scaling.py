@@ -46,6 +46,7 @@ for r in range(n):
         cnt = dv.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False)
         walls.append((time.perf_counter() - t0) * 1e3)
     wall = sorted(walls)[len(walls) // 2]   # median: a single host hiccup must not decide the slowest slab
+    dv.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, read=False, stage_times=True)   # (the stage times: one more pass)
     st, t = dv.stats(), dv.timings()
     rows.append({"rank": r, "z": [cuts[r], cuts[r + 1]], "voxels": cnt, "leaves": st["leaves"], "hits": st["hits"],
                  "ms": round(wall, 3), "stages": {k: round(v, 3) for k, v in t.items() if k.endswith("_ms") and isinstance(v, float)}})

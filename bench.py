@@ -598,10 +598,10 @@ def report(args, n, run, dv, comm):
                        "collective_ms_rank0": round(stages_ms["collective_ms"], 4),
                        # device time of each collective on rank 0 (it includes waiting for the slowest rank to arrive)
                        # (measured in the extra steps made with O2V_HIP_FLAG_STAGE_TIMES: timing a collective is a wait on the host;
-                       # the ranks' readiness words and the mesh bounds travel in one max-reduce)
-                       "per_collective_ms_rank0": dict(zip(("ready_and_bounds_allreduce_28B", "histogram_allreduce_16KiB",
-                                                            "block_extents_allgather", "slab_counts_allgather"),
-                                                           (lambda q: [round(q[0] + q[1], 4)] + [round(x, 4) for x in q[2:]])(run.get("collective_parts_ms", [0.0] * 5))))}},
+                       # the ranks' readiness words and the mesh bounds travel in one max-reduce, the partial histograms and the block extents in one all-gather)
+                       "per_collective_ms_rank0": dict(zip(("ready_and_bounds_allreduce_28B", "histogram_and_block_extents_allgather",
+                                                            "slab_counts_allgather"),
+                                                           (lambda q: [round(q[0] + q[1], 4), round(q[2] + q[3], 4), round(q[4], 4)])(run.get("collective_parts_ms", [0.0] * 5))))}},
         "roofline": roofline, "roofline_hbm_view": hbm_view if roofline is not hbm_view else None, "stages": stages, "pipeline": pipeline,
         "steady_state": "steps 2.. of one uploaded mesh: buffers sized, counters zeroed behind the previous step, and the coloured-MAX routes reuse "
                         "the previous step's finding that no hit is pooled (two launches left out); a single-use obj2voxel_instance pays the first "

@@ -89,9 +89,9 @@ typedef struct {
                             block extents and of the slab counts) */
     float collective_parts_ms[5]; /* the same by collective, device time on the context's stream: [0] the ranks' readiness words
                             and the mesh bounds in one all-reduce (max of 7 x u32: the minima travel as their complements),
-                            [1] unused (0) by the sharded run, [2] z histogram of predicted work (all-reduce sum of 2048 x
-                            u64), [3] block z extents (all-gather, 8 bytes per 256 triangles), [4] slab voxel counts
-                            (all-gather, 8 bytes per rank) */
+                            [1] unused (0), [2] every rank's z histogram of predicted work (2048 x u64) and the z extents of
+                            its blocks (8 bytes per 256 triangles) in one all-gather - each rank adds the histograms up itself -
+                            [3] unused (0), [4] slab voxel counts (all-gather, 8 bytes per rank) */
 } o2v_hip_timings;
 
 /* Work counters of the last o2v_hip_voxelize call. */
@@ -232,9 +232,10 @@ int o2v_hip_debug_hits_histogram(o2v_hip_ctx *ctx, uint64_t *out32);
  * src/voxelization.cpp:440-444).  Voxel data never crosses GPUs: each output voxel is owned by exactly one slab and the
  * union of the slabs is bit-identical to the single-GPU result.  What the ranks exchange is planning data, with RCCL over
  * xGMI: the passes over the triangle list that find the mesh bounds and the z histogram of predicted work are SHARDED
- * (rank r streams triangles [r, r+1) * T / N only) and combined with an all-reduce (max of 7 words: the six bounds - the
- * minima as complements - and a "this rank cannot go ahead" word; sum of 2048 u64), the z extent of every block of 256 triangles is all-gathered (so that each rank can skip the blocks that miss its slab
- * without reading them), and the per-slab voxel counts are all-gathered (output offsets for the sink).
+ * (rank r streams triangles [r, r+1) * T / N only).  Three collectives per run: an all-reduce (max of 7 words: the six bounds -
+ * the minima as complements - and a "this rank cannot go ahead" word); an all-gather of every rank's partial histogram (2048 u64,
+ * added up by every rank itself) together with the z extents of its blocks of 256 triangles (so that each rank can skip the
+ * blocks that miss its slab without reading them); an all-gather of the per-slab voxel counts (output offsets for the sink).
  *
  * Two ways to use it:
  *   one process per GPU   o2v_hip_comm_unique_id on rank 0 -> ship the 128 bytes to every rank (MPI, torch.distributed,

@@ -33,6 +33,36 @@ __global__ void k_unpack_ready(const uint32_t *__restrict__ words, Counters *__r
     else if (i < 6) c->bounds_enc[i] = words[i];
 }
 
+// Sharded runs: a rank's partial z histogram and the z extents of its blocks travel in ONE all-gather (a record per rank: kPlanBins
+// sums, then `bpr` extents); every rank then adds the histograms up itself (integer sums: the same on every rank).
+__global__ __launch_bounds__(kBlock) void k_pack_plan(const unsigned long long *__restrict__ hist, const float2 *__restrict__ my_extents,
+                                                      unsigned long long *__restrict__ record, uint32_t bpr)
+{
+    float2 *ext = reinterpret_cast<float2 *>(record + 2048);
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < 2048u + bpr; t += gridDim.x * kBlock) {
+        if (t < 2048u) record[t] = hist[t];
+        else ext[t - 2048u] = my_extents[t - 2048u];
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_plan(const unsigned long long *__restrict__ records, uint32_t world, uint32_t bpr,
+                                                        unsigned long long *__restrict__ hist, float2 *__restrict__ extents)
+{
+    const uint64_t rec_words = 2048u + bpr;  // (a float2 is one 8-byte word)
+    const uint64_t n = 2048u + (uint64_t) world * bpr;
+    for (uint64_t t = (uint64_t) blockIdx.x * kBlock + threadIdx.x; t < n; t += (uint64_t) gridDim.x * kBlock) {
+        if (t < 2048u) {
+            unsigned long long sum = 0;
+            for (uint32_t r = 0; r < world; ++r) sum += records[r * rec_words + t];
+            hist[t] = sum;
+        }
+        else {
+            const uint64_t j = t - 2048u;
+            const uint32_t r = (uint32_t) (j / bpr), i = (uint32_t) (j % bpr);
+            extents[j] = reinterpret_cast<const float2 *>(records + r * rec_words + 2048u)[i];
+        }
+    }
+}
+
 // findMeshBounds (obj2voxel.cpp:180-200): min/max are exact and order-free, so one reduce replaces the batches.
 // The vertex array is streamed as float4 triples (12 floats = 4 vertices, so the axis of every element is static);
 // one set of six atomics per workgroup.
@@ -156,6 +186,7 @@ __global__ void k_setup(Counters *c, Params p)
 // spreads that estimate over the triangle's z layers into <= 2048 bins (fixed point, integer atomics: the result
 // does not depend on the order of the adds, so every rank derives the same cuts).
 constexpr uint32_t kPlanBins = 2048;
+static_assert(kPlanBins == 2048, "k_pack_plan / k_unpack_plan are written for 2048 bins");
 #ifndef O2V_PLAN_LEAF_COST
 #define O2V_PLAN_LEAF_COST 4.0f
 #endif

@@ -107,6 +107,8 @@ struct o2v_hip_ctx {
     hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     unsigned long long *d_zhist = nullptr, *h_zhist = nullptr;  // kPlanBins each (h_: pinned), o2v_hip_plan_slabs
     float2 *d_zrange = nullptr;      // z extent per 256 triangles, written by the slab plan
+    unsigned long long *d_plan_gather = nullptr;  // sharded runs: one record per rank (k_pack_plan), all-gathered
+    uint32_t cap_plan_gather = 0;                 // ... in 8-byte words
     float *d_zrange_xform = nullptr;  // the transform they were computed with (12 floats)
     uint32_t cap_zrange = 0;
     uint32_t *d_block_list = nullptr, *d_block_count = nullptr;  // the blocks of 256 triangles that meet the slab (k_list_blocks)
@@ -788,6 +790,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->h_ctr) (void) hipHostFree(ctx->h_ctr);
     if (ctx->d_zhist) (void) hipFree(ctx->d_zhist);
     if (ctx->d_zrange) (void) hipFree(ctx->d_zrange);
+    if (ctx->d_plan_gather) (void) hipFree(ctx->d_plan_gather);
     if (ctx->d_block_list) (void) hipFree(ctx->d_block_list);
     if (ctx->d_block_count) (void) hipFree(ctx->d_block_count);
     if (ctx->d_zrange_xform) (void) hipFree(ctx->d_zrange_xform);
@@ -1553,10 +1556,19 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
                        bin_out * ss, tri_begin, tri_end);
     O2V_STAGE("k_zhist");
     if (comm) {
-        int rc = timed(2, [&]() -> int { return comm->allreduce_sum_u64(ctx->d_zhist, kPlanBins, s); });
+        // one all-gather for both: every rank's partial histogram and the extents of its blocks (k_pack_plan), summed / put in
+        // place by every rank itself (an all-reduce and an all-gather, one after the other, cost a collective's latency more)
+        const uint64_t rec_words = (uint64_t) kPlanBins + blocks_per_rank;
+        int rc;
+        if ((rc = grow(ctx, ctx->d_plan_gather, ctx->cap_plan_gather, rec_words * (uint64_t) comm->world))) return rc;  // (sized by the caller already)
+        const uint32_t wgs = (uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 2u, (rec_words * (uint64_t) comm->world + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_pack_plan, dim3(std::max(1u, std::min<uint32_t>(wgs, (uint32_t) ((rec_words + kBlock - 1) / kBlock)))), dim3(kBlock), 0, s,
+                           ctx->d_zhist, ctx->d_zrange + (uint64_t) comm->rank * blocks_per_rank,
+                           ctx->d_plan_gather + (uint64_t) comm->rank * rec_words, (uint32_t) blocks_per_rank);
+        rc = timed(2, [&]() -> int { return comm->allgather(ctx->d_plan_gather, rec_words * sizeof(unsigned long long), s); });
         if (rc) return comm_failed(rc);
-        rc = timed(3, [&]() -> int { return comm->allgather(ctx->d_zrange, blocks_per_rank * sizeof(float2), s); });
-        if (rc) return comm_failed(rc);
+        hipLaunchKernelGGL(k_unpack_plan, dim3(std::max(1u, wgs)), dim3(kBlock), 0, s, ctx->d_plan_gather, (uint32_t) comm->world,
+                           (uint32_t) blocks_per_rank, ctx->d_zhist, ctx->d_zrange);
     }
     O2V_CHECK(hipMemcpyAsync(ctx->h_zhist, ctx->d_zhist, n_bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1697,6 +1709,7 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
             }
             int rc_grow;
             if ((rc_grow = grow(ctx, ctx->d_zrange, ctx->cap_zrange, std::max<uint64_t>(bpr * (uint64_t) world, 1)))) return rc_grow;
+            if ((rc_grow = grow(ctx, ctx->d_plan_gather, ctx->cap_plan_gather, ((uint64_t) kPlanBins + bpr) * world))) return rc_grow;
             if (!ctx->d_zrange_xform) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zrange_xform), 12 * sizeof(float)));
             if ((rc_grow = grow(ctx, ctx->d_block_list, ctx->cap_block_list, std::max<uint64_t>(n_blocks, 1)))) return rc_grow;
             if (!ctx->d_block_count) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_block_count), sizeof(uint32_t)));

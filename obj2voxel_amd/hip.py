@@ -32,7 +32,7 @@ class Timings(C.Structure):
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}
-        d["collective_parts_ms"] = [float(x) for x in self.collective_parts_ms]   # status + bounds (one reduce), bounds alone (o2v_hip_plan_slabs), histogram, block extents, counts
+        d["collective_parts_ms"] = [float(x) for x in self.collective_parts_ms]   # status + bounds (one reduce), -, histograms + block extents (one gather), -, counts
         return d
 
 

@@ -98,8 +98,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "zslab2" and line["value"] > 0
     col = line["config"]["collectives"]
     assert col["world"] == 2 and col["backend"] == "callbacks"
-    assert set(col["per_collective_ms_rank0"]) == {"ready_and_bounds_allreduce_28B", "histogram_allreduce_16KiB",
-                                                   "block_extents_allgather", "slab_counts_allgather"}
+    assert set(col["per_collective_ms_rank0"]) == {"ready_and_bounds_allreduce_28B", "histogram_and_block_extents_allgather", "slab_counts_allgather"}
     assert all(v > 0 for v in col["per_collective_ms_rank0"].values()), col
     assert sum(col["per_collective_ms_rank0"].values()) > 0
     up = line["config"]["upload"]

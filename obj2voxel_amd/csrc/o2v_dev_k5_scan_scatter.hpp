@@ -9,63 +9,86 @@
 // per lane), compacts the occupied cells into `occ` through an LDS staging buffer (one global atomic per flush,
 // not per cell) and writes zeros back, so the grid and the flag map are clean for the next voxelization.
 
-constexpr uint32_t kFlagLoads = 2;  // 16-byte loads of the flag map per thread and round
-// `brick_slab` (optional): every listed brick learns its place in the list (= the number of its hit slab, Params::brick_slab);
-// this use of the kernel - ahead of k_voxelize, on the flags k_mark_bricks set - is skipped like k_mark_bricks itself when
-// the pass pools no hits.
+// Every wavefront walks its own share of the map with kFlagLoads 16-byte loads per lane in flight and stages the dirty bricks it
+// finds in its own LDS list (positions from a prefix sum over the lanes: no LDS atomics, and no workgroup barrier inside the loop -
+// the rounds of the barrier version, four on the bench headline, each waited for the slowest wavefront's loads).  A wavefront's
+// list is written out when it may not take another load's worth; what is left at the end goes out per workgroup, with ONE atomic
+// on the list's counter (atomics on one address serialise, ~5 ns each: one per wavefront would cost more than the scan).
+#ifndef O2V_FLAG_LOADS
+#define O2V_FLAG_LOADS 4
+#endif
+#ifndef O2V_SCAN_WGS_PER_CU
+#define O2V_SCAN_WGS_PER_CU 2
+#endif
+constexpr uint32_t kFlagLoads = O2V_FLAG_LOADS;     // 16-byte loads of the flag map per lane and round
+constexpr uint32_t kScanFlagsWgsPerCu = O2V_SCAN_WGS_PER_CU;
+constexpr uint32_t kFlagWaveCap = 2048;            // entries of a wavefront's list (a load adds at most 64 x 16)
+constexpr uint32_t kFlagGroupsPerBlockRound = kBlock * kFlagLoads;
 __global__ __launch_bounds__(kBlock) void k_scan_flags(uint8_t *brick_dirty, uint32_t *n_dirty, uint32_t *dirty_list, Counters *c, uint32_t *brick_slab,
                                                        uint32_t force_general, Params p)
 {
     if (brick_slab && pools_no_hits(c, p, force_general)) return;
-    // The workgroup collects dirty bricks in LDS over several rounds and reserves their place in the list with one global
-    // atomic per few thousand of them (atomics on one address serialise at ~88 per us: one per round and workgroup was most
-    // of this kernel's time).  Launched with two workgroups per CU.
-    constexpr uint32_t kRoundMax = kBlock * 16 * kFlagLoads;  // bricks one round can add
-    constexpr uint32_t kFlushAbove = 4096;
-    __shared__ uint32_t s_list[kFlushAbove + kRoundMax];
-    __shared__ uint32_t s_n, s_base;
+    __shared__ uint32_t s_list[kBlock / 64][kFlagWaveCap];
+    __shared__ uint32_t s_count[kBlock / 64], s_base;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *list = s_list[wave];
+    uint32_t n = 0;  // (wavefront-uniform) entries staged
     const uint32_t n_groups = (p.n_bricks + 15u) / 16u;  // the flag map is padded to a multiple of 16 bytes
     uint4 *f4 = reinterpret_cast<uint4 *>(brick_dirty);
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    auto flush = [&](uint32_t n) {
-        if (threadIdx.x == 0) s_base = atomicAdd(n_dirty, n);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-            if (s_base + i < p.cap_dirty) {
-                dirty_list[s_base + i] = s_list[i];
-                if (brick_slab) brick_slab[s_list[i]] = s_base + i;
+    auto write_out = [&](uint32_t base, uint32_t count) {
+        for (uint32_t i = lane; i < count; i += 64u)
+            if (base + i < p.cap_dirty) {
+                dirty_list[base + i] = list[i];
+                if (brick_slab) brick_slab[list[i]] = base + i;
             }
-        if (threadIdx.x == 0 && s_base + n > p.cap_dirty) atomicOr(&c->err_flags, kErrDirtyList);
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
+        if (lane == 0 && base + count > p.cap_dirty) atomicOr(&c->err_flags, kErrDirtyList);
     };
-    for (uint32_t g0 = blockIdx.x * kBlock * kFlagLoads; g0 < n_groups; g0 += gridDim.x * kBlock * kFlagLoads) {
+    const uint32_t wave_id = blockIdx.x * (kBlock / 64u) + wave, n_waves = gridDim.x * (kBlock / 64u);
+    for (uint64_t g0 = (uint64_t) wave_id * 64u * kFlagLoads; g0 < n_groups; g0 += (uint64_t) n_waves * 64u * kFlagLoads) {
         uint4 f[kFlagLoads];
 #pragma unroll
         for (uint32_t u = 0; u < kFlagLoads; ++u) {
-            const uint32_t g = g0 + u * kBlock + threadIdx.x;
+            const uint64_t g = g0 + u * 64u + lane;
             f[u] = g < n_groups ? f4[g] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (uint32_t u = 0; u < kFlagLoads; ++u) {
-            if (f[u].x | f[u].y | f[u].z | f[u].w) {
-                const uint32_t g = g0 + u * kBlock + threadIdx.x;
-                const uint32_t w[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+            const uint32_t w[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+            const bool any = (w[0] | w[1] | w[2] | w[3]) != 0u;
+            if (__ballot(any) == 0ull) continue;  // (wavefront-uniform)
+            if (n + 64u * 16u > kFlagWaveCap) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(n_dirty, n);
+                write_out(__shfl(base, 0, 64), n);
+                n = 0;
+            }
+            uint32_t mine = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) mine += (uint32_t) __popc((((w[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[k]) & 0x80808080u);  // non-zero bytes
+            const uint32_t incl = wave_inclusive_scan(mine);
+            uint32_t pos = n + incl - mine;
+            if (any) {
+                const uint32_t g = (uint32_t) (g0 + u * 64u + lane);
 #pragma unroll
                 for (uint32_t k = 0; k < 16; ++k)
-                    if ((w[k >> 2] >> ((k & 3u) * 8u)) & 0xffu) s_list[atomicAdd(&s_n, 1u)] = g * 16u + k;
+                    if ((w[k >> 2] >> ((k & 3u) * 8u)) & 0xffu) list[pos++] = g * 16u + k;
                 f4[g] = make_uint4(0, 0, 0, 0);
             }
+            n += __shfl(incl, 63, 64);
         }
-        __syncthreads();
-        const uint32_t n = s_n;
-        __syncthreads();  // (every thread has read n before anyone adds to s_n again: the decision below must be uniform)
-        if (n > kFlushAbove) flush(n);  // (the next round may add kRoundMax more)
     }
-    const uint32_t n = s_n;
-    if (n) flush(n);
+    // what is left: one reservation per workgroup
+    if (lane == 0) s_count[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kBlock / 64u; ++w) total += s_count[w];
+        s_base = total ? atomicAdd(n_dirty, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wave; ++w) base += s_count[w];
+    if (n) write_out(base, n);
 }
 
 constexpr uint32_t kScanBricksPerWave = 4;                                   // independent 1 KiB loads (four bricks each) in flight per wave

@@ -448,7 +448,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         O2V_LAUNCH("k_mark_bricks", s, k_mark_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, s, ctx->d_leaves, ctx->d_ctr, ctx->d_brick_dirty,
                            ctx->force_general ? 1u : 0u, p);
         const uint32_t flag_groups = (p.n_bricks + 15u) / 16u;
-        O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
+        O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * kScanFlagsWgsPerCu, std::max<uint32_t>(1u, (flag_groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads)))),
                            dim3(kBlock), 0, s, ctx->d_brick_dirty, &ctx->d_ctr->n_dirty, ctx->d_dirty_list, ctx->d_ctr, ctx->d_brick_slab, ctx->force_general ? 1u : 0u, p);
     }
     if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[2], s));
@@ -501,7 +501,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         }
         if (run_emit) {
             const uint32_t groups = (p.n_bricks + 15u) / 16u;
-            O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * 2u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads))),
+            O2V_LAUNCH("k_scan_flags", s, k_scan_flags, dim3(std::min<uint32_t>((uint32_t) ctx->num_cus * kScanFlagsWgsPerCu, std::max<uint32_t>(1u, (groups + kBlock * kFlagLoads - 1) / (kBlock * kFlagLoads)))),
                                dim3(kBlock), 0, s, ctx->d_dirty_max, &ctx->d_ctr->n_dirty_max, ctx->d_dirty_list_max, ctx->d_ctr, (uint32_t *) nullptr, 0u, p);
         }
     }

@@ -125,8 +125,9 @@ struct Counters {
     unsigned long long n_certain;   // occupancy-only mode: hits established without a voxel job (certain_prepare)
     unsigned long long n_jobs;      // candidate voxels that passed phase 1 of k_voxelize (= voxel jobs of phase 2)
     unsigned long long n_jobs_skipped;  // occupancy-only mode: jobs dropped before phase 2 because their voxel was marked already
-    uint32_t n_listed_hits, pad3;       // k_scan_bricks: the counters of the listed bricks' cells added up (modulo 2^32): must equal
+    uint32_t n_listed_hits, n_listed_blocks;  // k_scan_bricks: the counters of the listed bricks' cells added up (modulo 2^32): must equal
                                         // the hits k_voxelize counted into the grid (n_hits - n_direct), see o2v_hip_voxelize
+                                        // n_listed_blocks: k_list_blocks' count of the blocks of 256 triangles that meet the slab (0xffffffff: no list)
     unsigned long long n_candidates_sq; // sum over the leaves of (candidates of the leaf)^2: with n_candidates and the number of leaves, how
                                         // unequal the leaves are (k_voxelize sizes the batches of its last quarter by it)
     unsigned long long n_bypass;        // Params::root_bypass: root triangles that k_voxelize_occ stages itself (no Leaf, no Tile)

@@ -417,13 +417,17 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     const uint64_t list_above = list_hook && list_hook[0] == '1' ? 0ull : 256ull;
     if (have_zrange && (p.zs0 != 0 || p.zs1 < p.S) && n_tri_blocks > list_above && ctx->d_block_list && ctx->cap_block_list >= n_tri_blocks) {
         block_list = ctx->d_block_list;
-        O2V_CHECK(hipMemsetAsync(ctx->d_block_count, 0, sizeof(uint32_t), s));
+        // (the list's counter is a word of the pass's counters: zero since k_init)
         O2V_LAUNCH("k_list_blocks", s, k_list_blocks, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (n_tri_blocks + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_zrange, ctx->d_zrange_xform, ctx->d_ctr, ctx->d_block_list, ctx->d_block_count, p);
     }
     // (root_bypass: most super-blocks of three sub-batches are only read and counted - fewer workgroups with several super-blocks
     // each keep the loads of the next one in flight behind the current one's arithmetic)
-    const uint64_t root_wgs = p.root_bypass ? std::max<uint64_t>((uint64_t) ctx->num_cus * 2u, (p.n_tris + kBlock - 1) / kBlock / 6u) : (p.n_tris + kBlock - 1) / kBlock;
+    // (a slab visits the listed blocks only - how many is known on the device; the slab's share of z, and a third more, is the
+    // estimate here: too many workgroups cost this kernel as much again, 0.033 -> 0.06 - 0.08 ms on a slab of the 8-GPU weak job)
+    uint64_t walked_blocks = n_tri_blocks;
+    if (block_list && p.S) walked_blocks = std::min<uint64_t>(n_tri_blocks, (uint64_t) ((double) n_tri_blocks * (double) (p.zs1 - p.zs0) / (double) p.S * 1.33) + 64u);
+    const uint64_t root_wgs = p.root_bypass ? std::max<uint64_t>((uint64_t) ctx->num_cus * 2u, walked_blocks / 6u) : (p.n_tris + kBlock - 1) / kBlock;
     O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, std::max<uint64_t>(root_wgs, 1))),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
                        ctx->d_big, ctx->d_nodes[0], have_zrange ? ctx->d_zrange : nullptr,
@@ -772,6 +776,7 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
+    ctx->d_block_count = &ctx->d_ctr->n_listed_blocks;
     // k_resolve_big sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_big), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int) (kBigList * 12u));
@@ -798,7 +803,6 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->d_zrange) (void) hipFree(ctx->d_zrange);
     if (ctx->d_plan_gather) (void) hipFree(ctx->d_plan_gather);
     if (ctx->d_block_list) (void) hipFree(ctx->d_block_list);
-    if (ctx->d_block_count) (void) hipFree(ctx->d_block_count);
     if (ctx->d_zrange_xform) (void) hipFree(ctx->d_zrange_xform);
     if (ctx->h_zhist) (void) hipHostFree(ctx->h_zhist);
     for (o2v_hip_staging &b : ctx->stage)
@@ -1554,7 +1558,6 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
             return rc;
         if (!ctx->d_zrange_xform) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zrange_xform), 12 * sizeof(float)));
         if ((rc = grow(ctx, ctx->d_block_list, ctx->cap_block_list, std::max<uint64_t>(n_blocks, 1)))) return rc;
-        if (!ctx->d_block_count) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_block_count), sizeof(uint32_t)));
     }
     ctx->zrange_generation = ~0ull;
     hipLaunchKernelGGL(k_zhist, dim3((uint32_t) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) ctx->num_cus * 6u, (n_range + kBlock - 1) / kBlock))),
@@ -1718,7 +1721,6 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
             if ((rc_grow = grow(ctx, ctx->d_plan_gather, ctx->cap_plan_gather, ((uint64_t) kPlanBins + bpr) * world))) return rc_grow;
             if (!ctx->d_zrange_xform) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_zrange_xform), 12 * sizeof(float)));
             if ((rc_grow = grow(ctx, ctx->d_block_list, ctx->cap_block_list, std::max<uint64_t>(n_blocks, 1)))) return rc_grow;
-            if (!ctx->d_block_count) O2V_CHECK(hipMalloc(reinterpret_cast<void **>(&ctx->d_block_count), sizeof(uint32_t)));
             return O2V_HIP_OK;
         };
         // (bad parameters are a failure of this rank like any other: reported through the status word, so that the other

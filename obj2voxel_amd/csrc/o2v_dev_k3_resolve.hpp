@@ -886,22 +886,40 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     };
+    // The list entries of a round are requested two rounds ahead and its bricks' cells one round ahead (both loads depend on the
+    // one before: three round trips per round otherwise, with the colour lookup).
+    auto list_entry = [&](uint32_t r, uint32_t k) -> uint32_t {
+        const uint32_t item = r * kEmitBricksPerRound + (wave * kEmitBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
+        return (r < n_rounds && item < n_dirty) ? dirty_list[item] : 0xffffffffu;
+    };
+    auto cells_of = [&](uint32_t b, ulonglong2 &lo_, ulonglong2 &hi_) {
+        lo_ = hi_ = make_ulonglong2(0, 0);
+        if (b != 0xffffffffu) {
+            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p.maxgrid + (uint64_t) b * kBrickCells) + (lane % kLanesPerBrick) * 2u;
+            lo_ = q[0];
+            hi_ = q[1];
+        }
+    };
+    uint32_t next_brick[kEmitBricksPerWave], after_brick[kEmitBricksPerWave];
+    ulonglong2 next_lo[kEmitBricksPerWave], next_hi[kEmitBricksPerWave];
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
+        next_brick[k] = list_entry(blockIdx.x, k);
+        after_brick[k] = list_entry(blockIdx.x + gridDim.x, k);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) cells_of(next_brick[k], next_lo[k], next_hi[k]);
     for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
         uint32_t brick[kEmitBricksPerWave];
         ulonglong2 lo[kEmitBricksPerWave], hi[kEmitBricksPerWave];
 #pragma unroll
         for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
-            const uint32_t item = r * kEmitBricksPerRound + (wave * kEmitBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
-            brick[k] = item < n_dirty ? dirty_list[item] : 0xffffffffu;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
-            lo[k] = hi[k] = make_ulonglong2(0, 0);
-            if (brick[k] != 0xffffffffu) {
-                const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p.maxgrid + (uint64_t) brick[k] * kBrickCells) + (lane % kLanesPerBrick) * 2u;
-                lo[k] = q[0];
-                hi[k] = q[1];
-            }
+            brick[k] = next_brick[k];
+            lo[k] = next_lo[k];
+            hi[k] = next_hi[k];
+            next_brick[k] = after_brick[k];
+            cells_of(after_brick[k], next_lo[k], next_hi[k]);
+            after_brick[k] = list_entry(r + 2u * gridDim.x, k);
         }
 #pragma unroll
         for (uint32_t k = 0; k < kEmitBricksPerWave; ++k) {
@@ -986,19 +1004,26 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
         const uint32_t item = r * kOccBricksPerRound + (wave * kOccBricksPerWave + k) * kBricksPerLoad + lane / kLanesPerBrick;
         return (r < n_rounds && item < n_dirty) ? dirty_list[item] : 0xffffffffu;
     };
-    uint32_t next_brick[kOccBricksPerWave];
+    // (... and the bricks' cells one round ahead: a round then waits for neither)
+    auto cells_of = [&](uint32_t b) -> uint32_t { return b != 0xffffffffu ? grid4[(uint64_t) b * kLanesPerBrick + lane % kLanesPerBrick] : 0u; };
+    uint32_t next_brick[kOccBricksPerWave], next_cells[kOccBricksPerWave], after_brick[kOccBricksPerWave];
 #pragma unroll
-    for (uint32_t k = 0; k < kOccBricksPerWave; ++k) next_brick[k] = list_entry(blockIdx.x, k);
+    for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
+        next_brick[k] = list_entry(blockIdx.x, k);
+        after_brick[k] = list_entry(blockIdx.x + gridDim.x, k);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kOccBricksPerWave; ++k) next_cells[k] = cells_of(next_brick[k]);
     for (uint32_t r = blockIdx.x; r < n_rounds; r += gridDim.x) {
         uint32_t brick[kOccBricksPerWave], cells4[kOccBricksPerWave];
 #pragma unroll
         for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
             brick[k] = next_brick[k];
-            next_brick[k] = list_entry(r + gridDim.x, k);
+            cells4[k] = next_cells[k];
+            next_brick[k] = after_brick[k];
+            next_cells[k] = cells_of(after_brick[k]);
+            after_brick[k] = list_entry(r + 2u * gridDim.x, k);
         }
-#pragma unroll
-        for (uint32_t k = 0; k < kOccBricksPerWave; ++k)
-            cells4[k] = brick[k] != 0xffffffffu ? grid4[(uint64_t) brick[k] * kLanesPerBrick + lane % kLanesPerBrick] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < kOccBricksPerWave; ++k) {
             // (wavefront-uniform loop over the four cells of a lane: the staging slots are reserved with one LDS atomic per

@@ -432,7 +432,7 @@ def route_entry(r, prof):
     """The bench line's entry for one workload run by obj2voxel_amd.workloads.run()."""
     from obj2voxel_amd import workloads
     kern, stale = profile_for(prof, r["workload"], r["stats"])
-    alg = workloads.kernel_algorithmic_bytes(r["stats"], r["textured"], r["strategy"] == "BLEND")
+    alg = workloads.kernel_algorithmic_bytes(r["stats"], r["textured"], r["strategy"] == "BLEND", r.get("kernels_ms"))
     rows = [kernel_view(k, v["ms"], v["launches"], alg.get(k), kern, stale) for k, v in (r.get("kernels_ms") or {}).items()]
     rows.sort(key=lambda x: -x["ms"])
     return {"workload": r["workload"], "what": r["what"], "triangles": r["tris"], "resolution": r["res"], "supersampling": r["supersampling"],
@@ -478,7 +478,7 @@ def report(args, n, run, dv, comm):
     }
     stage_kernels = {
         "bounds": ["k_init", "k_bounds", "k_setup"],
-        "expand": ["k_expand_roots", "k_expand_nodes", "k_expand_big", "k_mark_bricks"],
+        "expand": ["k_count_roots", "k_expand_roots", "k_expand_nodes", "k_expand_big", "k_mark_bricks"],
         "voxelize": ["k_voxelize_occ", "k_voxelize<false>", "k_voxelize<true>"],
         "scan": ["k_scan_flags", "k_scan_bricks", "k_scatter", "k_reset_bricks"],
         "resolve": ["k_resolve<4>", "k_resolve<6>", "k_resolve_inline_list<4>", "k_resolve_inline_list<6>", "k_resolve_list16<4>", "k_resolve_list16<6>", "k_resolve_wave<32>", "k_resolve_wave<64>",

@@ -130,6 +130,7 @@ struct Counters {
                                         // n_listed_blocks: k_list_blocks' count of the blocks of 256 triangles that meet the slab (0xffffffff: no list)
     unsigned long long n_candidates_sq; // sum over the leaves of (candidates of the leaf)^2: with n_candidates and the number of leaves, how
                                         // unequal the leaves are (k_voxelize sizes the batches of its last quarter by it)
+    uint32_t n_need_blocks, pad4;       // k_count_roots: blocks of 256 triangles with a triangle that k_expand_roots has to handle
     unsigned long long n_bypass;        // Params::root_bypass: root triangles that k_voxelize_occ stages itself (no Leaf, no Tile)
     unsigned long long dbg[16];  // event counts of an instrumented build (-DO2V_INSTRUMENT, tools/instrument.sh); else zero
     uint32_t ext_hist[256];      // k_tri_extent (at upload time only): triangles by the binary exponent of their extent

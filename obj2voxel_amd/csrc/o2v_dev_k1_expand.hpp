@@ -421,6 +421,84 @@ __device__ __forceinline__ bool root_leaf_of_one_tile(const Sub &s, const Params
     return !(pl.count >> 32) && pl.ntiles == 1u;
 }
 
+// Params::root_bypass on a tessellated surface (practically every triangle is one leaf of one tile: o2v_hip_voxelize decides from the
+// histogram of the triangles' extents): k_expand_roots would only read and count, through its LDS staging and barriers.  This kernel
+// does that part alone - a wavefront per block of 256 triangles, its 36 loads per lane in flight together, no barrier - and lists the
+// blocks that hold a triangle k_expand_roots has to handle (a node, a leaf of several tiles, a leaf too large): k_expand_roots then
+// walks that list (as a rule empty) and counts the bypassed triangles of those blocks itself.  `seq_list` / `seq_count`: the blocks
+// that meet the slab (k_list_blocks), or null / ~0 for all.
+constexpr uint32_t kCountRootsWgsPerCu = 4;
+__global__ __launch_bounds__(kBlock) void k_count_roots(const float *__restrict__ verts, Counters *c, const uint32_t *__restrict__ seq_list,
+                                                        const uint32_t *seq_count, uint32_t *need_list, uint32_t *need_count, Params p)
+{
+    __shared__ unsigned long long s_sum[3];
+    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
+    __syncthreads();
+    Affine xf;
+    xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
+    xf.m[1] = {c->xform[3], c->xform[4], c->xform[5]};
+    xf.m[2] = {c->xform[6], c->xform[7], c->xform[8]};
+    xf.t = {c->xform[9], c->xform[10], c->xform[11]};
+    const bool listed = seq_list != nullptr && *seq_count != 0xffffffffu;
+    const uint64_t n_seq = listed ? (uint64_t) *seq_count : (p.n_tris + kBlock - 1) / kBlock;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave_id = (uint64_t) blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6), n_waves = (uint64_t) gridDim.x * (kBlock / 64u);
+    unsigned long long my_n = 0, my_cand = 0, my_sq = 0;
+    for (uint64_t i = wave_id; i < n_seq; i += n_waves) {
+        const uint64_t blk = listed ? (uint64_t) seq_list[i] : i;
+        float q[kBlock / 64u][9];
+#pragma unroll
+        for (uint32_t j = 0; j < kBlock / 64u; ++j) {
+            const uint64_t tri = blk * kBlock + j * 64u + lane;
+#pragma unroll
+            for (uint32_t k = 0; k < 9; ++k) q[j][k] = tri < p.n_tris ? verts[tri * 9u + k] : 0.f;
+        }
+        bool need = false;
+        unsigned long long bn = 0, bc = 0, bs = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kBlock / 64u; ++j) {
+            const uint64_t tri = blk * kBlock + j * 64u + lane;
+            if (tri >= p.n_tris) continue;
+            Sub s{};
+            s.v0 = affine_apply(xf, V3{q[j][0], q[j][1], q[j][2]});
+            s.v1 = affine_apply(xf, V3{q[j][3], q[j][4], q[j][5]});
+            s.v2 = affine_apply(xf, V3{q[j][6], q[j][7], q[j][8]});
+            // (k_expand_roots' classify(), same order)
+            if (misses_slab(s, p)) continue;
+            if (roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit) {
+                const LeafPlan pl = plan_leaf(s, p);
+                if (pl.count >> 32) need = true;
+                else if (pl.ntiles == 1u) {
+                    bn += 1;
+                    bc += pl.count;
+                    bs += leaf_size_squared(pl.count);
+                }
+                else if (pl.ntiles) need = true;
+            }
+            else need = true;
+        }
+        if (__ballot(need) != 0ull) {
+            if (lane == 0) need_list[atomicAdd(need_count, 1u)] = (uint32_t) blk;
+        }
+        else {
+            my_n += bn;
+            my_cand += bc;
+            my_sq += bs;
+        }
+    }
+    if (my_n) {
+        atomicAdd(&s_sum[0], my_n);
+        atomicAdd(&s_sum[1], my_cand);
+        atomicAdd(&s_sum[2], my_sq);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum[0]) {
+        atomicAdd(&c->n_bypass, s_sum[0]);
+        atomicAdd(&c->n_candidates, s_sum[1]);
+        atomicAdd(&c->n_candidates_sq, s_sum[2]);
+    }
+}
+
 
 // One breadth-first round of forEachSubdividedTriangle (voxelization.cpp:349-379).  The reference pops a LIFO
 // stack: after subdivide4 the centre piece (index 0) replaces the parent and pieces 1,2,3 are pushed, so the

@@ -112,6 +112,9 @@ struct o2v_hip_ctx {
     float *d_zrange_xform = nullptr;  // the transform they were computed with (12 floats)
     uint32_t cap_zrange = 0;
     uint32_t *d_block_list = nullptr, *d_block_count = nullptr;  // the blocks of 256 triangles that meet the slab (k_list_blocks)
+    uint32_t *d_need_list = nullptr;  // k_count_roots: the blocks k_expand_roots still has to walk
+    uint32_t cap_need_list = 0;
+    bool lean_roots = false;          // this call: k_count_roots ahead of k_expand_roots (o2v_hip_voxelize)
     uint32_t cap_block_list = 0;
     float mesh_bounds_hint[6] = {0, 0, 0, 0, 0, 0};  // bounds and largest triangle extent of the uploaded mesh: only used to
     float max_tri_extent = -1.f;                     // bound the number of subdivision rounds (-1: unknown)
@@ -427,11 +430,21 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     // estimate here: too many workgroups cost this kernel as much again, 0.033 -> 0.06 - 0.08 ms on a slab of the 8-GPU weak job)
     uint64_t walked_blocks = n_tri_blocks;
     if (block_list && p.S) walked_blocks = std::min<uint64_t>(n_tri_blocks, (uint64_t) ((double) n_tri_blocks * (double) (p.zs1 - p.zs0) / (double) p.S * 1.33) + 64u);
-    const uint64_t root_wgs = p.root_bypass ? std::max<uint64_t>((uint64_t) ctx->num_cus * 2u, walked_blocks / 6u) : (p.n_tris + kBlock - 1) / kBlock;
+    uint64_t root_wgs = p.root_bypass ? std::max<uint64_t>((uint64_t) ctx->num_cus * 2u, walked_blocks / 6u) : (p.n_tris + kBlock - 1) / kBlock;
+    const uint32_t *k1_list = block_list, *k1_count = ctx->d_block_count;
+    if (ctx->lean_roots && p.root_bypass) {
+        // a tessellated surface: the one-tile root triangles are counted by a kernel of their own, k_expand_roots only walks the
+        // blocks that hold something else (k_count_roots)
+        O2V_LAUNCH("k_count_roots", s, k_count_roots, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * kCountRootsWgsPerCu, std::max<uint64_t>((walked_blocks + 3u) / 4u, 1))),
+                           dim3(kBlock), 0, s, ctx->d_verts, ctx->d_ctr, block_list, ctx->d_block_count, ctx->d_need_list, &ctx->d_ctr->n_need_blocks, p);
+        k1_list = ctx->d_need_list;
+        k1_count = &ctx->d_ctr->n_need_blocks;
+        root_wgs = (uint64_t) ctx->num_cus;  // (the list is short or empty)
+    }
     O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, std::max<uint64_t>(root_wgs, 1))),
                        dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
                        ctx->d_big, ctx->d_nodes[0], have_zrange ? ctx->d_zrange : nullptr,
-                       ctx->d_zrange_xform, block_list, ctx->d_block_count, p);
+                       ctx->d_zrange_xform, k1_list, k1_count, p);
     for (uint32_t round = 0; round < n_rounds; ++round) {
         // most rounds are empty or small: a narrow grid keeps an empty launch short (the kernel strides over its input)
         O2V_LAUNCH("k_expand_nodes", s, k_expand_nodes, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
@@ -801,6 +814,7 @@ void o2v_hip_destroy(o2v_hip_ctx *ctx)
     if (ctx->h_ctr) (void) hipHostFree(ctx->h_ctr);
     if (ctx->d_zhist) (void) hipFree(ctx->d_zhist);
     if (ctx->d_zrange) (void) hipFree(ctx->d_zrange);
+    if (ctx->d_need_list) (void) hipFree(ctx->d_need_list);
     if (ctx->d_plan_gather) (void) hipFree(ctx->d_plan_gather);
     if (ctx->d_block_list) (void) hipFree(ctx->d_block_list);
     if (ctx->d_zrange_xform) (void) hipFree(ctx->d_zrange_xform);
@@ -1120,6 +1134,28 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         const char *no_bypass = std::getenv("O2V_NO_ROOT_BYPASS");  // (A/B: every leaf through its Leaf / Tile records)
         p.root_bypass = (modes.occupancy_only && !(no_bypass && no_bypass[0] == '1')) ? 1u : 0u;
     }
+    // ... and on a tessellated surface - fewer than one triangle in 512 is 4 voxels or more across (the histogram of the triangles'
+    // extents, made at upload): practically every block of 256 holds nothing but one-tile leaves - a z-slab run lets k_count_roots
+    // run ahead of k_expand_roots (run_pass).  Measured: the expand stage of a slab of the 8-GPU weak job 0.054 -> 0.034 ms; on the
+    // whole grid (the bench headline) the two kernels take what k_expand_roots alone takes (0.028 against 0.026 ms), so not there.
+    // Either way the same leaves are made; O2V_NO_COUNT_ROOTS=1: never, O2V_COUNT_ROOTS=1: also on the whole grid (A/B).
+    ctx->lean_roots = false;
+    const char *lean_always = std::getenv("O2V_COUNT_ROOTS");
+    if (p.root_bypass && ctx->max_tri_extent >= 0.f && ctx->n_tris && (z0 != 0 || z1 < params->resolution || (lean_always && lean_always[0] == '1'))) {
+        const float *b = params->bounds_known ? params->bounds : ctx->mesh_bounds_hint;
+        const float max_axis = std::max(b[3] - b[0], std::max(b[4] - b[1], b[5] - b[2]));
+        float unit_norm = 0.f;
+        for (int i = 0; i < 3; ++i)
+            unit_norm = std::max(unit_norm, std::fabs((float) p.unit[i * 3]) + std::fabs((float) p.unit[i * 3 + 1]) + std::fabs((float) p.unit[i * 3 + 2]));
+        const float voxels_per_unit = unit_norm * (float) p.S / max_axis;
+        const char *off = std::getenv("O2V_NO_COUNT_ROOTS");
+        if (max_axis > 0.f && std::isfinite(voxels_per_unit) && voxels_per_unit > 0.f && !(off && off[0] == '1')) {
+            uint64_t large = ctx->ext_hist[255];
+            for (uint32_t e = 1; e < 255; ++e)   // bin e: extents in [2^(e-127), 2^(e-126))
+                if (std::ldexp(1.0f, (int) e - 127) * voxels_per_unit >= 4.0f) large += ctx->ext_hist[e];
+            ctx->lean_roots = large * 512u <= ctx->n_tris;
+        }
+    }
     p.direct_max = modes.direct_max ? 1u : 0u;
     p.pick_max = (p.direct_max && use_uv) ? 1u : 0u;  // textured: the winner's colour is picked afterwards (k_pick)
     p.mat = Materials{ctx->d_types, ctx->d_colors, ctx->d_texids, ctx->d_textures, ctx->n_textures};
@@ -1308,6 +1344,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         if ((rc = grow_required(ctx->d_leaves, ctx->cap_leaves, want_leaves))) return rc;
         if ((rc = grow_required(ctx->d_tiles, ctx->cap_tiles, want_tiles))) return rc;
         if ((rc = grow_required(ctx->d_big, ctx->cap_big, want_big))) return rc;
+        if (ctx->lean_roots && (rc = grow_required(ctx->d_need_list, ctx->cap_need_list, (ctx->n_tris + kBlock - 1) / kBlock))) return rc;
         uint32_t cap_n0 = ctx->cap_nodes, cap_n1 = ctx->cap_nodes;
         if ((rc = grow_required(ctx->d_nodes[0], cap_n0, want_nodes))) return rc;
         if ((rc = grow_required(ctx->d_nodes[1], cap_n1, want_nodes))) return rc;

@@ -162,7 +162,7 @@ def run(name, steps=5, warmup=2, dv=None, kernel_steps=0, loaded=None):
             dv.close()
 
 
-def kernel_algorithmic_bytes(stats, textured, strategy_blend):
+def kernel_algorithmic_bytes(stats, textured, strategy_blend, kernels=None):
     """Algorithmic bytes per launch of the pipeline's main kernels from the device statistics of a
     run: what each kernel has to read and write once, without re-reads, write amplification or cache-line granularity."""
     L, tiles, H, V, T = stats["leaves"], stats["tiles"], stats["hits"], stats["voxels"], stats["triangles"]
@@ -196,6 +196,11 @@ def kernel_algorithmic_bytes(stats, textured, strategy_blend):
         out["k_expand_roots"] = 36 * T + 96 * (L - Lb) + 8 * (tiles - Lb)
         out["k_voxelize_occ"] = 36 * T + 96 * (L - Lb) + 8 * (tiles - Lb) + 16 * jobs + 16 * (jobs - stats.get("skipped_jobs", 0)) + 2 * H
         out["k_emit_occ"] = 2 * cpb * D + 16 * V
+        if kernels is not None and "k_count_roots" in kernels:
+            # (a tessellated surface: k_count_roots reads the vertex array; k_expand_roots only the blocks it lists - unknown here,
+            # as a rule none - and writes the records of what is not bypassed)
+            out["k_count_roots"] = 36 * T
+            out["k_expand_roots"] = 96 * (L - Lb) + 8 * (tiles - Lb)
     elif direct:
         out["k_emit_max"] = 8 * cpb * D + 32 * V + 16 * V
     return {k: int(v) for k, v in out.items()}

@@ -182,6 +182,48 @@ def test_no_max_grid_for_a_mesh_of_large_triangles(dv, oracle):
         assert (per_cell > 12.0) == direct and per_cell > 4.0, (per_cell, st)   # 4 + 8 bytes per cell (+ flags), or 4
 
 
+@pytest.mark.parametrize("with_large", [False, True])
+def test_count_roots_ahead_of_expand_roots(oracle, monkeypatch, with_large):
+    """A tessellated material-less surface in z-slabs: k_count_roots counts the one-tile root triangles and lists the blocks that
+    hold anything else for k_expand_roots (o2v_hip_voxelize; O2V_COUNT_ROOTS=1 takes that route on the whole grid as well).  The
+    voxels are those of the route without it and the oracle's; `with_large`: a few triangles that need subdivision (listed blocks)."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(260)                      # 270 k triangles, ~2.4 voxels across at 400^3
+    if with_large:
+        big = meshes.uv_sphere(6) * 0.5            # 140 triangles, ~50 voxels across: fewer than one in 512
+        v = np.concatenate([v[:100_000], big[:70], v[100_000:], big[70:]]).astype(np.float32)
+    res = 400
+    want = meshes.sorted_voxels(oracle.voxelize(v, res))
+    outs = {}
+    for mode in ("default", "always", "never"):
+        monkeypatch.delenv("O2V_COUNT_ROOTS", raising=False)
+        monkeypatch.delenv("O2V_NO_COUNT_ROOTS", raising=False)
+        if mode == "always":
+            monkeypatch.setenv("O2V_COUNT_ROOTS", "1")
+        if mode == "never":
+            monkeypatch.setenv("O2V_NO_COUNT_ROOTS", "1")
+        d = hip.DeviceVoxelizer(0)
+        try:
+            d.set_triangles(v)
+            whole = meshes.sorted_voxels(d.voxelize(res, kernel_times=True))
+            ran_whole = "k_count_roots" in d.kernel_times()
+            st = d.stats()
+            cuts, bnd = d.plan_slabs(res, 3)
+            parts = []
+            ran_slab = True
+            for r in range(3):
+                parts.append(d.voxelize(res, zslab=(cuts[r], cuts[r + 1]), bounds=bnd, kernel_times=True))
+                ran_slab = ran_slab and "k_count_roots" in d.kernel_times()
+        finally:
+            d.close()
+        assert np.array_equal(whole, want), mode
+        assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), want), mode
+        assert ran_whole == (mode == "always") and ran_slab == (mode != "never"), (mode, ran_whole, ran_slab)
+        assert st["bypassed_leaves"] > 0.99 * 270_000 and st["leaves"] >= st["bypassed_leaves"] + (100 if with_large else 0), st
+        outs[mode] = st
+    assert outs["always"]["leaves"] == outs["never"]["leaves"] and outs["always"]["candidates"] == outs["never"]["candidates"]
+
+
 def test_non_multiple_of_four_resolution(dv, oracle):
     got, want = _run_both(dv, oracle, meshes.uv_sphere(8), 77)
     _compare(got, want)

@@ -89,3 +89,29 @@ def test_wavefront_prefix_sums_use_dpp(device_asm):
     body = [l.strip() for l in device_asm[start:end]]
     assert sum("row_bcast:15" in l for l in body) >= 1 and sum("row_bcast:31" in l for l in body) >= 1
     assert sum("row_shr:8" in l for l in body) >= 1
+
+
+def _kernel_body(device_asm, name):
+    start = next(i for i, l in enumerate(device_asm) if re.match(r"^_ZN\S*" + name + r"\S*:", l))
+    end = next(i for i in range(start, len(device_asm)) if device_asm[i].startswith(".Lfunc_end"))
+    return [l.strip() for l in device_asm[start:end]]
+
+
+def test_flag_scan_has_no_barrier_in_its_loop(device_asm):
+    """k_scan_flags (o2v_dev_k5_scan_scatter.hpp): every wavefront scans its own share of the dirty map - list positions from a DPP
+    prefix sum, staging in its own LDS list - so the only workgroup barriers are the two around the final reservation, and there is
+    no LDS atomic (the barrier version's list positions).  Four 16-byte loads per lane are issued together."""
+    body = _kernel_body(device_asm, "k_scan_flags")
+    assert sum(l.startswith("s_barrier") for l in body) <= 2, [l for l in body if l.startswith("s_barrier")]
+    assert not any(l.startswith("ds_add") for l in body)
+    assert sum("row_bcast:31" in l for l in body) >= 1
+    assert sum(l.startswith("global_load_dwordx4") for l in body) >= 4
+
+
+def test_count_roots_runs_without_lds_staging(device_asm):
+    """k_count_roots (o2v_dev_k1_expand.hpp): a wavefront per block of 256 triangles, the 36 loads of a lane's four triangles in
+    flight together, no LDS staging and no barrier in the loop (the one barrier pair belongs to the final sums)."""
+    body = _kernel_body(device_asm, "k_count_roots")
+    assert sum(l.startswith("s_barrier") for l in body) <= 2
+    assert not any(l.startswith("ds_write_b32") or l.startswith("ds_read_b32") for l in body)
+    assert sum(l.startswith("global_load_dword ") or l.startswith("global_load_dword\t") for l in body) >= 36

@@ -249,14 +249,20 @@ class DeviceVoxelizer:
                          read=True, stage_times=False):
         """o2v_hip_voxelize_sharded: collective over `comm` (a Comm); this rank voxelizes its planned z-slab.
         Returns (voxels or count of this rank, counts of all ranks, z cuts)."""
-        p = self._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0), FLAG_STAGE_TIMES if stage_times else 0)
-        n = C.c_uint64(0)
-        counts = np.zeros(comm.world, dtype=np.uint64)
-        cuts = np.zeros(comm.world + 1, dtype=np.uint32)
-        self._check(self._L.o2v_hip_voxelize_sharded(self._ctx, comm.handle, C.byref(p), C.byref(n), _ptr(counts), _ptr(cuts)),
+        flags = FLAG_STAGE_TIMES if stage_times else 0
+        # (a loop of identical calls - bench.py's timed steps - reuses the parameter block and the two small result arrays)
+        key = (resolution, supersampling, strategy, flags, comm.world) if unit_transform is None and bounds is None else None
+        if key is None or getattr(self, "_sharded_key", None) != key:
+            self._sharded_key = key
+            self._sharded_params = self._params(resolution, supersampling, strategy, unit_transform, bounds, (0, 0), flags)
+            self._sharded_counts = np.zeros(comm.world, dtype=np.uint64)
+            self._sharded_cuts = np.zeros(comm.world + 1, dtype=np.uint32)
+            self._sharded_ptrs = (_ptr(self._sharded_counts), _ptr(self._sharded_cuts))
+        p, n, counts, cuts = self._sharded_params, self._n_out, self._sharded_counts, self._sharded_cuts
+        self._check(self._L.o2v_hip_voxelize_sharded(self._ctx, comm.handle, C.byref(p), C.byref(n), *self._sharded_ptrs),
                     "o2v_hip_voxelize_sharded")
         self.count = n.value
-        return (self.read_voxels() if read else self.count), [int(c) for c in counts], [int(z) for z in cuts]
+        return (self.read_voxels() if read else self.count), counts.tolist(), cuts.tolist()
 
     def read_voxels(self):
         out = np.empty((self.count, 4), dtype=np.uint32)

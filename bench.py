@@ -311,13 +311,100 @@ def main():
                 "voxels": companion["voxels"], "stages_ms_rank0": {k: round(v, 4) for k, v in companion["stages_ms"].items()},
                 "strong_scaling_same_job": strong_entry(companion["strong"], companion, n),
                 "answers": "BASELINE.json north_star '>= 6x at 8 GPUs': strong_scaling_same_job.speedup of this job (DESIGN.md section 5)"}
-        print(json.dumps(out), flush=True)
+        emit(out)
     dv.close()
     if comm is not None:
         comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_BUDGET = 4096                         # bytes of the one stdout line (the driver keeps a bounded tail of stdout and parses its last line)
+DETAILS_FILE = os.path.join(ROOT, "bench_details.json")
+
+# The stdout line: the contract's keys and nothing else.  Everything else report() gathers (routes, stages, pipeline, kernels_ms,
+# capi_wall, published_workload, cli_wall, formulas, mix_model, stats ...) goes to the sidecar bench_details.json and to stderr.
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+             "data", "mtris_per_s", "config", "roofline", "cpu_baseline", "strong_scaling_same_job", "config4", "build_id", "details")
+CONFIG_KEYS = ("workload", "resolution", "triangles", "voxels", "parallelism", "collectives")
+COLLECTIVE_KEYS = ("backend", "world", "rccl_world_size", "collective_ms_rank0")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "traffic", "valu_busy", "active_lane_fraction",
+                 "estimated", "stale", "source")
+CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "value_1_thread", "sample")
+STRONG_KEYS = ("one_gpu_ms", "n_gpu_ms", "speedup", "efficiency", "voxels_match")
+CONFIG4_KEYS = ("workload", "value", "mtris_per_s", "ms_per_step", "voxels", "strong_scaling_same_job")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d} if isinstance(d, dict) else d
+
+
+def compact(out):
+    """The object of the stdout line: the bench contract's keys (+ the two multi-GPU curves), nested objects cut to their
+    contract fields.  Never more: five rounds of diagnostics appended to this line made it 24.7 KB and the driver's record of
+    round 5 came out unparsed."""
+    line = _pick(out, LINE_KEYS)
+    cfg = _pick(out.get("config") or {}, CONFIG_KEYS)
+    if isinstance(cfg.get("collectives"), dict):
+        cfg["collectives"] = _pick(cfg["collectives"], COLLECTIVE_KEYS)
+    line["config"] = cfg
+    line["roofline"] = _pick(out.get("roofline"), ROOFLINE_KEYS)
+    if isinstance(line["roofline"], dict) and isinstance(line["roofline"].get("traffic"), float):
+        line["roofline"]["traffic"] = int(line["roofline"]["traffic"])
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _pick(out["cpu_baseline"], CPU_KEYS)
+    if out.get("strong_scaling_same_job"):
+        line["strong_scaling_same_job"] = _pick(out["strong_scaling_same_job"], STRONG_KEYS)
+    if out.get("config4"):
+        c4 = _pick(out["config4"], CONFIG4_KEYS)
+        if c4.get("strong_scaling_same_job"):
+            c4["strong_scaling_same_job"] = _pick(c4["strong_scaling_same_job"], STRONG_KEYS)
+        line["config4"] = c4
+    line["details"] = "bench_details.json (next to bench.py) and stderr"
+    return line
+
+
+def compact_line(out):
+    """compact(out) as one JSON line of less than LINE_BUDGET bytes: free text is shortened first, then optional keys go."""
+    line = compact(out)
+
+    def dump():
+        return json.dumps(line, separators=(",", ":"))
+    s = dump()
+    for keep in (240, 120, 60):    # free text first: every string of the line cut to `keep` characters
+        if len(s) < LINE_BUDGET:
+            break
+
+        def shorten(o):
+            for k, v in list(o.items()):
+                if isinstance(v, dict):
+                    shorten(v)
+                elif isinstance(v, str) and len(v) > keep:
+                    o[k] = v[:keep - 3] + "..."
+        shorten(line)
+        s = dump()
+    for key in ("build_id", "mtris_per_s", "config4", "strong_scaling_same_job"):   # then the keys beyond the contract
+        if len(s) < LINE_BUDGET:
+            break
+        line.pop(key, None)
+        s = dump()
+    if len(s) >= LINE_BUDGET:
+        raise RuntimeError(f"bench line of {len(s)} bytes exceeds its budget of {LINE_BUDGET}")
+    return s
+
+
+def emit(out):
+    """Rank 0: everything to the sidecar and to stderr, the compact line - the LAST thing written to stdout - for the driver."""
+    try:
+        with open(os.environ.get("O2V_BENCH_DETAILS", DETAILS_FILE), "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+    except OSError as e:
+        print(f"bench: details file not written ({e})", file=sys.stderr)
+    print("bench details: " + json.dumps(out), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
 
 
 def same_job_on_one_gpu(dv, dist, rank, run, n, barrier):
@@ -560,7 +647,9 @@ def report(args, n, run, dv, comm):
                                  "active_lane_fraction": "SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 64",
                                  "valu_busy": "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (profiled_kernel_us x 2.4 GHz)",
                                  "counters": "profiles/current.json -> kernels[kernel].sq (rocprofv3 --pmc passes of this command); kernel_ms: two hipEvents on the kernel's own dispatch (hipExtLaunchKernelGGL), last timed step"},
-                    "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU: " + (prof or {}).get("source", "profiles/current.json")}
+                    # the instruction count is the committed one (deterministic for a build; `stale` if the build id differs), the time is live
+                    "source": "counters: committed rocprofv3 --pmc summary profiles/current.json (same build id unless `stale`); kernel_ms: live hipEvents",
+                    "counters_from": (prof or {}).get("source", "profiles/current.json")}
         mc = mix_ceiling(dom_kernel)
         if mc:
             # A model, not a measurement: the compiled kernel's STATIC instruction histogram priced with a microbenchmark's issue

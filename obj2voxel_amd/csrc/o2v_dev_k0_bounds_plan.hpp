@@ -5,11 +5,13 @@
 
 // ---- K0: bounds + transform ---------------------------------------------------------------------------------
 
-__global__ void k_init(Counters *c)
+// (n_words: the pass's counters end where ext_hist begins - that kilobyte is only written and read at upload time)
+constexpr uint32_t kPassCounterWords = offsetof(Counters, ext_hist) / 4;
+__global__ void k_init(Counters *c, uint32_t n_words)
 {
     uint32_t i = threadIdx.x;
     uint32_t *w = reinterpret_cast<uint32_t *>(c);
-    for (uint32_t k = i; k < sizeof(Counters) / 4; k += blockDim.x) w[k] = 0;
+    for (uint32_t k = i; k < n_words; k += blockDim.x) w[k] = 0;
     __syncthreads();
     if (i < 3) c->bounds_enc[i] = f2ord(__builtin_inff());
     else if (i < 6) c->bounds_enc[i] = f2ord(-__builtin_inff());

@@ -697,8 +697,10 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
             // block into the next)
             const uint64_t pos0 = root_plan.at(batch - n_list_batches, nt);
             const uint64_t pos = pos0 + threadIdx.x;
-            const uint64_t tri = blocks_listed ? (uint64_t) block_list[pos >> 8] * kTilesPerBatch + (pos & 255u) : pos;
-            const bool have = threadIdx.x < nt && tri < p.n_tris;
+            // (a thread past the batch's items reads nothing: the last batch's positions may lie past the list's end)
+            const bool in_batch = threadIdx.x < nt;
+            const uint64_t tri = !in_batch ? ~0ull : blocks_listed ? (uint64_t) block_list[pos >> 8] * kTilesPerBatch + (pos & 255u) : pos;
+            const bool have = in_batch && tri < p.n_tris;
             float q[9];
 #pragma unroll
             for (uint32_t j = 0; j < 9; ++j) q[j] = have ? verts[tri * 9u + j] : 0.f;

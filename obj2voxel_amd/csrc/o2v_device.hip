@@ -399,7 +399,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     ctx->ktimes_used = 0;
     if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[0], s));
     // (the counters were zeroed behind the previous pass, off its critical path, unless something else used them since)
-    if (!ctx->ctr_clean) O2V_LAUNCH("k_init", s, k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    if (!ctx->ctr_clean) O2V_LAUNCH("k_init", s, k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr, kPassCounterWords);
     ctx->ctr_clean = false;
     if (!p.bounds_known) {
         // one workgroup per CU: every workgroup ends with six atomics on the same six words, which serialise (1024
@@ -475,7 +475,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         // K1's counters go to the host on an auxiliary stream while k_voxelize runs (see below)
         O2V_CHECK(hipEventRecord(ctx->ev_k1, s));
         O2V_CHECK(hipStreamWaitEvent(ctx->aux[0], ctx->ev_k1, 0));
-        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->aux[0]));
+        O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, kPassCounterWords * 4u, hipMemcpyDeviceToHost, ctx->aux[0]));
     }
 
     {
@@ -639,7 +639,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     }
     if (ctx->stage_events) O2V_CHECK(hipEventRecord(ctx->ev[5], s));
     // (a kernel that writes the counters into the page-locked copy instead of this copy command was measured: the same step time)
-    O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, kPassCounterWords * 4u, hipMemcpyDeviceToHost, s));
     // (polling the stream with hipStreamQuery instead was measured: the same step time - the runtime's wait spins already)
     O2V_CHECK(hipStreamSynchronize(s));
     O2V_CHECK(hipGetLastError());
@@ -660,7 +660,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         it->launches += 1;
     }
     // the next pass's counters: zeroed now, behind this pass (its results are on the host)
-    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr, kPassCounterWords);
     ctx->ctr_clean = true;
     return O2V_HIP_OK;
 }
@@ -725,7 +725,7 @@ int ctx_finish_triangles(o2v_hip_ctx *ctx, bool any_textured, const TriHints *hi
     }
     else if (count) {
         ctx->ctr_clean = false;
-        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr, (uint32_t) (sizeof(Counters) / 4));
         hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (count * 9 / 12 + kBlock) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
         hipLaunchKernelGGL(k_tri_extent, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count + kBlock - 1) / kBlock)),
@@ -1571,7 +1571,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
         return rc;
     };
     ctx->ctr_clean = false;
-    if (!bounds_reduced) hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr);
+    if (!bounds_reduced) hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr, kPassCounterWords);
     if (!p.bounds_known && !bounds_reduced) {
         if (n_range)
             hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_range * 9 / 12 + kBlock) / kBlock)),
@@ -1617,7 +1617,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
                            (uint32_t) blocks_per_rank, ctx->d_zhist, ctx->d_zrange);
     }
     O2V_CHECK(hipMemcpyAsync(ctx->h_zhist, ctx->d_zhist, n_bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, kPassCounterWords * 4u, hipMemcpyDeviceToHost, s));
     O2V_CHECK(hipStreamSynchronize(s));
     O2V_CHECK(hipGetLastError());
     ctx->zrange_generation = ctx->tri_generation;  // k_expand_roots may use the extents (it checks the transform)
@@ -1775,7 +1775,7 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
         const uint64_t share_begin = b0r * kBlock, share_end = std::min<uint64_t>(T, b1r * kBlock);
         const uint64_t n_share = share_end > share_begin ? share_end - share_begin : 0;
         ctx->ctr_clean = false;
-        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s0, ctx->d_ctr);
+        hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s0, ctx->d_ctr, kPassCounterWords);
         if (!params->bounds_known && !rc_prepare && n_share)
             hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_share * 9 / 12 + kBlock) / kBlock)),
                                dim3(kBlock), 0, s0, ctx->d_verts + share_begin * 9, n_share * 9, ctx->d_ctr);

@@ -23,6 +23,47 @@ def _write_obj(path, v):
     path.write_text("\n".join(lines) + "\n")
 
 
+def _stdout_line(r):
+    """What the driver parses: the LAST line of stdout - one compact JSON object of the contract's keys, under 4 KB."""
+    import bench
+    lines = r.stdout.strip().splitlines()
+    last = lines[-1]
+    assert len(last) < bench.LINE_BUDGET, len(last)
+    assert sum(1 for ln in lines if ln.startswith("{")) == 1, "one JSON line on stdout"
+    line = json.loads(last)
+    assert set(line) <= set(bench.LINE_KEYS), sorted(set(line) - set(bench.LINE_KEYS))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in line, k
+    assert set(line["roofline"]) <= set(bench.ROOFLINE_KEYS) and set(line["config"]) <= set(bench.CONFIG_KEYS)
+    return line
+
+
+def test_default_bench_stdout_is_the_compact_line(tmp_path):
+    """`python bench.py --steps 2` as the driver runs it (every leg on: routes, capi, published workload, cpu baseline): the last
+    stdout line is the compact object with `roofline` and `cpu_baseline`; the details are in the sidecar and on stderr."""
+    env = dict(os.environ, O2V_BENCH_DETAILS=str(tmp_path / "details.json"))
+    env.pop("O2V_ASSETS", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--route-steps", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _stdout_line(r)
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    assert "configs[2]" in line["config"]["workload"] and line["config"]["resolution"] == 1024 and line["config"]["voxels"] == 4936186
+    rf = line["roofline"]
+    assert rf["kernel"] == "k_voxelize_occ" and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["kernel_ms"] > 0
+    cb = line["cpu_baseline"]
+    assert set(cb) == set(bench_keys("CPU_KEYS")) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    det = json.load(open(tmp_path / "details.json"))
+    assert {"routes", "stages", "pipeline", "capi_wall", "published_workload", "kernels_ms", "stats"} <= set(det)
+    assert "bench details: " in r.stderr
+
+
+def bench_keys(name):
+    import bench
+    return getattr(bench, name)
+
+
 def test_kernel_times_cover_the_pipeline():
     from obj2voxel_amd import hip
     d = hip.DeviceVoxelizer(0)
@@ -66,11 +107,13 @@ def test_stage_times_only_on_request():
 def test_bench_line_routes_and_assets(tmp_path):
     _write_obj(tmp_path / "dragon.obj", meshes.uv_sphere(40))
     _write_obj(tmp_path / "spot.obj", meshes.uv_sphere(16))
-    env = dict(os.environ, O2V_ASSETS=str(tmp_path))
+    env = dict(os.environ, O2V_ASSETS=str(tmp_path), O2V_BENCH_DETAILS=str(tmp_path / "details.json"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--route-steps", "1",
                         "--no-cpu-baseline", "--no-capi"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    short = _stdout_line(r)
+    line = json.load(open(tmp_path / "details.json"))          # routes, kernels_ms ...: the sidecar, not the stdout line
+    assert short["config"]["workload"] == line["config"]["workload"] and short["value"] == line["value"]
     assert "dragon.obj" in line["config"]["workload"] and line["config"]["triangles"] == len(meshes.uv_sphere(40))
     names = [x["workload"] for x in line["routes"]]
     assert names[0] == "config2" and "asset:spot" in names and "asset:sponza" not in names
@@ -85,16 +128,19 @@ def test_bench_line_routes_and_assets(tmp_path):
     assert line["build_id"] and "kernels_ms" in line
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo():
+def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path):
     """The N > 1 bench plumbing on a single-GPU box: two processes (torch.distributed launch, gloo), both on GPU 0, the
     library's collectives through host-memory callbacks.  The line carries the world size, the per-collective times and the
     upload comparison (the RCCL broadcast leg needs the nccl backend and is absent here)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
            "--same-device", "--workload", "weak", "--resolution", "256", "--nv", "120"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, O2V_BENCH_DETAILS=str(tmp_path / "details.json")))
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    short = _stdout_line(r)
+    assert short["n_gpus"] == 2 and short["strong_scaling_same_job"]["voxels_match"] is True
+    assert short["config"]["collectives"]["world"] == 2 and "upload" not in short["config"]
+    line = json.load(open(tmp_path / "details.json"))
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "zslab2" and line["value"] > 0
     col = line["config"]["collectives"]
     assert col["world"] == 2 and col["backend"] == "callbacks"

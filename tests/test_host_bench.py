@@ -6,6 +6,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import pytest  # noqa: E402
+
 import bench  # noqa: E402
 
 REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -104,6 +106,88 @@ def test_other_workloads_get_an_estimate_not_the_counters():
     assert two["roofline"]["bound"] == "valu" and two["roofline"]["estimated"] is True
     assert two["config"]["collectives"]["backend"] == "rccl" and two["config"]["parallelism"] == "zslab2"
     assert two["config"]["collectives"]["rccl_world_size"] == 2 and two["scaling"] == "weak"
+
+
+def _full_line(n=1):
+    """A line as heavy as the real one: routes, stages, capi_wall, published_workload, a cpu_baseline with every diagnostic."""
+    cur = json.load(open(bench.PROFILE_SUMMARY))
+    stats = dict(STATS, **{k: v for k, v in cur["workload_stats"].items() if not k.startswith("_")})
+    out = _line(n, stats, comm=_Comm() if n > 1 else None, **({"name": "weak", "res": 2896, "nv": 1321} if n > 1 else {}))
+    out["routes"] = [{"workload": f"route{i}", "what": "x" * 200, "kernels_ms": {f"k{j}": 0.1 for j in range(30)}} for i in range(8)]
+    out["capi_wall"] = {"ms": 4.1, "ms_all": [4.1] * 8, "what": "y" * 300}
+    out["published_workload"] = {"workload": "z" * 300, "later_calls_s": [0.03] * 4}
+    out["cli_wall"] = {"headline": {"wall_s": 0.5}, "readme": {"wall_s": 0.6}}
+    out["cpu_baseline"] = {"value": 21.2, "unit": "Mvoxels/s", "cores": 32, "kind": "port", "cpu_model": "AMD EPYC 9575F 64-Core Processor",
+                           "hardware_threads": 256, "median_s_by_threads": {str(k): 0.3 for k in (256, 128, 64, 32, 16)}, "value_1_thread": 1.61,
+                           "runs_s": [0.23] * 3, "phases_s": {"prelude": 0.01, "chunk_loop": 0.2, "join": 0.02},
+                           "sample": "the full workload (870488 tris at 1024^3 -> 4936186 voxels): median of 3 runs with 32 threads (the best of "
+                                     "[16, 32, 64, 128, 256]) over 64^3 chunks after one warm-up run, and one run with 1 thread",
+                           "matches_gpu_voxel_count": True}
+    if n > 1:
+        se = bench.strong_entry({"seconds": 4.0e-3, "voxels": stats["voxels"] * n, "cuts": list(range(n + 1))},
+                                {"seconds_per_step": 0.6e-3, "voxels": stats["voxels"] * n}, n)
+        out["strong_scaling_same_job"] = se
+        out["config4"] = {"workload": bench.WORKLOAD_TEXT["config4"].format(nv=3536, T=49999040, res=4096, n=n), "metric": "Mvoxels/sec at 4096^3 grid",
+                          "value": 60000.0, "mtris_per_s": 30000.0, "ms_per_step": 1.3, "voxels": 79000000, "stages_ms_rank0": dict(STAGES),
+                          "strong_scaling_same_job": se, "answers": "w" * 200}
+        out["config"]["upload"] = {"bytes": 1, "what": "v" * 200}
+    return out
+
+
+def test_stdout_line_is_compact_whatever_the_details_hold():
+    """The driver keeps a bounded tail of stdout and parses its last line: round 5's 24.7 KB line came out unparsed.  The line
+    has a hard budget and a fixed key set; everything else is in the sidecar."""
+    out = _full_line(1)
+    assert len(json.dumps(out)) > 8000          # (the details are what they were)
+    s = bench.compact_line(out)
+    assert len(s) < 4096 and "\n" not in s
+    line = json.loads(s)
+    assert set(line) <= set(bench.LINE_KEYS)
+    for k in REQUIRED + ("cpu_baseline",):
+        assert k in line, k
+    assert set(line["config"]) == {"workload", "resolution", "triangles", "voxels", "parallelism", "collectives"}
+    assert "configs[2]" in line["config"]["workload"] and line["dtype"] == "f32" and line["vs_baseline"] is None
+    r = line["roofline"]
+    assert set(r) <= set(bench.ROOFLINE_KEYS) and {"bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "traffic"} <= set(r)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "cpu_model", "value_1_thread", "sample"}
+    for gone in ("routes", "stages", "pipeline", "capi_wall", "published_workload", "cli_wall", "kernels_ms", "stats", "steady_state"):
+        assert gone not in line
+
+
+def test_stdout_line_of_an_eight_gpu_run_is_compact_and_carries_both_curves():
+    out = _full_line(8)
+    s = bench.compact_line(out)
+    line = json.loads(s)
+    assert len(s) < 4096 and line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert line["config"]["collectives"]["rccl_world_size"] == 2 or line["config"]["collectives"]["rccl_world_size"] == 8
+    assert line["strong_scaling_same_job"]["speedup"] > 0 and line["config4"]["strong_scaling_same_job"]["speedup"] > 0
+    assert "upload" not in line["config"] and "answers" not in line["config4"]
+
+
+def test_stdout_line_budget_sheds_text_then_optional_keys(monkeypatch):
+    out = _full_line(8)
+    out["cpu_baseline"] = dict(value=1.0, unit="Mvoxels/s", cores=1, kind="port", cpu_model="c" * 3000, value_1_thread=1.0, sample="s" * 3000)
+    out["config"]["workload"] = "w" * 3000
+    s = bench.compact_line(out)
+    assert len(s) < 4096
+    line = json.loads(s)
+    for k in REQUIRED:
+        assert k in line, k
+    monkeypatch.setattr(bench, "LINE_BUDGET", 600)      # nothing left to shed: loud, not a silently oversized line
+    with pytest.raises(RuntimeError):
+        bench.compact_line(out)
+
+
+def test_emit_writes_the_details_beside_the_line(tmp_path, capsys, monkeypatch):
+    out = _full_line(1)
+    monkeypatch.setenv("O2V_BENCH_DETAILS", str(tmp_path / "d.json"))
+    bench.emit(out)
+    cap = capsys.readouterr()
+    last = cap.out.strip().splitlines()[-1]
+    assert json.loads(last) == bench.compact(out) and len(last) < 4096
+    assert json.load(open(tmp_path / "d.json")) == json.loads(json.dumps(out))
+    assert "bench details: " in cap.err and "routes" in cap.err
 
 
 def test_same_job_strong_scaling_entry():

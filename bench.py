@@ -710,6 +710,8 @@ def report(args, n, run, dv, comm):
         out["capi_wall"] = capi_wall(467, 1024) if run["name"] != "config2" else capi_wall(nv, res)   # (always the stand-in mesh)
     if n == 1 and not args.no_capi:
         out["published_workload"] = published_workload()
+    if n == 1 and not args.no_capi:
+        out["cli_wall"] = cli_wall()
     if n == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(run["verts"], res, V, (run.get("kw") or {}).get("supersampling", 1))
     return out
@@ -731,6 +733,18 @@ def capi_wall(nv, res):
                         "(the first creates the device session and allocates the dense grids)"}
     except Exception as e:  # the helper needs gcc; the bench line must not depend on it
         return {"error": str(e)}
+
+
+def cli_wall():
+    """Process-level wall time of the command line front end on the headline stand-in (binary STL, -r 1024) and on the stand-in of
+    the reference README's showcase run (OBJ + MTL + PNG, -r 8192): process start -> exit with the output file closed, every run
+    a new process - the only kind of figure the reference publishes (README.adoc:177-178: 1.82 s) and what a CLI user gets
+    (tools/bench_cli.py).  Goes to the details file, not to the stdout line."""
+    try:
+        from tools import bench_cli
+        return bench_cli.measure("both", reps=3)
+    except Exception as e:  # noqa: BLE001 - the line must not depend on it
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def published_workload():

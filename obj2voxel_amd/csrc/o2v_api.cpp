@@ -502,6 +502,50 @@ void release_session(Session *s, bool from_cache)
     delete s;  // caching is off, or a concurrent voxelization on another thread used a temporary session
 }
 
+// A session on its way: acquire_session() on the calling thread or on one of its own (see voxelize()).  Whoever takes the
+// session releases it; one that nobody took (the call failed before it was needed) is released here.
+struct PendingSession {
+    std::vector<int> devices;
+    Session *session = nullptr;
+    bool from_cache = false, started = false, taken = false, background = false;
+    std::string why;
+    double create_ms = 0.0;
+    std::thread worker;
+    void run()
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        session = acquire_session(devices, from_cache, why);
+        create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void start(bool on_a_thread)
+    {
+        started = true;
+        devices = requested_devices();
+        if (on_a_thread) {
+            try {
+                worker = std::thread{[this] { run(); }};
+                background = true;
+                return;
+            }
+            catch (const std::system_error &) {
+                // (no thread to be had: on this one)
+            }
+        }
+        run();
+    }
+    Session *take()
+    {
+        if (worker.joinable()) worker.join();
+        taken = true;
+        return session;
+    }
+    ~PendingSession()
+    {
+        if (worker.joinable()) worker.join();
+        if (session && !taken) release_session(session, from_cache);
+    }
+};
+
 // The GPU leg of voxelize_specialized (reference obj2voxel.cpp:467-520): bounds, transform, per-triangle
 // voxelization, colour combine and packing all happen on the device(s); the host only moves data.
 obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session, const std::vector<int> &devices, MeshArrays *mesh_ptr,
@@ -668,6 +712,12 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No resolution was specified");
         return OBJ2VOXEL_ERR_NO_RESOLUTION;
     }
+    // A file input is parsed as a whole when it is opened, and a new process' first device session costs as much again (HIP
+    // runtime start, context, code object): neither needs the other, so the session is made on a thread meanwhile.  (A CLI run
+    // is one process per model, src/main.cpp:147-200: it always pays for a new session.)  A callback source has nothing to
+    // overlap with; its session is made when its first triangle is there, as before.
+    PendingSession pending;
+    if (inst.input_kind == IoKind::FILE) pending.start(true);
     std::unique_ptr<TriangleSource> input = open_input(inst);
     if (!input) return OBJ2VOXEL_ERR_IO_ERROR_ON_OPEN_INPUT_FILE;
     inst.sink = open_output(inst);
@@ -687,10 +737,11 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
     }
     // The device session comes before the rest of the source: with one GPU the triangles are drained straight into its
     // staging memory.
-    const std::vector<int> devices = requested_devices();
-    bool from_cache = false;
-    std::string why;
-    Session *session = acquire_session(devices, from_cache, why);
+    if (!pending.started) pending.start(false);
+    Session *session = pending.take();
+    const std::vector<int> &devices = pending.devices;
+    const bool from_cache = pending.from_cache;
+    const std::string &why = pending.why;
     if (!session) {
         log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "No usable MI355X (gfx950) device (" + why + "): the GPU voxelization path cannot run "
                                                "and this library has no CPU fallback");
@@ -703,7 +754,10 @@ obj2voxel_error_t voxelize(obj2voxel_instance &inst)
         bool from_cache;
         ~Guard() { release_session(s, from_cache); }
     } guard{session, from_cache};
-    if (!from_cache) log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: creating the device session " + std::to_string(clock.lap_ms()) + " ms");
+    if (!from_cache)
+        log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: creating the device session " + std::to_string(pending.create_ms) + " ms" +
+                                                   (pending.background ? " on a thread beside the input's parsing, waited for " + std::to_string(clock.lap_ms()) + " ms"
+                                                                       : std::string()));
 
     MeshArrays mesh;
     StreamedUpload stream;

@@ -568,7 +568,7 @@ def report(args, n, run, dv, comm):
         "expand": ["k_count_roots", "k_expand_roots", "k_expand_nodes", "k_expand_big", "k_mark_bricks"],
         "voxelize": ["k_voxelize_occ", "k_voxelize<false>", "k_voxelize<true>"],
         "scan": ["k_scan_flags", "k_scan_bricks", "k_scatter", "k_reset_bricks"],
-        "resolve": ["k_resolve<4>", "k_resolve<6>", "k_resolve_inline_list<4>", "k_resolve_inline_list<6>", "k_resolve_list16<4>", "k_resolve_list16<6>", "k_resolve_wave<32>", "k_resolve_wave<64>",
+        "resolve": ["k_resolve<4>", "k_resolve<6>", "k_resolve_inline_list<4>", "k_resolve_inline_list<6>", "k_resolve_list16<4>", "k_resolve_list16<6>", "k_resolve_wave<32>", "k_resolve_wave<64>", "k_resolve_tiers",
                     "k_resolve_sorted", "k_resolve_big", "k_resolve_huge", "k_pick", "k_emit_max"],
     }
     if direct and not Hp:   # the max grid's flag scan runs in the "scan" interval, the emission in "resolve"

@@ -142,6 +142,7 @@ enum : uint32_t {
     kErrRank = 4u,
     kErrDirtyList = 8u,  // more dirty bricks than the dirty list holds (Params::cap_dirty)
     kErrCounterWrap = 16u,  // 2^32 or more leaves (or tiles) in one pass: the counters of k_expand_* wrapped
+    kErrSoloRoots = 32u,    // Params::solo_roots: a root triangle is not a leaf of one tile after all (the pass is repeated with k_expand_roots)
 };
 
 struct Params {
@@ -173,6 +174,7 @@ struct Params {
     // Occupancy-only mode: a root triangle that is one leaf of one tile (the usual triangle of a tessellated surface) gets no
     // Leaf and no Tile record; k_voxelize_occ makes its leaf from the vertex array (k_expand_roots only counts it).
     uint32_t root_bypass;
+    uint32_t solo_roots;   // root_bypass and no k_expand_roots at all: k_voxelize_occ also counts the root leaves (see o2v_hip_voxelize)
     float plan_leaf_cost;  // slab planning (k_zhist): what a leaf costs beside its hits, in hit equivalents
     uint32_t exact_clip;   // O2V_HIP_FLAG_EXACT_CLIP: no work-removal shortcuts in k_voxelize (every leaf is treated as not `small`)
     // Direct MAX path (MAX strategy, no textured triangle; section 4 of DESIGN.md): one 64-bit cell per output voxel that

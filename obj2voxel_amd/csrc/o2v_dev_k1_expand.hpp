@@ -413,12 +413,24 @@ __global__ __launch_bounds__(kBlock) void k_expand_roots(const float *__restrict
 // Params::root_bypass: the root triangles k_expand_roots leaves to k_voxelize_occ - those that are voxelized as they are
 // (voxelization.cpp:488-511: roughly axis-aligned, or a voxel AABB of fewer than 512 cells), touch the slab and fit one tile.
 // The same sequence of tests as k_expand_roots' classify(), on the same transformed vertices: both kernels decide alike.
+// `other` (Params::solo_roots, where k_expand_roots is not launched at all): the triangle is none of k_voxelize_occ's and not
+// nothing either - a node, a leaf of several tiles, a leaf too large: k_expand_roots' business.
+__device__ __forceinline__ bool root_leaf_of_one_tile(const Sub &s, const Params &p, LeafPlan &pl, bool &other)
+{
+    other = false;
+    if (misses_slab(s, p)) return false;
+    if (!(roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit)) {
+        other = true;
+        return false;
+    }
+    pl = plan_leaf(s, p);
+    other = (pl.count >> 32) != 0u || pl.ntiles > 1u;
+    return !(pl.count >> 32) && pl.ntiles == 1u;
+}
 __device__ __forceinline__ bool root_leaf_of_one_tile(const Sub &s, const Params &p, LeafPlan &pl)
 {
-    if (misses_slab(s, p)) return false;
-    if (!(roughly_axis_aligned(s.v0, s.v1, s.v2) || voxel_volume(s) < kSubdivisionVolumeLimit)) return false;
-    pl = plan_leaf(s, p);
-    return !(pl.count >> 32) && pl.ntiles == 1u;
+    bool other;
+    return root_leaf_of_one_tile(s, p, pl, other);
 }
 
 // Params::root_bypass on a tessellated surface (practically every triangle is one leaf of one tile: o2v_hip_voxelize decides from the

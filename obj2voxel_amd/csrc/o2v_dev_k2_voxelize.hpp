@@ -578,6 +578,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
     // longest jobs first keeps the end of a sub-batch, when lanes run out of work, short.
     uint2 *jobq = jobq_all + (size_t) blockIdx.x * (OCC ? 2u * kQueueCap : kQueueCap);
     __shared__ uint32_t s_next_x[kVoxBlock], s_next_y[kVoxBlock];  // every lane's prefetched next job record (take_job)
+    __shared__ unsigned long long s_solo[OCC ? 3 : 1];  // Params::solo_roots: this workgroup's root leaves, their candidates, the squares
     __shared__ uint8_t s_cls[64];    // classify_flags
     __shared__ uint8_t s_kept[128];  // classify_kept: index | keep_lo << 6
 
@@ -621,7 +622,8 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
     {
         const double n_l = (double) c->n_leaves + (double) c->n_bypass, sum = (double) c->n_candidates, sq = (double) c->n_candidates_sq;
         // (variance of the leaves' candidate counts against their squared mean: above 1/2 the leaves are "very unequal")
-        if (n_l > 0.0 && sq * n_l > 1.5 * sum * sum) taper = true;
+        // (Params::solo_roots: these are counted by this kernel itself, so they are not read here - every workgroup must make the same plan)
+        if (!(OCC && p.solo_roots) && n_l > 0.0 && sq * n_l > 1.5 * sum * sum) taper = true;
     }
 #ifdef O2V_NO_TAPER
     taper = false;
@@ -679,6 +681,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
         s_certain = 0;
         s_skipped = 0;
     }
+    if (OCC && threadIdx.x < 3u) s_solo[threadIdx.x] = 0ull;
     if (threadIdx.x < 64u) s_cls[threadIdx.x] = (uint8_t) classify_flags(threadIdx.x);
     for (uint32_t i = threadIdx.x; i < 128u; i += kVoxBlock) s_kept[i] = (uint8_t) classify_kept(i & 63u, i >= 64u);
 
@@ -704,6 +707,8 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
             float q[9];
 #pragma unroll
             for (uint32_t j = 0; j < 9; ++j) q[j] = have ? verts[tri * 9u + j] : 0.f;
+            bool solo_leaf = false, solo_other = false;
+            uint32_t solo_cnt = 0;
             if (threadIdx.x < nt) {
                 Affine xf;
                 xf.m[0] = {c->xform[0], c->xform[1], c->xform[2]};
@@ -715,7 +720,11 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                 sb.v1 = affine_apply(xf, V3{q[3], q[4], q[5]});
                 sb.v2 = affine_apply(xf, V3{q[6], q[7], q[8]});
                 LeafPlan pl{};
-                const bool is_leaf = have && root_leaf_of_one_tile(sb, p, pl);
+                bool other = false;
+                const bool is_leaf = have && root_leaf_of_one_tile(sb, p, pl, other);
+                solo_leaf = is_leaf;
+                solo_other = have && other;
+                solo_cnt = is_leaf ? (uint32_t) pl.count : 0u;   // (one tile: at most kTileSize)
                 uint32_t *lw = &s_leaf[threadIdx.x * kLeafStride];
                 const V3 nrm = normalize(tri_normal(sb.v0, sb.v1, sb.v2));  // voxelization.cpp:438
                 const float vals[12] = {sb.v0.x, sb.v0.y, sb.v0.z, sb.v1.x, sb.v1.y, sb.v1.z, sb.v2.x, sb.v2.y, sb.v2.z, nrm.x, nrm.y, nrm.z};
@@ -728,6 +737,20 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                 lw[22] = is_leaf ? pl.d[1] | (pl.d[2] << 16) : 0u;
                 lw[23] = __float_as_uint(is_leaf ? tri_area(sb.v0, sb.v1, sb.v2) : 0.f);
                 s_tstart[threadIdx.x] = 0u;
+            }
+            if (p.solo_roots) {
+                // no k_expand_roots ran: its counts of the root leaves (statistics; the batches' sizes) are made here, and a
+                // triangle that is its business after all voids the pass (o2v_hip_voxelize repeats it with k_expand_roots)
+                const unsigned long long ml = __ballot(solo_leaf);
+                if (__ballot(solo_other) && lane == 0) atomicOr(&c->err_flags, kErrSoloRoots);
+                if (ml) {
+                    const uint32_t cand = __shfl(wave_inclusive_scan(solo_cnt), 63, 64), sq = __shfl(wave_inclusive_scan(solo_cnt * solo_cnt), 63, 64);
+                    if (lane == 0) {
+                        atomicAdd(&s_solo[0], (unsigned long long) __popcll(ml));
+                        atomicAdd(&s_solo[1], (unsigned long long) cand);
+                        atomicAdd(&s_solo[2], (unsigned long long) sq);
+                    }
+                }
             }
             __syncthreads();
         }
@@ -1473,6 +1496,11 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
     if (threadIdx.x == 0 && !OCC && s_direct) atomicAdd(&c->n_direct, (unsigned long long) s_direct);
     if (threadIdx.x == 0 && s_certain) atomicAdd(&c->n_certain, (unsigned long long) s_certain);
     if (threadIdx.x == 0 && s_skipped) atomicAdd(&c->n_jobs_skipped, (unsigned long long) s_skipped);
+    if (OCC && threadIdx.x == 0 && p.solo_roots && s_solo[0]) {
+        atomicAdd(&c->n_bypass, s_solo[0]);
+        atomicAdd(&c->n_candidates, s_solo[1]);
+        atomicAdd(&c->n_candidates_sq, s_solo[2]);
+    }
 }
 
 // The clip kernel of the weighted routes (UV: the mesh has textured triangles) ...

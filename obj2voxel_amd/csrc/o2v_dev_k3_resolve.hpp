@@ -355,17 +355,16 @@ __global__ __launch_bounds__(kBlock) void k_resolve_list16(const uint32_t *__res
 // record; the (key, position) pairs are bitonic-sorted across the W lanes with cross-lane moves only (no LDS, no
 // barrier); the payload is gathered to its sorted lane; the groups are folded and coloured in parallel by the lanes at their
 // first records, and the cell's chain over the groups runs on every lane of the cell on broadcast values.
+// (the body: wavefront `wave` of `n_waves` that share the list)
 template <uint32_t W>
-__global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restrict__ list, const uint32_t *n_list,
-                                                         const Counters *c, const Occ *__restrict__ occ,
-                                                         SortedView sorted, Materials m, uint4 *out, uint32_t list_cap,
-                                                         Params p)
+__device__ __forceinline__ void resolve_wave_body(uint32_t wave, uint32_t n_waves, const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                  const Counters *c, const Occ *__restrict__ occ, SortedView sorted, const Materials &m,
+                                                  uint4 *out, uint32_t list_cap, const Params &p)
 {
     constexpr uint32_t kPerWave = 64u / W;
     if (pass_overflowed(c, p)) return;
     const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
     const uint32_t lane = threadIdx.x & 63u, sub = lane / W, sl = lane % W, base_lane = sub * W;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlock / 64u);
     for (uint32_t item0 = wave * kPerWave; item0 < total; item0 += n_waves * kPerWave) {  // wave-uniform
         const uint32_t item = item0 + sub;
         const bool valid = item < total;
@@ -444,6 +443,131 @@ __global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restr
         if (n != 0 && sl == 0) emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
+template <uint32_t W>
+__global__ __launch_bounds__(kBlock) void k_resolve_wave(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                         const Counters *c, const Occ *__restrict__ occ,
+                                                         SortedView sorted, Materials m, uint4 *out, uint32_t list_cap,
+                                                         Params p)
+{
+    resolve_wave_body<W>((blockIdx.x * kBlock + threadIdx.x) >> 6, gridDim.x * (kBlock / 64u), list, n_list, c, occ, sorted, m, out, list_cap, p);
+}
+
+// Between phases in which the lanes of ONE wavefront exchange values through LDS: the hardware runs a wavefront's LDS
+// instructions in order, so this only has to keep the compiler from moving them across.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// BLEND over a crowded cell: the chain over its (sub-voxel, triangle) groups - CellFold's close_tri / close_sub sequence
+// (moveUvBufferIntoVoxels, voxelization.cpp:513-526; insertWeighted / mix, :56-63, util.hpp:160-172; downscale,
+// voxelization.hpp:82-85) - run by ONE wavefront on values in LDS.  The float mix is not associative, so the chain is
+// sequential; what can be had is a short step.  On entry entry t < n holds, if it is the first record of its group, the
+// group's {key, weight, r, g, b (bits)}; the other entries are skipped.
+//   1. the group starts are compacted in place (positions 0 .. G - 1; the key becomes the sub-voxel index);
+//   2. every sub-voxel's chain is independent of the others', and so are the three colour channels of one chain (they share
+//      only the running weight, one add per step, which every lane keeps for itself): lane 3 s + c walks sub-voxel s, channel c -
+//      a step is two LDS reads, w + W, w c + W C and ONE division per lane (the fold on one lane, values through v_readlane,
+//      took three divisions and five v_readlane per step: ~45 instructions against ~18; a wavefront alone on its SIMD issues
+//      one per ~4.6 cycles whatever their dependences);
+//   3. the sub-voxels' results are combined in ascending order (at most eight steps) by lanes 0 .. 2.
+// Same operations on the same operands in the same order as CellFold: same bits.  Returns the cell's ARGB (every lane).
+__device__ __forceinline__ uint32_t blend_chain_lds(uint32_t *s_hi, float *s_w, float *s_r, float *s_g, uint32_t *s_b_bits, uint32_t n,
+                                                    uint32_t *s_seg /*[16]*/, float *s_res /*[32]*/)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    float *s_b = reinterpret_cast<float *>(s_b_bits);
+    uint32_t n_groups = 0;  // wave-uniform
+    {
+        uint32_t prev_hi = 0;  // wave-uniform: the key of the entry before this chunk
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t t = base + lane;
+            const bool in = t < n;
+            const uint32_t hi_t = in ? s_hi[t] : 0u;
+            const uint32_t before = __shfl_up(hi_t, 1u, 64);
+            const bool start = in && (t == 0u || (lane == 0u ? prev_hi : before) != hi_t);
+            const float w_t = start ? s_w[t] : 0.f, r_t = start ? s_r[t] : 0.f, g_t = start ? s_g[t] : 0.f, b_t = start ? s_b[t] : 0.f;
+            prev_hi = (uint32_t) __builtin_amdgcn_readlane((int) hi_t, 63);
+            const unsigned long long m = __ballot(start);
+            const uint32_t pos = n_groups + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+            // (every lane has read its entry; pos <= t, and the entries of later chunks lie above every pos of this one)
+            if (start) {
+                s_hi[pos] = hi_t >> 29;
+                s_w[pos] = w_t;
+                s_r[pos] = r_t;
+                s_g[pos] = g_t;
+                s_b[pos] = b_t;
+            }
+            n_groups += (uint32_t) __popcll(m);
+        }
+    }
+    if (lane < 16u) s_seg[lane] = 0u;  // [s]: first group of sub-voxel s, [8 + s]: one past its last (both 0: none)
+    wave_lds_sync();
+    for (uint32_t g = lane; g < n_groups; g += 64u) {
+        const uint32_t sub = s_hi[g];
+        if (g == 0u || s_hi[g - 1u] != sub) s_seg[sub] = g;
+        if (g + 1u == n_groups || s_hi[g + 1u] != sub) s_seg[8u + sub] = g + 1u;
+    }
+    wave_lds_sync();
+    const uint32_t sub = lane / 3u, ch = lane - sub * 3u;
+    const bool walker = lane < 24u;
+    const uint32_t g0 = walker ? s_seg[sub] : 0u, g1 = walker ? s_seg[8u + sub] : 0u;
+    const uint32_t len = g1 - g0;
+    uint32_t longest = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 8u; ++q) {
+        const uint32_t l = s_seg[8u + q] - s_seg[q];
+        longest = l > longest ? l : longest;
+    }
+    const float *col = ch == 0u ? s_r : (ch == 1u ? s_g : s_b);
+    float W = 0.f, C = 0.f;
+    if (len) {
+        W = s_w[g0];
+        C = col[g0];
+    }
+    // (the next step's operands are requested before this step's arithmetic: the LDS round trip hides behind it)
+    const uint32_t last = len ? g1 - 1u : 0u;
+    uint32_t at = g0 + 1u < g1 ? g0 + 1u : last;
+    float w_next = s_w[at], c_next = col[at];
+    for (uint32_t k = 1; k < longest; ++k) {
+        const float w = w_next, c = c_next;
+        at = at + 1u < g1 ? at + 1u : last;
+        w_next = s_w[at];
+        c_next = col[at];
+        if (k < len) {
+            // wmix(fresh, acc), util.hpp:160-165: ws = l.w + r.w; (l.w l.c + r.w r.c) / ws
+            const float ws = w + W;
+            C = (w * c + W * C) / ws;
+            W = ws;
+        }
+    }
+    if (walker && ch == 0u) s_res[sub * 4u] = W;
+    if (walker) s_res[sub * 4u + 1u + ch] = C;
+    wave_lds_sync();
+    // the cell's chain over its sub-voxels, ascending (close_sub): lane c < 3 runs channel c
+    float cw = 0.f, cc = 0.f;
+    bool have_cell = false;
+    const uint32_t mych = lane < 3u ? lane : 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 8u; ++q) {
+        if (s_seg[8u + q] == s_seg[q]) continue;  // (wave-uniform)
+        const float sw = s_res[q * 4u], sc = s_res[q * 4u + 1u + mych];
+        if (have_cell) {
+            const float ws = sw + cw;
+            cc = (sw * sc + cw * cc) / ws;
+            cw = ws;
+        }
+        else {
+            cw = sw;
+            cc = sc;
+            have_cell = true;
+        }
+    }
+    const float fr = __shfl(cc, 0, 64), fg = __shfl(cc, 1, 64), fb = __shfl(cc, 2, 64);
+    return pack_argb(fr, fg, fb);
+}
 
 template <typename KeyPtr, typename IdxPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_pow2, uint32_t tid, uint32_t nthreads)
@@ -474,10 +598,10 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, IdxPtr idx, uint32_t n_
 // payload is gathered in sorted order, and lane 0 replays the fold (which is inherently sequential: the float
 // combine is not associative).
 template <uint32_t THREADS, uint32_t CAP>
-__global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
-                                                            uint32_t *cursor, const Counters *c,
-                                                            const Occ *__restrict__ occ, SortedView sorted, Materials m,
-                                                            uint4 *out, uint32_t list_cap, Params p)
+__device__ __forceinline__ void resolve_sorted_body(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                    uint32_t *cursor, const Counters *c,
+                                                    const Occ *__restrict__ occ, SortedView sorted, const Materials &m,
+                                                    uint4 *out, uint32_t list_cap, const Params &p)
 {
     if (pass_overflowed(c, p)) return;
     __shared__ uint64_t s_key[CAP];
@@ -485,6 +609,8 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
     __shared__ uint32_t s_hi[CAP];
     __shared__ float s_w[CAP], s_u[CAP], s_v[CAP];
     __shared__ uint32_t s_item;
+    __shared__ uint32_t s_seg[16];
+    __shared__ float s_res[32];
     const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
     for (;;) {
         __syncthreads();
@@ -538,42 +664,8 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
             }
             __syncthreads();
             if (threadIdx.x < 64u) {
-                // The chain over the groups is sequential, but nothing in it has to wait for memory: the first wavefront
-                // loads 64 entries at a time, one per lane, and walks the group starts among them in order, every value
-                // of the step coming out of a lane's register (v_readlane: the lane index is wavefront-uniform).  All
-                // lanes run the same recurrence; lane 0 writes the result.
-                const uint32_t lane = threadIdx.x;
-                bool have_sub = false, have_cell = false;
-                WCol sub_acc{0, 0, 0, 0}, cell_acc{0, 0, 0, 0};
-                uint32_t cur_sub = 0;
-                for (uint32_t base = 0; base < n; base += 64u) {
-                    const uint32_t t = base + lane;
-                    const bool in = t < n;
-                    const uint32_t hi_t = in ? s_hi[t] : 0u;
-                    const bool start = in && (t == 0 || hi_t != s_hi[t - 1]);
-                    const float w_t = in ? s_w[t] : 0.f, r_t = in ? s_u[t] : 0.f, g_t = in ? s_v[t] : 0.f;
-                    const uint32_t b_t = in ? s_idx[t] : 0u;
-                    unsigned long long starts = __ballot(start);
-                    while (starts) {
-                        const int j = __builtin_ctzll(starts);
-                        starts &= starts - 1ull;
-                        const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) hi_t, j);
-                        const WCol fresh{__uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(w_t), j)),
-                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(r_t), j)),
-                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(g_t), j)),
-                                         __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) b_t, j))};
-                        if (have_sub && (hi >> 29) != cur_sub) {
-                            cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
-                            have_cell = true;
-                            have_sub = false;
-                        }
-                        sub_acc = have_sub ? wcombine(p.blend, fresh, sub_acc) : fresh;
-                        have_sub = true;
-                        cur_sub = hi >> 29;
-                    }
-                }
-                if (have_sub) cell_acc = have_cell ? wcombine(p.blend, sub_acc, cell_acc) : sub_acc;
-                if (lane == 0) out[i] = cell_record(o, pack_argb(cell_acc.r, cell_acc.g, cell_acc.b), p);
+                const uint32_t argb = blend_chain_lds(s_hi, s_w, s_u, s_v, s_idx, n, s_seg, s_res);
+                if (threadIdx.x == 0) out[i] = cell_record(o, argb, p);
             }
         }
         else {
@@ -615,6 +707,33 @@ __global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__re
             }
         }
     }
+}
+template <uint32_t THREADS, uint32_t CAP>
+__global__ __launch_bounds__(THREADS) void k_resolve_sorted(const uint32_t *__restrict__ list, const uint32_t *n_list,
+                                                            uint32_t *cursor, const Counters *c,
+                                                            const Occ *__restrict__ occ, SortedView sorted, Materials m,
+                                                            uint4 *out, uint32_t list_cap, Params p)
+{
+    resolve_sorted_body<THREADS, CAP>(list, n_list, cursor, c, occ, sorted, m, out, list_cap, p);
+}
+
+// The cooperative tiers for 17 .. 256 hits in ONE launch of one-wavefront workgroups: the first `g_mid` take cells of 65 .. 256
+// hits from their cursor (k_resolve_sorted<64, 256>'s body - the longest cells, so they start first), the next `g_w64` are
+// k_resolve_wave<64>'s wavefronts (33 .. 64 hits), the rest k_resolve_wave<32>'s (17 .. 32).  Each of the three is a handful of
+// latency chains over few cells; as launches of their own on one stream they ran one after the other (configs[1]: 5 + 22 + 50 us
+// for 0.2 MB, the bench mesh with BLEND 47 + 33 + 92 us), together they take as long as the slowest.
+struct TierLists {
+    const uint32_t *mid, *w64, *w32;
+    const uint32_t *n_mid, *n_w64, *n_w32;
+    uint32_t *cursor_mid;
+};
+__global__ __launch_bounds__(64) void k_resolve_tiers(TierLists lists, uint32_t g_mid, uint32_t g_w64, const Counters *c, const Occ *__restrict__ occ,
+                                                      SortedView sorted, Materials m, uint4 *out, uint32_t list_cap, Params p)
+{
+    const uint32_t b = blockIdx.x;
+    if (b < g_mid) resolve_sorted_body<64, kMidList>(lists.mid, lists.n_mid, lists.cursor_mid, c, occ, sorted, m, out, list_cap, p);
+    else if (b < g_mid + g_w64) resolve_wave_body<64>(b - g_mid, g_w64, lists.w64, lists.n_w64, c, occ, sorted, m, out, list_cap, p);
+    else resolve_wave_body<32>(b - g_mid - g_w64, gridDim.x - g_mid - g_w64, lists.w32, lists.n_w32, c, occ, sorted, m, out, list_cap, p);
 }
 
 // Tier 3b: cells with 2049..8192 hits (the poles of a finely tessellated sphere at high resolution).  One workgroup

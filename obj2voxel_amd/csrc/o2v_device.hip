@@ -115,6 +115,8 @@ struct o2v_hip_ctx {
     uint32_t *d_need_list = nullptr;  // k_count_roots: the blocks k_expand_roots still has to walk
     uint32_t cap_need_list = 0;
     bool lean_roots = false;          // this call: k_count_roots ahead of k_expand_roots (o2v_hip_voxelize)
+    bool solo_roots = false;          // this call: no k_expand_roots at all, k_voxelize_occ counts the root leaves itself (o2v_hip_voxelize)
+    uint64_t solo_refused_key = 0;    // the mesh and settings for which a solo pass found a triangle that needs k_expand_roots
     uint32_t cap_block_list = 0;
     float mesh_bounds_hint[6] = {0, 0, 0, 0, 0, 0};  // bounds and largest triangle extent of the uploaded mesh: only used to
     float max_tri_extent = -1.f;                     // bound the number of subdivision rounds (-1: unknown)
@@ -432,7 +434,11 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     if (block_list && p.S) walked_blocks = std::min<uint64_t>(n_tri_blocks, (uint64_t) ((double) n_tri_blocks * (double) (p.zs1 - p.zs0) / (double) p.S * 1.33) + 64u);
     uint64_t root_wgs = p.root_bypass ? std::max<uint64_t>((uint64_t) ctx->num_cus * 2u, walked_blocks / 6u) : (p.n_tris + kBlock - 1) / kBlock;
     const uint32_t *k1_list = block_list, *k1_count = ctx->d_block_count;
-    if (ctx->lean_roots && p.root_bypass) {
+    if (p.solo_roots) {
+        // every root triangle is a leaf of one tile or misses the slab (o2v_hip_voxelize): nothing for K1 to write, and what it
+        // would count k_voxelize_occ counts
+    }
+    else if (ctx->lean_roots && p.root_bypass) {
         // a tessellated surface: the one-tile root triangles are counted by a kernel of their own, k_expand_roots only walks the
         // blocks that hold something else (k_count_roots)
         O2V_LAUNCH("k_count_roots", s, k_count_roots, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * kCountRootsWgsPerCu, std::max<uint64_t>((walked_blocks + 3u) / 4u, 1))),
@@ -441,17 +447,18 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         k1_count = &ctx->d_ctr->n_need_blocks;
         root_wgs = (uint64_t) ctx->num_cus;  // (the list is short or empty)
     }
-    O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, std::max<uint64_t>(root_wgs, 1))),
-                       dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
-                       ctx->d_big, ctx->d_nodes[0], have_zrange ? ctx->d_zrange : nullptr,
-                       ctx->d_zrange_xform, k1_list, k1_count, p);
-    for (uint32_t round = 0; round < n_rounds; ++round) {
+    if (!p.solo_roots)
+        O2V_LAUNCH("k_expand_roots", s, k_expand_roots, dim3(std::min<uint64_t>(persistent, std::max<uint64_t>(root_wgs, 1))),
+                           dim3(kBlock), 0, s, ctx->d_verts, ctx->d_uvs, ctx->d_ctr, ctx->d_leaves, ctx->d_tiles,
+                           ctx->d_big, ctx->d_nodes[0], have_zrange ? ctx->d_zrange : nullptr,
+                           ctx->d_zrange_xform, k1_list, k1_count, p);
+    for (uint32_t round = 0; round < (p.solo_roots ? 0u : n_rounds); ++round) {
         // most rounds are empty or small: a narrow grid keeps an empty launch short (the kernel strides over its input)
         O2V_LAUNCH("k_expand_nodes", s, k_expand_nodes, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_nodes[round & 1], round,
                            ctx->d_ctr, ctx->d_leaves, ctx->d_tiles, ctx->d_big, ctx->d_nodes[(round + 1) & 1], p);
     }
     // (left out if no leaf of this mesh can have more than four tiles, o2v_hip_voxelize; should one turn up, the pass is repeated)
-    if (!ctx->skip_big)
+    if (!ctx->skip_big && !p.solo_roots)
         O2V_LAUNCH("k_expand_big", s, k_expand_big, dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, s, ctx->d_big, ctx->d_ctr, ctx->d_tiles, p);
     // (a mesh that pooled no hits in its last pass with these settings - every triangle whole and on the direct MAX path - will
     // not pool any now: the two launches are left out; should K1's counters say otherwise, the pass is repeated with them)
@@ -599,15 +606,16 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         else
             O2V_LAUNCH("k_resolve_list16<4>", sw, k_resolve_list16<4>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_list_lane16,
                                &ctx->d_ctr->n_lane16, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_LAUNCH("k_reset_bricks", sm, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_grid,
+        // (behind the 9..16-hit tier: nothing waits for the counters' reset but the next pass)
+        O2V_LAUNCH("k_reset_bricks", sw, k_reset_bricks, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sw, ctx->d_grid,
                            ctx->d_dirty_list, ctx->d_ctr, p);
-        O2V_LAUNCH("k_resolve_wave<64>", sm, k_resolve_wave<64>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_w64,
-                           &ctx->d_ctr->n_w64, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_LAUNCH("k_resolve_wave<32>", sm, k_resolve_wave<32>, dim3((uint32_t) ctx->num_cus * 4u), dim3(kBlock), 0, sm, ctx->d_list_lane,
-                           &ctx->d_ctr->n_lane, ctx->d_ctr, ctx->d_occ, sorted_view, m, ctx->d_out, p.cap_vox, p);
-        O2V_LAUNCH("k_resolve_sorted<64,256>", sm, (k_resolve_sorted<64, kMidList>), dim3((uint32_t) ctx->num_cus * 8u), dim3(64), 0, sm,
-                           ctx->d_list_mid, &ctx->d_ctr->n_mid, &ctx->d_ctr->cursor_mid, ctx->d_ctr, ctx->d_occ, sorted_view, m,
-                           ctx->d_out, p.cap_vox, p);
+        {
+            // the cooperative tiers for 17 .. 256 hits: one launch of one-wavefront workgroups (k_resolve_tiers)
+            const uint32_t g_mid = (uint32_t) ctx->num_cus * 8u, g_w = (uint32_t) ctx->num_cus * 16u;
+            const TierLists tl{ctx->d_list_mid, ctx->d_list_w64, ctx->d_list_lane, &ctx->d_ctr->n_mid, &ctx->d_ctr->n_w64, &ctx->d_ctr->n_lane, &ctx->d_ctr->cursor_mid};
+            O2V_LAUNCH("k_resolve_tiers", sm, k_resolve_tiers, dim3(g_mid + 2u * g_w), dim3(64), 0, sm, tl, g_mid, g_w, ctx->d_ctr, ctx->d_occ, sorted_view, m,
+                               ctx->d_out, p.cap_vox, p);
+        }
         O2V_LAUNCH("k_resolve_sorted<256,2048>", sl, (k_resolve_sorted<kBlock, kLongList>), dim3((uint32_t) ctx->num_cus * 2u), dim3(kBlock), 0, sl,
                            ctx->d_list_long, &ctx->d_ctr->n_long, &ctx->d_ctr->cursor_long, ctx->d_ctr, ctx->d_occ, sorted_view, m,
                            ctx->d_out, p.cap_vox, p);
@@ -1284,6 +1292,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     uint32_t n_rounds = 4;
     while ((1u << n_rounds) < p.S && n_rounds < kMaxRounds) ++n_rounds;
     ctx->skip_big = false;
+    bool solo_ok = false;
     if (ctx->max_tri_extent >= 0.f) {
         // tighter: a (sub-)triangle whose extent is at most 5 voxels has a voxel AABB of at most 7^3 < 512 cells and is
         // a leaf; every round halves the extents.  Scale = the mesh transform's (obj2voxel.cpp:370-402).
@@ -1304,12 +1313,24 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             // ... and a leaf less than 7.9 voxels across has fewer than 10^3 cells = four tiles: none for k_expand_big (a larger
             // one can only be an axis-aligned triangle, voxelization.cpp:335-347)
             ctx->skip_big = ext_vox < 7.9f;
+            solo_ok = ext_vox < 4.99f;
         }
     }
     if (const char *all = std::getenv("O2V_ALL_LAUNCHES"); all && all[0] == '1') {  // (A/B: no launch left out on the strength of the hints)
         n_rounds = std::max<uint32_t>(n_rounds, 1u);
         ctx->skip_big = false;
+        solo_ok = false;
     }
+    // Occupancy only, every triangle less than 5 voxels across (the largest extent, known since the upload, at this call's scale):
+    // its voxel box has at most 6 cells per axis - 216: below the subdivision limit of 512 (voxelization.cpp:488-511) and one tile -
+    // so every root triangle is a leaf of one tile or misses the slab, and k_expand_roots (K1) would write nothing: it is not
+    // launched, k_voxelize_occ makes the leaves (as with root_bypass) and counts them.  The kernel checks the premise per triangle
+    // (kErrSoloRoots); should it ever fail, the pass is repeated with K1 and this mesh keeps it.
+    const uint64_t solo_key = ctx->tri_generation * 1000003ull + p.S * 131ull + p.zs0 * 31ull + p.zs1 + 1u;
+    if (const char *force = std::getenv("O2V_TEST_FORCE_SOLO_ROOTS"); force && force[0] == '1') solo_ok = true;  // test hook: whatever the hint says
+    ctx->solo_roots = p.root_bypass && solo_ok && ctx->solo_refused_key != solo_key;
+    if (const char *off = std::getenv("O2V_NO_SOLO_ROOTS"); off && off[0] == '1') ctx->solo_roots = false;
+    p.solo_roots = ctx->solo_roots ? 1u : 0u;
     ctx->force_general = false;
     ctx->mark_missing = false;  // (a call that ended early - an error, a failed allocation - must not leave it to the next one)
     if (!p.occupancy_only) ctx->grid_dirty = true;  // until a pass completes (the scan / reset kernels leave it clean)
@@ -1405,6 +1426,13 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         if ((rc = run_pass(ctx, p, use_uv, n_rounds))) return rc;
         const Counters &h = *ctx->h_ctr;
         ctx->timings.passes = pass;
+        if (p.solo_roots && (h.err_flags & kErrSoloRoots)) {
+            // a root triangle that is k_expand_roots' business although the hint ruled that out: the pass again, with K1
+            ctx->solo_refused_key = solo_key;
+            ctx->solo_roots = false;
+            p.solo_roots = 0;
+            continue;
+        }
         if (h.err_flags) {
             // (a dirty-list overflow leaves bricks behind that no list names: the grids stay marked for a full clear)
             // (nor does a pass that ran without a brick list - mark_missing - clean up behind itself)

@@ -180,3 +180,54 @@ def test_hit_weights_equal_in_exact_mode_untextured(kind, ss):
     assert len(fast) == len(exact) > 1_000_000, (len(fast), len(exact))
     same = (fast == exact).all(axis=1)
     assert same.all(), (int((~same).sum()), fast[~same][:3], exact[~same][:3])
+
+
+def test_root_stage_left_out_for_small_triangles(monkeypatch, oracle):
+    """Occupancy only, every triangle less than five voxels across: k_expand_roots is not launched, k_voxelize_occ makes and counts
+    the root leaves (Params::solo_roots).  Same voxels and the same leaf / tile / candidate statistics as with the root stage
+    (O2V_NO_SOLO_ROOTS=1), on the whole grid and on a z-slab; checked against the oracle."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(150)              # 89 400 triangles, ~3.4 voxels across at 320^3
+    want = meshes.sorted_voxels(oracle.voxelize(v, 320))
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_triangles(v)
+        runs = {}
+        for solo in (True, False):
+            if solo:
+                monkeypatch.delenv("O2V_NO_SOLO_ROOTS", raising=False)
+            else:
+                monkeypatch.setenv("O2V_NO_SOLO_ROOTS", "1")
+            whole = meshes.sorted_voxels(d.voxelize(320))
+            st, kt = d.stats(), None
+            d.voxelize(320, read=False, kernel_times=True)
+            kt = d.kernel_times()
+            slab = meshes.sorted_voxels(d.voxelize(320, zslab=(96, 200)))
+            runs[solo] = (whole, {k: st[k] for k in ("leaves", "tiles", "bypassed_leaves", "candidates", "voxels")}, set(kt), slab, d.timings()["passes"])
+        assert "k_expand_roots" not in runs[True][2] and "k_expand_roots" in runs[False][2]
+        assert "k_voxelize_occ" in runs[True][2]
+        assert np.array_equal(runs[True][0], want) and np.array_equal(runs[False][0], want)
+        assert runs[True][1] == runs[False][1] and runs[True][1]["bypassed_leaves"] == len(v)
+        assert np.array_equal(runs[True][3], runs[False][3]) and np.array_equal(runs[True][3], want[(want[:, 2] >= 96) & (want[:, 2] < 200)])
+        assert runs[True][4] == 1
+    finally:
+        d.close()
+
+
+def test_root_stage_comes_back_when_a_triangle_needs_it(monkeypatch, oracle):
+    """The premise of solo_roots is checked per triangle on the device: with the hint overridden (test hook) on a mesh of large
+    triangles, the first pass reports kErrSoloRoots and the call repeats it with k_expand_roots - same voxels as the oracle."""
+    from obj2voxel_amd import hip
+    v = meshes.uv_sphere(12)               # triangles tens of voxels across: subdivided
+    want = meshes.sorted_voxels(oracle.voxelize(v, 200))
+    monkeypatch.setenv("O2V_TEST_FORCE_SOLO_ROOTS", "1")
+    d = hip.DeviceVoxelizer(0)
+    try:
+        d.set_triangles(v)
+        got = meshes.sorted_voxels(d.voxelize(200))
+        assert d.timings()["passes"] >= 2
+        assert np.array_equal(got, want)
+        got = meshes.sorted_voxels(d.voxelize(200))      # remembered for this mesh and these settings: one pass, with the root stage
+        assert d.timings()["passes"] == 1 and np.array_equal(got, want)
+    finally:
+        d.close()

@@ -195,6 +195,9 @@ def test_count_roots_ahead_of_expand_roots(oracle, monkeypatch, with_large):
     res = 400
     want = meshes.sorted_voxels(oracle.voxelize(v, res))
     outs = {}
+    # (a mesh without a triangle of five voxels would skip the root stage altogether - Params::solo_roots,
+    # tests/test_gpu_exact_ab.py::test_root_stage_left_out_for_small_triangles; this test is about the stage itself)
+    monkeypatch.setenv("O2V_NO_SOLO_ROOTS", "1")
     for mode in ("default", "always", "never"):
         monkeypatch.delenv("O2V_COUNT_ROOTS", raising=False)
         monkeypatch.delenv("O2V_NO_COUNT_ROOTS", raising=False)
@@ -371,6 +374,23 @@ def test_long_hit_lists(dv, oracle, strategy):
     T = len(v)
     kw = dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=strategy)
     for res in (24, 6, 2):            # up to thousands of hits per voxel at the coarse end
+        got, want = _run_both(dv, oracle, v, res, **kw)
+        _compare(got, want)
+
+
+@pytest.mark.parametrize("strategy", [0, 1])
+def test_long_hit_lists_with_supersampling(dv, oracle, strategy):
+    """Crowded cells whose hits are spread over the eight sub-voxels of 2x supersampling: the cooperative tiers fold every
+    sub-voxel's chain on its own and combine the eight results in ascending order (downscale, voxelization.hpp:82-85) -
+    BLEND runs the sub-voxels' chains side by side on the lanes of one wavefront (blend_chain_lds).  Textured and coloured
+    triangles mixed, so the chains' colours differ per group."""
+    from obj2voxel_amd import hip
+    v, uv = meshes.uv_sphere(60, with_uv=True)          # 14160 triangles
+    T = len(v)
+    types = np.where(np.arange(T) % 3 == 0, hip.TRI_TEXTURED, hip.TRI_UNTEXTURED).astype(np.uint32)
+    kw = dict(uvs=uv, types=types, colors=meshes.triangle_colors(T), texids=np.zeros(T, np.int32),
+              textures=[(meshes.checker_texture(64, 8), 1)], strategy=strategy, supersampling=2)
+    for res in (20, 8, 3, 1):            # tens to thousands of hits per output voxel
         got, want = _run_both(dv, oracle, v, res, **kw)
         _compare(got, want)
 

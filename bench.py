@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto", "weak", "config4"])
     ap.add_argument("--resolution", type=int, default=0, help="override (debugging only; invalidates the metric)")
     ap.add_argument("--nv", type=int, default=0, help="override (debugging only; invalidates the metric)")
+    ap.add_argument("--config4-resolution", type=int, default=0, help="override of the N = 8 companion job (tests only; invalidates it)")
+    ap.add_argument("--config4-nv", type=int, default=0, help="override of the N = 8 companion job (tests only; invalidates it)")
     args = ap.parse_args()
 
     import numpy as np
@@ -290,6 +292,7 @@ def main():
     if n == 8 and name == "weak" and args.workload == "auto":
         main_run["verts"] = None
         cname, cres, cnv = workload_for(n, "config4")
+        cres, cnv = args.config4_resolution or cres, args.config4_nv or cnv
         companion = time_workload(cname, cres, cnv, max(args.steps // 2, 3), 2)
         companion["strong"] = same_job_on_one_gpu(dv, dist, rank, companion, n, barrier)
         companion["verts"] = None   # 1.8 GB of host memory

@@ -52,6 +52,12 @@ typedef struct {
     float bounds[6];           /* min xyz, max xyz */
     uint32_t z_begin, z_end;   /* this GPU's slab of output z, [z_begin, z_end); 0,0 = the whole grid */
     uint32_t flags;            /* O2V_HIP_FLAG_*; 0 = the product's defaults */
+    /* An x / y tile of the output grid, [x_begin, x_end) x [y_begin, y_end) (0, 0 = the whole axis; begin a multiple of 4): only
+     * the voxels inside are produced, as with the z slab.  One pass handles a box - the mesh's voxel bounding box within slab and
+     * tile - of at most 65 535 samples (resolution x supersampling) per axis: voxel coordinates travel in 16-bit fields relative
+     * to the box (the reference carries u32, src/util.hpp:185-196).  A wider grid is voxelized tile by tile; every output voxel
+     * belongs to exactly one tile, so the tiles' records concatenated are the whole grid's (obj2voxel_voxelize() does that). */
+    uint32_t x_begin, x_end, y_begin, y_end;
 } o2v_hip_params;
 
 /* o2v_hip_params::flags.

@@ -659,33 +659,50 @@ obj2voxel_error_t voxelize_on_device(obj2voxel_instance &inst, Session *session,
         // mechanism again (obj2voxel.cpp:226-243, voxelization.cpp:440-444) - each slab's records going to the sink before the
         // next slab starts.  The mesh bounds and the z extents of the triangle blocks (which let a slab skip the blocks it
         // cannot meet) are computed once, by the slab plan.
-        uint32_t layers = 0;
-        if (o2v_hip_max_slab_layers(session->ctx, &params, &layers) != O2V_HIP_OK) return device_error("querying device memory failed");
-        if (const char *force = std::getenv("O2V_TEST_SLAB_LAYERS")) layers = std::min<uint32_t>(layers, (uint32_t) std::atoi(force));  // test hook
-        if (layers == 0) {
-            log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "resolution " + std::to_string(params.resolution) + ": not even one 4-layer slab of the dense grid fits the device memory");
-            return OBJ2VOXEL_ERR_DEVICE;
-        }
-        if (layers < params.resolution) {
-            const uint32_t n_slabs = (params.resolution + layers - 1) / layers;
-            log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "the dense grid does not fit the device: " + std::to_string(n_slabs) + " z-slabs of " +
-                                                       std::to_string(layers) + " layers");
-            uint32_t cuts[2];
-            float bounds[6];
-            if (o2v_hip_plan_slabs(session->ctx, &params, 1, cuts, bounds) != O2V_HIP_OK) return device_error("device slab plan failed");
-            params.bounds_known = 1;
-            for (int i = 0; i < 6; ++i) params.bounds[i] = bounds[i];
-        }
-        for (uint32_t z0 = 0; z0 < params.resolution; z0 += layers) {
-            params.z_begin = layers < params.resolution ? z0 : 0;
-            params.z_end = layers < params.resolution ? std::min<uint32_t>(params.resolution, z0 + layers) : 0;
-            if (o2v_hip_voxelize(session->ctx, &params, &counts[0]) != O2V_HIP_OK) return device_error("device voxelization failed");
-            ms_device += clock.lap_ms();
-            log_pipeline();
-            const obj2voxel_error_t rc_sink = drain_to_sink();
-            if (rc_sink != OBJ2VOXEL_ERR_OK) return rc_sink;
-            ms_sink += clock.lap_ms();
-        }
+        // A pass handles a box of at most 65 535 samples per axis (voxel coordinates travel in 16-bit fields relative to it,
+        // include/o2v_hip.h), where the reference carries u32 coordinates (src/util.hpp:185-196): a finer grid is cut into x / y
+        // tiles the same way - every output voxel belongs to exactly one tile.
+        const uint32_t ss = params.supersampling ? params.supersampling : 1u;
+        const uint32_t tile = (65535u / ss) & ~3u;
+        const bool tiled = params.resolution > tile;
+        if (tiled)
+            log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "resolution " + std::to_string(params.resolution) + ": x / y tiles of " + std::to_string(tile) + " voxels");
+        for (uint32_t y0 = 0; y0 < params.resolution; y0 += tile)
+            for (uint32_t x0 = 0; x0 < params.resolution; x0 += tile) {
+                if (tiled) {
+                    params.x_begin = x0;
+                    params.x_end = std::min<uint64_t>(params.resolution, (uint64_t) x0 + tile);
+                    params.y_begin = y0;
+                    params.y_end = std::min<uint64_t>(params.resolution, (uint64_t) y0 + tile);
+                }
+                uint32_t layers = 0;
+                if (o2v_hip_max_slab_layers(session->ctx, &params, &layers) != O2V_HIP_OK) return device_error("querying device memory failed");
+                if (const char *force = std::getenv("O2V_TEST_SLAB_LAYERS")) layers = std::min<uint32_t>(layers, (uint32_t) std::atoi(force));  // test hook
+                if (layers == 0) {
+                    log_message(OBJ2VOXEL_LOG_LEVEL_ERROR, "resolution " + std::to_string(params.resolution) + ": not even one 4-layer slab of the dense grid fits the device memory");
+                    return OBJ2VOXEL_ERR_DEVICE;
+                }
+                if (layers < params.resolution && !tiled) {
+                    const uint32_t n_slabs = (params.resolution + layers - 1) / layers;
+                    log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "the dense grid does not fit the device: " + std::to_string(n_slabs) + " z-slabs of " +
+                                                               std::to_string(layers) + " layers");
+                    uint32_t cuts[2];
+                    float bounds[6];
+                    if (o2v_hip_plan_slabs(session->ctx, &params, 1, cuts, bounds) != O2V_HIP_OK) return device_error("device slab plan failed");
+                    params.bounds_known = 1;
+                    for (int i = 0; i < 6; ++i) params.bounds[i] = bounds[i];
+                }
+                for (uint32_t z0 = 0; z0 < params.resolution; z0 += layers) {
+                    params.z_begin = layers < params.resolution ? z0 : 0;
+                    params.z_end = layers < params.resolution ? std::min<uint32_t>(params.resolution, z0 + layers) : 0;
+                    if (o2v_hip_voxelize(session->ctx, &params, &counts[0]) != O2V_HIP_OK) return device_error("device voxelization failed");
+                    ms_device += clock.lap_ms();
+                    log_pipeline();
+                    const obj2voxel_error_t rc_sink = drain_to_sink();
+                    if (rc_sink != OBJ2VOXEL_ERR_OK) return rc_sink;
+                    ms_sink += clock.lap_ms();
+                }
+            }
     }
     log_message(OBJ2VOXEL_LOG_LEVEL_DEBUG, "host phases: session + upload " + std::to_string(ms_upload) + " ms, device call(s) " +
                                                std::to_string(ms_device) + " ms, read back + sink " + std::to_string(ms_sink) + " ms");

@@ -19,7 +19,7 @@ struct __attribute__((aligned(16))) Leaf {  // 96 B
     float t[6];        // uv per vertex
     uint32_t tri;      // input triangle index
     uint32_t pathkey;  // order key of this leaf among the leaves of `tri` (0 = unsplit triangle)
-    uint32_t bmin_xy;  // clamped AABB min: x | y << 16
+    uint32_t bmin_xy;  // clamped AABB min, relative to the grid's origin in sample space (Params::so): x | y << 16
     uint32_t bmin_z_dx;  // z | dx << 16
     uint32_t dy_dz;      // dy | dz << 16
     float area;          // area of the whole input triangle (voxelization.cpp:416)
@@ -159,6 +159,11 @@ struct Params {
     // beyond it (the crop encloses every triangle), the clamp only keeps a wrong crop from writing outside the allocation.
     uint32_t xo0, yo0;
     uint32_t cs_lo[3], cs_hi[3];
+    // The grid's origin in sample space, (xo0, yo0, zo0) << ss_shift.  Coordinates that travel in 16-bit fields - a leaf's box
+    // (Leaf::bmin_*), the job records of k_voxelize, the staged records of the emission kernels - are RELATIVE to it, so what
+    // is limited to 65 535 is a pass' box, not the resolution (o2v_hip_voxelize refuses a box that is wider; obj2voxel_voxelize
+    // cuts such a grid into x / y tiles).  Arithmetic on positions (the voxel planes of the clip) uses origin + relative.
+    uint32_t so[3];
     uint32_t blend;
     uint32_t cap_leaves, cap_tiles, cap_big, cap_nodes, cap_hits, cap_vox;
     uint32_t n_bricks;     // bricks of this slab
@@ -293,6 +298,24 @@ __device__ __forceinline__ uint64_t cell_index(uint32_t ox, uint32_t oy, uint32_
     brick = ((rz >> kBrickZs) * p.NBy + (ry >> kBrickYs)) * p.NBx + (rx >> kBrickXs);
     return (uint64_t) brick * kBrickCells +
            ((((rz & (kBrickZ - 1u)) << kBrickYs) + (ry & (kBrickY - 1u))) << kBrickXs) + (rx & (kBrickX - 1u));
+}
+// the same for a voxel given relative to the grid's origin (output cells; Params::so)
+__device__ __forceinline__ uint64_t cell_index_rel(uint32_t rx, uint32_t ry, uint32_t rz, const Params &p, uint32_t &brick)
+{
+    brick = ((rz >> kBrickZs) * p.NBy + (ry >> kBrickYs)) * p.NBx + (rx >> kBrickXs);
+    return (uint64_t) brick * kBrickCells +
+           ((((rz & (kBrickZ - 1u)) << kBrickYs) + (ry & (kBrickY - 1u))) << kBrickXs) + (rx & (kBrickX - 1u));
+}
+// the first voxel of a brick, relative to the grid's origin (output cells)
+__device__ __forceinline__ void brick_origin_rel(uint32_t brick, const Params &p, uint32_t &x, uint32_t &y, uint32_t &z)
+{
+    const uint32_t row = brick / p.NBx;
+    const uint32_t bx = brick - row * p.NBx;
+    const uint32_t bz = row / p.NBy;
+    const uint32_t by = row - bz * p.NBy;
+    x = bx << kBrickXs;
+    y = by << kBrickYs;
+    z = bz << kBrickZs;
 }
 // the first voxel (output grid) of a brick of a grid whose bricks are numbered x fastest
 __device__ __forceinline__ void brick_origin(uint32_t brick, const Params &p, uint32_t &x, uint32_t &y, uint32_t &z)

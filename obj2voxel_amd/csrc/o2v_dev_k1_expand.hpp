@@ -32,7 +32,7 @@ __device__ __forceinline__ LeafPlan plan_leaf(const Sub &s, const Params &p)
         lo[a] = lo[a] > glo[a] ? lo[a] : glo[a];
         hi[a] = hi[a] < ghi[a] ? hi[a] : ghi[a];
         empty |= lo[a] >= hi[a];
-        pl.lo[a] = lo[a];
+        pl.lo[a] = lo[a] - p.so[a];  // (relative to the grid's origin: lo >= cs_lo >= so)
         pl.d[a] = empty ? 0u : hi[a] - lo[a];
     }
     pl.count = empty ? 0ull : (uint64_t) pl.d[0] * pl.d[1] * pl.d[2];
@@ -57,7 +57,11 @@ __device__ __forceinline__ bool misses_slab(const Sub &s, const Params &p)
     V3 mn = tri_min(s.v0, s.v1, s.v2), mx = tri_max(s.v0, s.v1, s.v2);
     uint32_t zlo = floor_u32(mn.z), zhi = floor_u32(mx.z) + 1u;
     uint32_t xlo = floor_u32(mn.x), ylo = floor_u32(mn.y);
-    return zhi <= p.zs0 || zlo >= p.zs1 || xlo >= p.S || ylo >= p.S;
+    if (zhi <= p.zs0 || zlo >= p.zs1 || xlo >= p.S || ylo >= p.S) return true;
+    // ... or the pass' box in x / y (the grid's box, Params::cs_lo: the mesh's bounding box - which nothing misses - or an x / y
+    // tile of a grid wider than 65 535 samples)
+    const uint32_t xhi = floor_u32(mx.x) + 1u, yhi = floor_u32(mx.y) + 1u;
+    return xhi <= p.cs_lo[0] || xlo >= p.cs_hi[0] || yhi <= p.cs_lo[1] || ylo >= p.cs_hi[1];
 }
 
 __device__ __forceinline__ void write_leaf(Leaf *leaves, uint32_t idx, const Sub &s, uint32_t tri, uint32_t pathkey,
@@ -660,9 +664,8 @@ __global__ __launch_bounds__(kBlock) void k_mark_bricks(const Leaf *__restrict__
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 if (d[a] == 0u) continue;
-                // output cells [lo >> ss, (lo + d - 1) >> ss], relative to the grid's origin
-                const uint32_t org = a == 0 ? p.xo0 : (a == 1 ? p.yo0 : p.zo0);
-                const uint32_t c0 = (lo[a] >> p.ss_shift) - org, c1 = ((lo[a] + d[a] - 1u) >> p.ss_shift) - org;
+                // output cells [lo >> ss, (lo + d - 1) >> ss], relative to the grid's origin (as the leaf's box is, Params::so)
+                const uint32_t c0 = lo[a] >> p.ss_shift, c1 = (lo[a] + d[a] - 1u) >> p.ss_shift;
                 b0[a] = c0 >> sh[a];
                 nb[a] = (c1 >> sh[a]) - b0[a] + 1u;
             }

@@ -876,13 +876,15 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                 uint2 rec = make_uint2(0u, 0u);
                 if (valid) {
                     const uint32_t *lf = &s_leaf[kk * kLeafStride];
+                    // (qx, qy, qz: the voxel relative to the grid's origin - what the 16-bit fields carry; its position adds Params::so)
                     const uint32_t qx = (lf[20] & 0xffffu) + lx, qy = (lf[20] >> 16) + ly, qz = (lf[21] & 0xffffu) + lz;
+                    const float px = (float) (qx + p.so[0]), py = (float) (qy + p.so[1]), pz = (float) (qz + p.so[2]);
                     const V3 v0{__uint_as_float(lf[0]), __uint_as_float(lf[1]), __uint_as_float(lf[2])};
                     const V3 v1{__uint_as_float(lf[3]), __uint_as_float(lf[4]), __uint_as_float(lf[5])};
                     const V3 v2{__uint_as_float(lf[6]), __uint_as_float(lf[7]), __uint_as_float(lf[8])};
                     const V3 nrm{__uint_as_float(lf[9]), __uint_as_float(lf[10]), __uint_as_float(lf[11])};
                     // plane distance cull, voxelization.cpp:451-458
-                    const V3 rel = V3{(float) qx + 0.5f, (float) qy + 0.5f, (float) qz + 0.5f} - v0;
+                    const V3 rel = V3{px + 0.5f, py + 0.5f, pz + 0.5f} - v0;
                     const float sd = dot(nrm, rel);
                     keep = !(abs_f(sd) > kPlaneDistanceLimit);
                     if (OCC && keep) {
@@ -935,7 +937,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                             keep = false;
                             const uint32_t ox = qx >> p.ss_shift, oy = qy >> p.ss_shift, oz = qz >> p.ss_shift;
                             uint32_t brick;
-                            const uint64_t cell = cell_index(ox, oy, oz, p, brick);
+                            const uint64_t cell = cell_index_rel(ox, oy, oz, p, brick);
                             p.occgrid[cell] = 1;      // (plain stores; benign races: every writer stores the same value)
                             p.dirty_max[brick] = 1;
                         }
@@ -948,7 +950,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                         leaf.b = v1;
                         leaf.c = v2;
                         uint32_t cf0, out_unused, near_unused;
-                        piece_masks<false>(leaf, (float) qx, (float) qy, (float) qz, small, 0.f, 63u, cf0, out_unused, near_unused);
+                        piece_masks<false>(leaf, px, py, pz, small, 0.f, 63u, cf0, out_unused, near_unused);
                         rec = make_uint2(qx | (qy << 16), qz | (kk << 16) | (cf0 << 24) | (small ? 1u << 30 : 0u) | ((s_tcount[kk] & 0x40000000u) << 1));
                         heavy = (uint32_t) __popc(cf0) >= kHeavyPlanes;
                     }
@@ -1047,7 +1049,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                     x_first = xlo;
                     n_out = xhi - xlo + 1u;
                     if (s_tcount[k] >> 31) {
-                        const float ox = (float) (lf[20] & 0xffffu), oy = (float) (lf[20] >> 16), oz = (float) (lf[21] & 0xffffu);
+                        const float ox = (float) ((lf[20] & 0xffffu) + p.so[0]), oy = (float) ((lf[20] >> 16) + p.so[1]), oz = (float) ((lf[21] & 0xffffu) + p.so[2]);
                         const V3 p0{__uint_as_float(lf[0]) - ox, __uint_as_float(lf[1]) - oy, __uint_as_float(lf[2]) - oz};
                         const V3 p1{__uint_as_float(lf[3]) - ox, __uint_as_float(lf[4]) - oy, __uint_as_float(lf[5]) - oz};
                         const V3 p2{__uint_as_float(lf[6]) - ox, __uint_as_float(lf[7]) - oy, __uint_as_float(lf[8]) - oz};
@@ -1120,8 +1122,8 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
 #pragma unroll
                     for (uint32_t j = 0; j < kPerLane; ++j) {
                         uint32_t brick;
-                        const uint64_t cell = cell_index((rec[j].x & 0xffffu) >> p.ss_shift, (rec[j].x >> 16) >> p.ss_shift,
-                                                         (rec[j].y & 0xffffu) >> p.ss_shift, p, brick);
+                        const uint64_t cell = cell_index_rel((rec[j].x & 0xffffu) >> p.ss_shift, (rec[j].x >> 16) >> p.ss_shift,
+                                                             (rec[j].y & 0xffffu) >> p.ss_shift, p, brick);
                         seen[j] = ok[j] ? __hip_atomic_load(&p.occgrid[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t) 1;
                     }
 #pragma unroll
@@ -1196,7 +1198,7 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                     if (d_valid) {
                         const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
                         uint32_t brick;
-                        const uint64_t cell = cell_index(d_px >> p.ss_shift, d_py >> p.ss_shift, d_pz >> p.ss_shift, p, brick);
+                        const uint64_t cell = cell_index_rel(d_px >> p.ss_shift, d_py >> p.ss_shift, d_pz >> p.ss_shift, p, brick);
                         p.occgrid[cell] = 1;
                         p.dirty_max[brick] = 1;
                     }
@@ -1221,7 +1223,8 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                 if (d_valid) {
                     const uint32_t d_px = d_xy & 0xffffu, d_py = d_xy >> 16, d_pz = d_zk & 0xffffu;
                     const uint32_t ox = d_px >> p.ss_shift, oy = d_py >> p.ss_shift, oz = d_pz >> p.ss_shift;
-                    cell = cell_index(ox, oy, oz, p, brick);
+                    cell = cell_index_rel(ox, oy, oz, p, brick);
+                    // (the origin is a whole number of output voxels: the relative coordinates have the absolute ones' parity)
                     const uint32_t sub = p.ss_shift ? ((d_px & 1u) | ((d_py & 1u) << 1) | ((d_pz & 1u) << 2)) : 0u;
                     keyhi = (sub << 29) | lf[18];
                     if (!direct) {
@@ -1321,9 +1324,9 @@ __device__ __forceinline__ void voxelize_body(const Leaf *__restrict__ leaves, c
                         const uint32_t *lf = &s_leaf[__umul24(my_k, kLeafStride)];
                         pos_xy = rec.x;
                         pos_zk = rec.y & 0x00ffffffu;  // z | tile slot << 16
-                        fx = (float) (rec.x & 0xffffu);
-                        fy = (float) (rec.x >> 16);
-                        fz = (float) (rec.y & 0xffffu);
+                        fx = (float) ((rec.x & 0xffffu) + p.so[0]);
+                        fy = (float) ((rec.x >> 16) + p.so[1]);
+                        fz = (float) ((rec.y & 0xffffu) + p.so[2]);
                         cf = (rec.y >> 24) & 63u;
                         small = (rec.y >> 30) & 1u;
                         lean = (rec.y >> 31) != 0u;

@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
         __syncthreads();
         const uint32_t base = s_base;
         for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-            if (base + i < p.cap_vox) out[base + i] = make_uint4(s_rec[i].x & 0xffffu, s_rec[i].x >> 16, s_rec[i].y, s_argb[i]);
+            if (base + i < p.cap_vox) out[base + i] = make_uint4((s_rec[i].x & 0xffffu) + p.xo0, (s_rec[i].x >> 16) + p.yo0, s_rec[i].y + p.zo0, s_argb[i]);
         __syncthreads();
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
             const unsigned long long v4[4] = {lo[k].x, lo[k].y, hi[k].x, hi[k].y};
             if (v4[0] | v4[1] | v4[2] | v4[3]) {
                 uint32_t x0, y0, z0;
-                brick_origin(brick[k], p, x0, y0, z0);
+                brick_origin_rel(brick[k], p, x0, y0, z0);   // (staged relative to the grid's origin, which the flush adds)
 #pragma unroll
                 for (uint32_t e = 0; e < 4; ++e) {
                     if (v4[e]) {
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_max(const uint32_t *__restrict_
                         }
                         const uint32_t slot = atomicAdd(&s_n, 1u);
                         s_rec[slot] = make_uint2((x0 + (local & (kBrickX - 1u))) | ((y0 + ((local >> kBrickXs) & (kBrickY - 1u))) << 16),
-                                                 z0 + (local >> (kBrickXs + kBrickYs)));  // (output coordinates are below 2^16)
+                                                 z0 + (local >> (kBrickXs + kBrickYs)));  // (a pass' box is at most 65 535 cells wide)
                         s_argb[slot] = argb;
                     }
                 }
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
         __syncthreads();
         const uint32_t base = s_base;
         for (uint32_t i = threadIdx.x; i < n; i += kBlock)
-            if (base + i < p.cap_vox) out[base + i] = make_uint4(s_rec[i].x & 0xffffu, s_rec[i].x >> 16, s_rec[i].y, white);
+            if (base + i < p.cap_vox) out[base + i] = make_uint4((s_rec[i].x & 0xffffu) + p.xo0, (s_rec[i].x >> 16) + p.yo0, s_rec[i].y + p.zo0, white);
         __syncthreads();
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
             // (wavefront-uniform loop over the four cells of a lane: the staging slots are reserved with one LDS atomic per
             // wavefront and cell position, not one per voxel)
             uint32_t x0, y0, z0;
-            brick_origin(brick[k] == 0xffffffffu ? 0u : brick[k], p, x0, y0, z0);
+            brick_origin_rel(brick[k] == 0xffffffffu ? 0u : brick[k], p, x0, y0, z0);   // (relative to the grid's origin, which the flush adds)
 #pragma unroll
             for (uint32_t e = 0; e < 4; ++e) {
                 const bool set = ((cells4[k] >> (8u * e)) & 0xffu) != 0u;
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_occ(const uint32_t *__restrict_
                         const uint32_t local = (lane % kLanesPerBrick) * 4u + e;
                         const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
                         s_rec[slot] = make_uint2((x0 + (local & (kBrickX - 1u))) | ((y0 + ((local >> kBrickXs) & (kBrickY - 1u))) << 16),
-                                                 z0 + (local >> (kBrickXs + kBrickYs)));  // (output coordinates are below 2^16)
+                                                 z0 + (local >> (kBrickXs + kBrickYs)));  // (a pass' box is at most 65 535 cells wide)
                     }
                 }
             }

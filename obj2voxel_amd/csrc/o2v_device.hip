@@ -362,6 +362,16 @@ GridBox grid_box(const o2v_hip_ctx *ctx, const o2v_hip_params *params, uint32_t 
 {
     const uint32_t G = params->resolution, S = G * ss;
     GridBox b{{0u, 0u, z0}, {G, G, z1}, false};
+    // (an x / y tile of the grid, o2v_hip_params::x_begin; 0, 0: the whole axis)
+    if (params->x_begin || params->x_end) {
+        b.lo[0] = params->x_begin;
+        b.hi[0] = std::min(params->x_end, G);
+    }
+    if (params->y_begin || params->y_end) {
+        b.lo[1] = params->y_begin;
+        b.hi[1] = std::min(params->y_end, G);
+    }
+    if (b.lo[0] >= b.hi[0] || b.lo[1] >= b.hi[1]) b.empty = true;
     const char *off = std::getenv("O2V_NO_CROP");
     if ((off && off[0] == '1') || ctx->max_tri_extent < 0.f || ctx->n_tris == 0) return b;
     const float *h = ctx->mesh_bounds_hint;
@@ -406,8 +416,8 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     if (!p.bounds_known) {
         // one workgroup per CU: every workgroup ends with six atomics on the same six words, which serialise (1024
         // workgroups: 43 us for 31 MB, 256: 24 us)
-        O2V_LAUNCH("k_bounds", s, k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (p.n_tris * 9 / 12 + kBlock) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
+        O2V_LAUNCH("k_bounds", s, k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (p.n_tris * 9 / 12 + kBoundsBlock) / kBoundsBlock)),
+                           dim3(kBoundsBlock), 0, s, ctx->d_verts, p.n_tris * 9, ctx->d_ctr);
     }
     // (letting the last workgroup of k_bounds compute the transform - one launch less - was measured: the stage 0.021 -> 0.027 ms)
     O2V_LAUNCH("k_setup", s, k_setup, dim3(1), dim3(64), 0, s, ctx->d_ctr, p);
@@ -586,7 +596,8 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         }
         // (tier 1 on the inline cells runs as fast with two workgroups per CU as with eight - it is not bound by the wavefronts in
         // flight - and leaves the counting sort and the cooperative tiers beside it room: bench mesh with BLEND -0.1 ms)
-        const uint32_t resolve_wgs = (uint32_t) ctx->num_cus * 2u;
+        uint32_t resolve_wgs = (uint32_t) ctx->num_cus * 2u;
+        if (const char *e = std::getenv("O2V_RESOLVE_WGS_PER_CU"); e && std::atoi(e) > 0) resolve_wgs = (uint32_t) ctx->num_cus * (uint32_t) std::atoi(e);
         if (use_uv)
             O2V_LAUNCH("k_resolve<6>", s, k_resolve<6>, dim3(resolve_wgs), dim3(kBlock), 0, s, ctx->d_occ, sorted_view, slab_view, ctx->d_ctr, m,
                                ctx->d_out, 0u, p);
@@ -734,8 +745,8 @@ int ctx_finish_triangles(o2v_hip_ctx *ctx, bool any_textured, const TriHints *hi
     else if (count) {
         ctx->ctr_clean = false;
         hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr, (uint32_t) (sizeof(Counters) / 4));
-        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (count * 9 / 12 + kBlock) / kBlock)),
-                           dim3(kBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
+        hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (count * 9 / 12 + kBoundsBlock) / kBoundsBlock)),
+                           dim3(kBoundsBlock), 0, s, ctx->d_verts, count * 9, ctx->d_ctr);
         hipLaunchKernelGGL(k_tri_extent, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus * 4u, (count + kBlock - 1) / kBlock)),
                            dim3(kBlock), 0, s, ctx->d_verts, count, &ctx->d_ctr->pad2, ctx->d_ctr->ext_hist);
         O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
@@ -1069,8 +1080,8 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         return O2V_HIP_ERR_BAD_ARGUMENT;
     }
     const uint64_t S64 = (uint64_t) params->resolution * ss;
-    if (S64 > 65535u) {
-        ctx->err = "sample resolution must be below 65536";
+    if (S64 > 0x7fffffffull) {
+        ctx->err = "sample resolution must be below 2^31";
         return O2V_HIP_ERR_LIMIT;
     }
     uint32_t z0 = params->z_begin, z1 = params->z_end;
@@ -1078,6 +1089,15 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     if (z1 > params->resolution || z0 >= z1) {
         ctx->err = "z slab must satisfy z_begin < z_end <= resolution";
         return O2V_HIP_ERR_BAD_ARGUMENT;
+    }
+    // an x / y tile of the grid (0, 0: the whole axis), see o2v_hip_params::x_begin
+    uint32_t xy0[2] = {params->x_begin, params->y_begin}, xy1[2] = {params->x_end, params->y_end};
+    for (int k = 0; k < 2; ++k) {
+        if (xy0[k] == 0 && xy1[k] == 0) xy1[k] = params->resolution;
+        if (xy1[k] > params->resolution || xy0[k] >= xy1[k] || (xy0[k] & (kBrickX - 1u))) {
+            ctx->err = "x / y tile must satisfy begin < end <= resolution, begin a multiple of 4";
+            return O2V_HIP_ERR_BAD_ARGUMENT;
+        }
     }
     O2V_CHECK(hipSetDevice(ctx->device));
     ctx->n_vox = 0;
@@ -1090,8 +1110,16 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     p.S = (uint32_t) S64;
     p.G = params->resolution;
     // the dense grids cover the mesh's voxel bounding box within the slab (grid_box)
-    const GridBox box = grid_box(ctx, params, ss, z0, z1);
+    const GridBox box = grid_box(ctx, params, ss, z0, z1);   // (within the x / y tile, if the call names one)
     if (box.empty) return O2V_HIP_OK;  // the mesh does not reach this slab: no voxels
+    // Voxel coordinates travel in 16-bit fields relative to the grid's origin (Params::so): what is limited is the box of one
+    // pass, not the resolution.  (The reference carries u32 coordinates and 64-bit Morton keys, src/util.hpp:185-196; a box wider
+    // than this is cut into x / y tiles by the caller - obj2voxel_voxelize() does - as a slab too thick for memory is cut in z.)
+    for (int k = 0; k < 3; ++k)
+        if ((uint64_t) (box.hi[k] - box.lo[k]) * ss > 65535u) {
+            ctx->err = "the pass' box (the mesh's voxel bounding box within the slab / tile) must be at most 65535 samples wide; use x / y tiles (o2v_hip_params::x_begin ..) or z-slabs";
+            return O2V_HIP_ERR_LIMIT;
+        }
     p.xo0 = box.lo[0];
     p.yo0 = box.lo[1];
     p.NBx = (box.hi[0] - box.lo[0] + kBrickX - 1) / kBrickX;
@@ -1115,6 +1143,9 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
     }
     p.cs_lo[2] = std::max(p.cs_lo[2], p.zs0);
     p.cs_hi[2] = std::min(p.cs_hi[2], p.zs1);
+    p.so[0] = p.xo0 * ss;
+    p.so[1] = p.yo0 * ss;
+    p.so[2] = p.zo0 * ss;
     p.blend = params->strategy;
     p.bounds_known = params->bounds_known;
     for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
@@ -1602,8 +1633,8 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
     if (!bounds_reduced) hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s, ctx->d_ctr, kPassCounterWords);
     if (!p.bounds_known && !bounds_reduced) {
         if (n_range)
-            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_range * 9 / 12 + kBlock) / kBlock)),
-                               dim3(kBlock), 0, s, ctx->d_verts + tri_begin * 9, n_range * 9, ctx->d_ctr);
+            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_range * 9 / 12 + kBoundsBlock) / kBoundsBlock)),
+                               dim3(kBoundsBlock), 0, s, ctx->d_verts + tri_begin * 9, n_range * 9, ctx->d_ctr);
         O2V_STAGE("k_bounds");
         if (comm) {
             int rc = timed(1, [&]() -> int {
@@ -1805,17 +1836,25 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
         ctx->ctr_clean = false;
         hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, s0, ctx->d_ctr, kPassCounterWords);
         if (!params->bounds_known && !rc_prepare && n_share)
-            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_share * 9 / 12 + kBlock) / kBlock)),
-                               dim3(kBlock), 0, s0, ctx->d_verts + share_begin * 9, n_share * 9, ctx->d_ctr);
+            hipLaunchKernelGGL(k_bounds, dim3((uint32_t) std::min<uint64_t>((uint64_t) ctx->num_cus, (n_share * 9 / 12 + kBoundsBlock) / kBoundsBlock)),
+                               dim3(kBoundsBlock), 0, s0, ctx->d_verts + share_begin * 9, n_share * 9, ctx->d_ctr);
         hipLaunchKernelGGL(k_pack_ready, dim3(1), dim3(64), 0, s0, ctx->d_ctr, ctx->d_status, rc_prepare ? 1u : 0u);
-        const bool time_it = measure_collectives && ctx->ev_coll[0] && ctx->ev_coll[1];
-        if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[0], s0));
+        // (no local HIP error may keep this rank out of the collective: its peers would wait for the time limit instead of seeing
+        // the error in the status word - a timing event that cannot be recorded only switches the timing off)
+        bool time_it = measure_collectives && ctx->ev_coll[0] && ctx->ev_coll[1];
+        if (time_it && hipEventRecord(ctx->ev_coll[0], s0) != hipSuccess) {
+            (void) hipGetLastError();
+            time_it = false;
+        }
         const std::string prepare_err = ctx->err;
         if (comm->allreduce_max_u32(ctx->d_status, 7, s0)) {
             ctx->err = std::string("collective failed: ") + comm->err;
             return O2V_HIP_ERR_HIP;
         }
-        if (time_it) O2V_CHECK(hipEventRecord(ctx->ev_coll[1], s0));
+        if (time_it && hipEventRecord(ctx->ev_coll[1], s0) != hipSuccess) {
+            (void) hipGetLastError();
+            time_it = false;
+        }
         hipLaunchKernelGGL(k_unpack_ready, dim3(1), dim3(64), 0, s0, ctx->d_status, ctx->d_ctr);
         O2V_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, s0));
         // (the first collective of the run: if a rank of the job never gets here - it died, or the node is set up wrongly - the

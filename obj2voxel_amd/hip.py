@@ -12,7 +12,8 @@ STRATEGY_MAX, STRATEGY_BLEND = 0, 1
 class _Params(C.Structure):
     _fields_ = [("resolution", C.c_uint32), ("supersampling", C.c_uint32), ("strategy", C.c_uint32),
                 ("unit_transform", C.c_int32 * 9), ("bounds_known", C.c_uint32), ("bounds", C.c_float * 6),
-                ("z_begin", C.c_uint32), ("z_end", C.c_uint32), ("flags", C.c_uint32)]
+                ("z_begin", C.c_uint32), ("z_end", C.c_uint32), ("flags", C.c_uint32),
+                ("x_begin", C.c_uint32), ("x_end", C.c_uint32), ("y_begin", C.c_uint32), ("y_end", C.c_uint32)]
 
 
 FLAG_KERNEL_TIMES = 2  # ... every launch bracketed by events: DeviceVoxelizer.kernel_times()
@@ -206,8 +207,10 @@ class DeviceVoxelizer:
                     "o2v_hip_set_textures")
 
     @staticmethod
-    def _params(resolution, supersampling, strategy, unit_transform, bounds, zslab, flags=0):
+    def _params(resolution, supersampling, strategy, unit_transform, bounds, zslab, flags=0, xtile=(0, 0), ytile=(0, 0)):
         p = _Params()
+        p.x_begin, p.x_end = xtile
+        p.y_begin, p.y_end = ytile
         p.flags = flags
         p.resolution, p.supersampling, p.strategy = resolution, supersampling, strategy
         ut = (1, 0, 0, 0, 1, 0, 0, 0, 1) if unit_transform is None else tuple(int(x) for x in np.ravel(unit_transform))
@@ -228,9 +231,12 @@ class DeviceVoxelizer:
         return [int(z) for z in cuts], bnd
 
     def voxelize(self, resolution, *, supersampling=1, strategy=STRATEGY_MAX, unit_transform=None, bounds=None,
-                 zslab=(0, 0), read=True, exact_clip=False, kernel_times=False, stage_times=False):
+                 zslab=(0, 0), read=True, exact_clip=False, kernel_times=False, stage_times=False, xtile=(0, 0), ytile=(0, 0)):
+        """xtile / ytile: an x / y range of the output grid (o2v_hip_params::x_begin ..; begin a multiple of 4), like zslab."""
         flags = (FLAG_EXACT_CLIP if exact_clip else 0) | (FLAG_KERNEL_TIMES if kernel_times else 0) | (FLAG_STAGE_TIMES if stage_times else 0)
-        if unit_transform is None and bounds is None:
+        if tuple(xtile) != (0, 0) or tuple(ytile) != (0, 0):
+            p = self._params(resolution, supersampling, strategy, unit_transform, bounds, zslab, flags, tuple(xtile), tuple(ytile))
+        elif unit_transform is None and bounds is None:
             # (a loop of identical calls - bench.py's timed steps - does not build the parameter block again every time)
             key = (resolution, supersampling, strategy, zslab, flags)
             if getattr(self, "_plain_key", None) != key:

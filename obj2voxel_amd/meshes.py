@@ -131,6 +131,27 @@ def box_room(n=8):
     return np.asarray(tris, dtype=np.float32).reshape(-1, 9)
 
 
+def diagonal_strip(n=400, width=6e-5, thickness=4e-5):
+    """A thin ribbon along the diagonal of the unit square in the z ~ 0 plane, slightly wavy in z (so that its triangles are not
+    axis-aligned): 2 n triangles whose bounds are (0, 0, 0) .. (1, 1, thickness).  At a resolution of 100 000 it crosses every x
+    and y of the grid while the mesh's box stays a few layers thick - the shape the x / y tile tests use."""
+    t = np.linspace(0.0, 1.0, n + 1, dtype=np.float64)
+    # centre line x = y = t (inside the unit square by the ribbon's half width), z waving between 0 and thickness
+    half = 0.5 * width
+    cx = half + t * (1.0 - width)
+    z = 0.5 * thickness * (1.0 + np.sin(np.arange(n + 1) * 1.7))
+    a = np.stack([cx - half, cx + half, z], axis=1)          # one edge of the ribbon
+    b = np.stack([cx + half, cx - half, thickness - z], axis=1)   # the other
+    tris = []
+    for i in range(n):
+        tris.append(np.concatenate([a[i], b[i], a[i + 1]]))
+        tris.append(np.concatenate([b[i], b[i + 1], a[i + 1]]))
+    v = np.asarray(tris, dtype=np.float32)
+    # (the bounds are exactly the unit square: the first / last vertices touch 0 and 1)
+    v[0, 0] = 0.0; v[0, 4] = 0.0
+    return np.ascontiguousarray(v)
+
+
 def random_soup(T, seed=0, scale=0.2):
     """Random small triangles in the unit cube plus a few large diagonal ones (subdivision-heavy)."""
     rng = np.random.default_rng(seed)

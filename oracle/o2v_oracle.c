@@ -694,6 +694,72 @@ static void voxelize_chunk(voxelizer *vz, outvec *ov, const cached_tri *tris, co
 static voxelizer *g_vz_cache[O2V_MAX_THREADS];
 static outvec g_out_cache[O2V_MAX_THREADS];
 
+/* sortTriangleIntoChunks + the chunk loop (obj2voxel.cpp:226-243,254-314,503-505) for grids too fine for dense per-chunk
+ * tables: every (chunk, triangle) pair is listed, the list sorted by chunk and triangle - ascending triangle order inside a
+ * chunk, as the reference's serial loop leaves it (obj2voxel.cpp:489-491) - and the chunks voxelized one after the other by
+ * the calling thread.  Test infrastructure for the resolutions above 65 535 only. */
+typedef struct { uint64_t chunk; uint32_t tri; } o2v_bin_pair;
+static int o2v_bin_pair_cmp(const void *a, const void *b)
+{
+    const o2v_bin_pair *p = (const o2v_bin_pair *) a, *q = (const o2v_bin_pair *) b;
+    if (p->chunk != q->chunk) return p->chunk < q->chunk ? -1 : 1;
+    return p->tri < q->tri ? -1 : (p->tri > q->tri ? 1 : 0);
+}
+static int64_t o2v_voxelize_sparse_bins(const cached_tri *tris, uint64_t T, uint32_t chunks_per_axis, uint32_t strategy,
+                                        uint32_t supersampling, const o2v_oracle_texture *textures, uint32_t zlo, uint32_t zhi, outvec *ov)
+{
+    size_t n_pairs = 0, cap = 1024;
+    o2v_bin_pair *pairs = (o2v_bin_pair *) malloc(cap * sizeof(o2v_bin_pair));
+    for (uint64_t i = 0; i < T; ++i) {
+        const cached_tri *t = &tris[i];
+        for (uint32_t z = t->chunk_min[2]; z <= t->chunk_max[2] && z < chunks_per_axis; ++z)
+            for (uint32_t y = t->chunk_min[1]; y <= t->chunk_max[1] && y < chunks_per_axis; ++y)
+                for (uint32_t x = t->chunk_min[0]; x <= t->chunk_max[0] && x < chunks_per_axis; ++x) {
+                    if (n_pairs == cap) {
+                        cap *= 2;
+                        pairs = (o2v_bin_pair *) realloc(pairs, cap * sizeof(o2v_bin_pair));
+                    }
+                    pairs[n_pairs].chunk = ((uint64_t) z * chunks_per_axis + y) * chunks_per_axis + x;
+                    pairs[n_pairs].tri = (uint32_t) i;
+                    ++n_pairs;
+                }
+    }
+    qsort(pairs, n_pairs, sizeof(o2v_bin_pair), o2v_bin_pair_cmp);
+    uint32_t *items = (uint32_t *) malloc(sizeof(uint32_t) * (n_pairs ? n_pairs : 1));
+    for (size_t k = 0; k < n_pairs; ++k) items[k] = pairs[k].tri;
+    if (!g_vz_cache[0]) g_vz_cache[0] = voxelizer_new();
+    voxelizer *vz = g_vz_cache[0];
+    outvec lov = g_out_cache[0];
+    lov.n = 0;
+    memset(&t_stats, 0, sizeof(t_stats));
+    for (size_t k0 = 0; k0 < n_pairs;) {
+        size_t k1 = k0;
+        while (k1 < n_pairs && pairs[k1].chunk == pairs[k0].chunk) ++k1;
+        const uint64_t c = pairs[k0].chunk;
+        const uint32_t cx = (uint32_t) (c % chunks_per_axis), cy = (uint32_t) ((c / chunks_per_axis) % chunks_per_axis),
+                       cz = (uint32_t) (c / ((uint64_t) chunks_per_axis * chunks_per_axis));
+        int skip = 0;
+        if (zlo != zhi) {
+            const uint32_t oz0 = cz * O2V_CHUNK / supersampling, oz1 = (cz * O2V_CHUNK + O2V_CHUNK - 1u) / supersampling;
+            skip = oz1 < zlo || oz0 >= zhi;
+        }
+        if (!skip) voxelize_chunk(vz, &lov, tris, items, k0, k1, cx, cy, cz, strategy, supersampling, textures, zlo, zhi);
+        k0 = k1;
+    }
+    g_out_cache[0] = lov;
+    {
+        uint64_t *dst = (uint64_t *) &g_stats;
+        const uint64_t *src = (const uint64_t *) &t_stats;
+        for (size_t k = 0; k < sizeof(g_stats) / sizeof(uint64_t); ++k) dst[k] += src[k];
+    }
+    ov->d = (uint32_t *) malloc(sizeof(uint32_t) * 4 * (lov.n ? lov.n : 1));
+    ov->n = ov->cap = lov.n;
+    if (lov.n) memcpy(ov->d, lov.d, sizeof(uint32_t) * 4 * lov.n);
+    free(items);
+    free(pairs);
+    return (int64_t) ov->n;
+}
+
 /*
  * The whole path: cache -> bounds -> transform -> chunk binning -> per chunk voxelize (+downscale) -> pack.
  * obj2voxel.cpp:467-520 (voxelize_specialized<false>), :180-314.
@@ -811,6 +877,15 @@ int64_t o2v_oracle_voxelize(const float *verts, const float *uvs, const uint32_t
      * range) gives each range its place in each chunk's list, and the ranges fill their places - ascending triangle order
      * inside a chunk follows from the order of the ranges, as in the reference's serial loop (obj2voxel.cpp:489-491). */
     const size_t nchunks = (size_t) chunks_per_axis * chunks_per_axis * chunks_per_axis;
+    /* A grid of more than 2^27 chunks (resolutions beyond ~32 000) gets no dense per-chunk tables: the (chunk, triangle) pairs are
+     * listed and sorted instead - the same lists in the same ascending triangle order (o2v_sparse_bins below). */
+    const char *force_sparse = getenv("O2V_ORACLE_SPARSE_BINS"); /* (tests: the sparse path on a grid the dense path handles too) */
+    if (nchunks > ((size_t) 1 << 27) || (force_sparse && force_sparse[0] == '1')) {
+        const int64_t n = o2v_voxelize_sparse_bins(tris, T, chunks_per_axis, strategy, supersampling, textures, zlo, zhi, &ov);
+        free(tris);
+        *out = ov.d;
+        return n;
+    }
     uint64_t *chunk_start = (uint64_t *) calloc(nchunks + 1, sizeof(uint64_t));
     {
         int n_ranges = aux_threads;

@@ -154,3 +154,24 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path):
     assert line["scaling"] == "weak" and col["rccl_world_size"] is None
     ss = line["strong_scaling_same_job"]
     assert ss["voxels_match"] is True and ss["one_gpu_ms"] > 0 and ss["n_gpu_ms"] > 0 and abs(ss["speedup"] - ss["one_gpu_ms"] / ss["n_gpu_ms"]) < 0.01
+
+
+def test_bench_eight_ranks_on_one_gpu_prints_a_compact_line_with_both_curves(tmp_path):
+    """The first real 8-GPU run must not be lost to the line: eight processes (torch.distributed launch, gloo, all on GPU 0, the
+    jobs scaled down by the test-only overrides) go through everything `bench.py --gpus 8` does - the weak-scaling job, its
+    same-job strong scaling, the upload comparison and the configs[4] companion job with its own strong scaling - and rank 0's
+    LAST stdout line is the compact object: n_gpus 8, both curves, config4, under 4 KB; nobody else prints to stdout."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--same-device", "--resolution", "256", "--nv", "120", "--config4-resolution", "384", "--config4-nv", "200"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, O2V_BENCH_DETAILS=str(tmp_path / "details.json")))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _stdout_line(r)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["parallelism"] == "zslab8" and line["value"] > 0
+    assert line["config"]["collectives"]["world"] == 8 and "rccl_world_size" in line["config"]["collectives"]
+    ss = line["strong_scaling_same_job"]
+    assert ss["voxels_match"] is True and ss["speedup"] > 0
+    c4 = line["config4"]
+    assert c4["value"] > 0 and c4["voxels"] > 0 and c4["strong_scaling_same_job"]["voxels_match"] is True
+    det = json.load(open(tmp_path / "details.json"))
+    assert det["config4"]["answers"] and det["config"]["upload"]["h2d_per_rank_ms"] > 0

@@ -139,32 +139,52 @@ def test_log_callback_receives_messages():
     assert any(level == capi.LOG_DEBUG for level, _ in seen)
 
 
-@pytest.mark.parametrize("res,ss", [(65536, 1), (40000, 2)])
-def test_sample_resolution_above_65535_is_refused_with_a_logged_reason(res, ss):
-    """The reference takes any uint32 resolution (include/obj2voxel.h:130-138; its VoxelMap is sparse); the dense-grid path
-    refuses resolution x supersampling > 65 535 with OBJ2VOXEL_ERR_DEVICE (8, declared in include/obj2voxel.h as an extension)
-    and says why at ERROR level."""
+@pytest.mark.parametrize("res,ss,textured", [(100_000, 1, False), (40_000, 2, True)])
+def test_sample_resolution_above_65535_in_xy_tiles(oracle, res, ss, textured):
+    """The reference takes any uint32 resolution (include/obj2voxel.h:130-138: u32 coordinates, 64-bit Morton keys,
+    src/util.hpp:185-196).  Here voxel coordinates travel in 16-bit fields relative to a pass' box, so obj2voxel_voxelize() cuts a
+    grid of more than 65 535 samples per axis into x / y tiles (as it cuts one too thick for the memory into z-slabs).  A thin
+    ribbon along the diagonal of the z ~ 0 plane - it crosses every x and y, the mesh's box is a few layers thick - at a
+    sample resolution of 100 000 (2 x 2 tiles, occupancy only) and of 2 x 40 000 with a texture and BLEND (the weighted route,
+    supersampled): every record equals the oracle's."""
     from obj2voxel_amd import capi
     a = capi.api()
-    seen = []
-    cb = capi.LOG_CB(lambda _d, msg, level: (seen.append((level, msg.decode())), True)[1])
-    a.obj2voxel_set_log_callback.argtypes = [capi.LOG_CB, C.c_void_p]
-    a.obj2voxel_set_log_callback(cb, None)
     a.obj2voxel_set_log_level(capi.LOG_ERROR)
+    v = meshes.diagonal_strip(400, width=6e-5)
+    T = len(v)
+    uv = np.ascontiguousarray((v.reshape(T, 3, 3)[:, :, :2] * 37.0).reshape(T, 6), dtype=np.float32)
+    pix = meshes.checker_texture(64, 8)
+    tex = None
     try:
-        inst, inp = _instance(a, meshes.unit_cube())
-        out = capi.CountingOutput()
+        inst = a.obj2voxel_alloc()
+        if textured:
+            tex = a.obj2voxel_texture_alloc()
+            assert a.obj2voxel_texture_load_pixels(tex, pix.ctypes.data, 64, 64, 3)
+            inp = capi.TriangleInput(v, uvs=uv, texture=tex)
+        else:
+            inp = capi.TriangleInput(v)
+        out = capi.CollectingOutput()
+        a.obj2voxel_set_input_callback(inst, inp.callback, None)
         a.obj2voxel_set_output_callback(inst, out.callback, None)
         a.obj2voxel_set_resolution(inst, res)
         a.obj2voxel_set_supersampling(inst, ss)
-        assert a.obj2voxel_voxelize(inst) == capi.ERR_DEVICE == 8
+        a.obj2voxel_set_color_strategy(inst, capi.BLEND_STRATEGY if textured else capi.MAX_STRATEGY)
+        assert a.obj2voxel_voxelize(inst) == capi.ERR_OK
         a.obj2voxel_free(inst)
     finally:
-        a.obj2voxel_set_log_callback.argtypes = [C.c_void_p, C.c_void_p]
-        a.obj2voxel_set_log_callback(None, None)
+        if tex:
+            a.obj2voxel_texture_free(tex)
         a.obj2voxel_set_log_level(capi.LOG_INFO)
-    assert out.voxel_count == 0
-    assert any(level == capi.LOG_ERROR and "65536" in m for level, m in seen), seen
+        # (a 50 GB grid: give it back before the next test)
+        C.CDLL(__import__("obj2voxel_amd").LIB_PATH).o2v_release_cached_device_memory()
+    kw = dict(uvs=uv, types=np.full(T, 3, np.uint32), texids=np.zeros(T, np.int32), textures=[(pix, 1)], strategy=1) if textured else {}
+    want = oracle.voxelize(v, res, supersampling=ss, **kw)
+    got = out.voxels()
+    assert len(got) == len(want) > 50_000
+    assert int(got[:, 0].max()) > 0.99 * res and int(got[:, 1].max()) > 0.99 * res     # (beyond the first tile)
+    assert np.array_equal(meshes.sorted_voxels(got), meshes.sorted_voxels(want))
+    if textured:
+        assert len(np.unique(got[:, 3])) > 2
 
 
 @pytest.mark.parametrize("mode", [0, 1])

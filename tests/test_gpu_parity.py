@@ -594,3 +594,41 @@ def test_hit_slabs_are_a_budget_not_a_requirement(oracle, monkeypatch, mode, str
         _compare(got, oracle.voxelize(v, 160, strategy=strategy, supersampling=2, textures=tex, **kw))
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("route", ["occupancy", "coloured_max", "blend_ss2", "textured_blend"])
+def test_xy_tiles_partition_the_grid(dv, oracle, route):
+    """o2v_hip_params::x_begin .. y_end: an x / y tile of the output grid, like the z slab - triangles that miss it are dropped,
+    leaves are clamped to it, the 16-bit coordinate fields are relative to its box.  Every output voxel belongs to exactly one
+    tile: the records of 3 x 2 tiles (and a z slab inside one) concatenated equal the whole grid's and the oracle's, on every
+    route.  Large and small triangles mixed, so that subdivided leaves straddle the tile borders."""
+    from obj2voxel_amd import hip
+    v, uv = meshes.uv_sphere(40, with_uv=True)
+    big, buv = meshes.uv_sphere(5, radius=0.7, center=(0.1, -0.1, 0.05), with_uv=True)
+    v, uv = np.concatenate([v, big]).astype(np.float32), np.concatenate([uv, buv]).astype(np.float32)
+    T = len(v)
+    res = 200
+    kw = {"occupancy": dict(),
+          "coloured_max": dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=0),
+          "blend_ss2": dict(types=np.full(T, hip.TRI_UNTEXTURED, np.uint32), colors=meshes.triangle_colors(T), strategy=1, supersampling=2),
+          "textured_blend": dict(uvs=uv, types=np.full(T, hip.TRI_TEXTURED, np.uint32), texids=np.zeros(T, np.int32),
+                                 textures=[(meshes.checker_texture(64, 8), 1)], strategy=1)}[route]
+    got, want = _run_both(dv, oracle, v, res, **kw)
+    _compare(got, want)
+    want = meshes.sorted_voxels(want)
+    run = dict(supersampling=kw.get("supersampling", 1), strategy=kw.get("strategy", 0))
+    parts = []
+    xcuts, ycuts = (0, 64, 132, 200), (0, 100, 200)
+    for iy in range(2):
+        for ix in range(3):
+            xt, yt = (xcuts[ix], xcuts[ix + 1]), (ycuts[iy], ycuts[iy + 1])
+            part = dv.voxelize(res, xtile=xt, ytile=yt, **run)
+            assert len(part) == 0 or (part[:, 0].min() >= xt[0] and part[:, 0].max() < xt[1] and part[:, 1].min() >= yt[0] and part[:, 1].max() < yt[1])
+            parts.append(part)
+    assert np.array_equal(meshes.sorted_voxels(np.concatenate(parts)), want)
+    # a z slab inside a tile
+    part = meshes.sorted_voxels(dv.voxelize(res, xtile=(64, 132), ytile=(100, 200), zslab=(50, 120), **run))
+    m = (want[:, 0] >= 64) & (want[:, 0] < 132) & (want[:, 1] >= 100) & (want[:, 2] >= 50) & (want[:, 2] < 120)
+    assert np.array_equal(part, want[m])
+    with pytest.raises(hip.DeviceError):
+        dv.voxelize(res, xtile=(2, 100))      # a tile begins at a multiple of 4

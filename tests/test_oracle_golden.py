@@ -104,3 +104,26 @@ def test_per_thread_state_survives_between_calls(oracle):
         assert np.array_equal(run_a(2), want)
     finally:
         oracle.set_threads(1)
+
+
+def test_sparse_chunk_binning_equals_the_dense_tables(oracle, monkeypatch):
+    """Grids of more than 2^27 chunks (resolutions beyond ~32 000: the x / y tile tests) bin the triangles by a sorted list of
+    (chunk, triangle) pairs instead of dense per-chunk tables; forced on small grids here, the two must agree record for record
+    (order included: ascending chunks, ascending triangles inside a chunk)."""
+    import numpy as np
+    from obj2voxel_amd import meshes
+    v, uv = meshes.uv_sphere(14, with_uv=True)
+    T = len(v)
+    kw = dict(uvs=uv, types=np.where(np.arange(T) % 2 == 0, 3, 2).astype(np.uint32), colors=meshes.triangle_colors(T),
+              texids=np.zeros(T, np.int32), textures=[(meshes.checker_texture(32, 4), 1)])
+    for res, ss, strategy, zslab in ((96, 1, 1, (0, 0)), (70, 2, 0, (0, 0)), (130, 1, 1, (40, 90))):
+        monkeypatch.delenv("O2V_ORACLE_SPARSE_BINS", raising=False)
+        dense = oracle.voxelize(v, res, supersampling=ss, strategy=strategy, zslab=zslab, **kw)
+        monkeypatch.setenv("O2V_ORACLE_SPARSE_BINS", "1")
+        sparse = oracle.voxelize(v, res, supersampling=ss, strategy=strategy, zslab=zslab, **kw)
+        assert len(dense) > 1000 and np.array_equal(meshes.sorted_voxels(dense), meshes.sorted_voxels(sparse))
+    monkeypatch.delenv("O2V_ORACLE_SPARSE_BINS", raising=False)
+    # a thin strip in the z = const plane of a 100 000^3 grid: only the sparse path can hold its chunk lists
+    strip = meshes.diagonal_strip(400, width=6e-5)
+    vox = oracle.voxelize(strip, 100_000)
+    assert len(vox) > 100_000 and int(vox[:, 0].max()) > 99_000 and int(vox[:, 1].max()) > 99_000 and int(vox[:, 2].max()) < 16

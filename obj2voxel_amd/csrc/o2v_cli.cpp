@@ -146,5 +146,9 @@ int main(int argc, char **argv)
 
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     std::printf("%s (%.3f s)\n", result == OBJ2VOXEL_ERR_OK ? "Done!" : "Failed", secs);
-    return result;
+    // The output file is written and closed (obj2voxel_voxelize / obj2voxel_free); what is left is the teardown of the HIP
+    // runtime behind the library's cached device session (static destructors, unmapping the dense grids): tens of
+    // milliseconds of a run that takes a few hundred, for a process that is about to vanish.  Streams flushed, then out.
+    std::fflush(nullptr);
+    std::_Exit(result);
 }

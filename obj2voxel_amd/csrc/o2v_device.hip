@@ -776,10 +776,22 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
     if (!out_ctx) return O2V_HIP_ERR_BAD_ARGUMENT;
     *out_ctx = nullptr;
     int n = 0;
+    // (O2V_INIT_TIMES=1: where a new process' first session spends its time - the runtime's start is most of a CLI run)
+    const char *init_times = std::getenv("O2V_INIT_TIMES");
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!(init_times && init_times[0] == '1')) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[o2v_hip_create] %s: %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return O2V_HIP_ERR_NO_DEVICE;
+    lap("hipGetDeviceCount (runtime start)");
     if (hipSetDevice(device) != hipSuccess) return O2V_HIP_ERR_NO_DEVICE;
+    lap("hipSetDevice");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return O2V_HIP_ERR_NO_DEVICE;
+    lap("hipGetDeviceProperties");
     o2v_hip_ctx *ctx = new o2v_hip_ctx;
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -808,10 +820,18 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
+    lap("streams, events, counters");
     ctx->d_block_count = &ctx->d_ctr->n_listed_blocks;
     // k_resolve_big sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_big), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int) (kBigList * 12u));
+    lap("hipFuncSetAttribute (code object)");
+    // the first pass' counters, zeroed now: the launch also makes the runtime load the device code here - on the thread that
+    // creates the session beside the input's parsing (obj2voxel_voxelize) - rather than in front of the first pass
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_ctr, kPassCounterWords);
+    if (hipStreamSynchronize(ctx->stream) == hipSuccess) ctx->ctr_clean = true;
+    else (void) hipGetLastError();
+    lap("first launch");
     *out_ctx = ctx;
     return O2V_HIP_OK;
 }

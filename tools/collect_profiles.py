@@ -11,7 +11,7 @@ import re
 import shutil
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 N_SIMDS, CLOCK_GHZ = 256 * 4, 2.4   # as bench.py
 src = "gpurun_out/prof"
 out_dir = os.path.join("profiles", rnd)

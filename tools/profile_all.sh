@@ -33,10 +33,10 @@ python -c "from obj2voxel_amd import hip; print(hip.build_id())" > $OUT/build_id
 [ -x tools/ubench/_build/valu_rates ] && timeout -k 5 60 tools/ubench/_build/valu_rates > $OUT/valu_rates.json 2>/dev/null
 # the summaries are made here, so that the bench line below reads the counters of THIS build (profiles/current.json), and
 # travel back under gpurun_out/ (copy gpurun_out/prof/profiles/* into profiles/ afterwards)
-ROUND=${O2V_ROUND:-r05}
+ROUND=${O2V_ROUND:-r06}
 mkdir -p profiles/$ROUND
 # the clip loop's instruction histogram priced with the measured issue costs (the mix-weighted ceiling of bench.py's roofline)
-RATES=profiles/r04/valu_rates.json; [ -s $OUT/valu_rates.json ] && cp $OUT/valu_rates.json profiles/$ROUND/valu_rates.json && RATES=profiles/$ROUND/valu_rates.json
+RATES=profiles/r05/valu_rates.json; [ -s $OUT/valu_rates.json ] && cp $OUT/valu_rates.json profiles/$ROUND/valu_rates.json && RATES=profiles/$ROUND/valu_rates.json
 python tools/isa_hist.py --rates $RATES --json profiles/$ROUND/isa_hist.json > $OUT/isa_hist.txt 2>&1 && cp profiles/$ROUND/isa_hist.json profiles/current_isa.json
 python tools/collect_profiles.py $ROUND > $OUT/collect.log 2>&1
 # the bench line itself (with the routes, the CPU baseline and the C API wall time), unprofiled

@@ -274,7 +274,12 @@ const char *o2v_hip_comm_last_error(const o2v_hip_comm *comm);
  * (z_begin / z_end are ignored).  Plans work-balanced slabs from the sharded passes, voxelizes this rank's slab and
  * gathers the slab counts.  out_count: this rank's voxels (read them with o2v_hip_read_voxels); out_counts_all (optional):
  * world entries; out_cuts (optional): world + 1 ascending z cuts, rank r owns [out_cuts[r], out_cuts[r + 1]).
- * With a world of 1 this is o2v_hip_voxelize. */
+ * With a world of 1 this is o2v_hip_voxelize.  * Time limits: ncclCommInitRank and the run's first collective are given O2V_COMM_TIMEOUT_S seconds (120) for the other ranks to
+ * arrive; after that the call fails with a message naming the rank.  A collective that timed out stays queued on the device:
+ * the context and the communicator are then unusable (every later call on them fails or would wait for ever), o2v_hip_destroy
+ * and o2v_hip_comm_destroy return without waiting for the device (the communicator is aborted, the context's device memory is
+ * left to the process' end) - the process should report the error and exit.
+ */
 int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip_params *params, uint64_t *out_count,
                              uint64_t *out_counts_all, uint32_t *out_cuts);
 

@@ -24,6 +24,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;   // (optional)
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
@@ -68,6 +69,7 @@ RcclApi *rccl_api()
         api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
         api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
@@ -91,7 +93,9 @@ struct RcclComm final : o2v_hip_comm {
     {
         if (comm) {
             if (device >= 0) (void) hipSetDevice(device);
-            (void) api->CommDestroy(comm);
+            // (ncclCommDestroy waits for the communicator's outstanding work: with a collective stuck on a stream it would never return)
+            if (!poisoned) (void) api->CommDestroy(comm);
+            else if (api->CommAbort) (void) api->CommAbort(comm);
         }
     }
     const char *kind() const override { return "rccl"; }

@@ -26,6 +26,9 @@
 struct o2v_hip_comm {
     int rank = 0, world = 1;
     std::string err;
+    // A collective of this communicator is stuck on a stream (a rank never arrived and the time limit passed): it must not be
+    // waited for again - the destructor then aborts the communicator (ncclCommAbort) or leaves it to the process' end.
+    bool poisoned = false;
     virtual ~o2v_hip_comm() {}
     virtual const char *kind() const = 0;
     // All buffers are device memory of the calling rank; operations are in place and ordered on `stream`.

@@ -102,6 +102,7 @@ struct o2v_hip_ctx {
     uint64_t no_pool_key = 0;   // (key + 1 of) the mesh and settings whose last pass pooled no hits (run_pass: k_mark_bricks left out)
     bool marked_bricks = false, mark_missing = false; // the current pass listed its bricks before k_voxelize
     bool skip_big = false;      // no leaf of the uploaded mesh can have more than four tiles (its largest triangle's extent): k_expand_big left out
+    bool poisoned = false;      // a collective of a sharded run is stuck on the stream (time limit passed): o2v_hip_destroy must not wait for it
     bool ctr_clean = false;     // d_ctr was zeroed (k_init) behind the last pass and nothing has touched it since
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // the cooperative resolve tiers run beside tier 1
     hipEvent_t ev_fork = nullptr, ev_sorted = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -839,6 +840,12 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
 void o2v_hip_destroy(o2v_hip_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->poisoned) {
+        // a stuck collective is queued on the context's stream (o2v_hip_voxelize_sharded timed out): synchronising or freeing would
+        // block for ever.  The device memory goes with the process, which the caller was told to end (include/o2v_hip.h).
+        delete ctx;
+        return;
+    }
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     void *ptrs[] = {ctx->d_verts, ctx->d_uvs,  ctx->d_colors,   ctx->d_types,    ctx->d_texids, ctx->d_textures,
@@ -1879,7 +1886,13 @@ int o2v_hip_voxelize_sharded(o2v_hip_ctx *ctx, o2v_hip_comm *comm, const o2v_hip
         O2V_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, s0));
         // (the first collective of the run: if a rank of the job never gets here - it died, or the node is set up wrongly - the
         // others say so after o2v::comm_timeout_seconds() instead of waiting for ever)
-        if (!o2v::stream_wait_limited(s0, "the readiness all-reduce of the sharded run", ctx->err)) return O2V_HIP_ERR_HIP;
+        if (!o2v::stream_wait_limited(s0, "the readiness all-reduce of the sharded run", ctx->err)) {
+            // the collective stays queued on the stream: nothing may wait for this stream or this communicator again (a later
+            // hipFree / hipStreamSynchronize / ncclCommDestroy would only move the hang to the teardown)
+            ctx->poisoned = true;
+            comm->poisoned = true;
+            return O2V_HIP_ERR_HIP;
+        }
         if (time_it) O2V_CHECK(hipEventElapsedTime(&parts_ms[0], ctx->ev_coll[0], ctx->ev_coll[1]));
         if (rc_prepare) {
             ctx->err = prepare_err;

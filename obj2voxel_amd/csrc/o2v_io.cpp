@@ -567,7 +567,9 @@ struct ListSink final : VoxelSink {
             out.put(s.data(), s.size());
             return;
         }
-        // big-endian words: into the memory sink's buffer directly, or in place (a sink may modify the batch) and out to the file
+        // big-endian words: into the memory sink's buffer directly, or in place and out to the file (VoxelSink::write: the batch is
+        // the sink's to clobber - it is the read-back staging buffer, overwritten by the next batch anyway)
+        static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "the byte swap below makes big-endian words on a little-endian host");
         if (out.file) {
             for (size_t i = 0; i < count * 4; ++i) voxels[i] = __builtin_bswap32(voxels[i]);
             out.put(voxels, count * 16);
@@ -580,7 +582,11 @@ struct ListSink final : VoxelSink {
     }
     void expect(size_t voxels) override
     {
-        if (!out.file && format != FileFormat::XYZRGB) out.ok = out.ok && out.mem.reserve(voxels * 16);
+        if (!out.file && format != FileFormat::XYZRGB && !out.mem.reserve(voxels * 16)) {
+            // (said here, where it happens: a failed sink otherwise only shows as an IO error after the voxelization)
+            if (out.ok) log_message(LOG_ERROR, "out of memory: the output buffer for " + std::to_string(voxels) + " voxels (" + std::to_string(voxels * 16) + " bytes) could not be reserved");
+            out.ok = false;
+        }
     }
     void finalize() override
     {

@@ -57,7 +57,8 @@ struct VoxelSink {  // reference io.hpp:69-92
     size_t written = 0;
     virtual ~VoxelSink() = default;
     virtual bool can_write() const = 0;
-    /// `voxels` holds count (x, y, z, argb) quadruples; a sink may modify the buffer.
+    /// `voxels` holds count (x, y, z, argb) quadruples.  The batch is consumed: a sink may clobber it (the file sinks byte-swap
+    /// it in place), so a caller that wants to hand one batch to two sinks must copy it.
     virtual void write(uint32_t *voxels, size_t count) = 0;
     virtual void finalize() = 0;
     /// The in-memory bytes of a memory sink, else null.

@@ -42,6 +42,8 @@ python tools/collect_profiles.py $ROUND > $OUT/collect.log 2>&1
 # the bench line itself (with the routes, the CPU baseline and the C API wall time), unprofiled
 timeout -k 5 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 cp $OUT/bench_line.json profiles/$ROUND/bench_line.json
+# (the stdout line is the compact object the driver parses; everything else bench.py gathered is in its details file)
+cp bench_details.json profiles/$ROUND/bench_details.json 2>/dev/null
 # predicted multi-GPU balance (one GPU runs the planned slabs of the N = 8 jobs one after the other)
 timeout -k 5 200 python tools/predict_scaling.py 8 weak > $OUT/predict_scaling_8_weak.jsonl 2>&1
 timeout -k 5 500 python tools/predict_scaling.py 8 config4 > $OUT/predict_scaling_8_config4.jsonl 2>&1

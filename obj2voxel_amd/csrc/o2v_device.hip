@@ -491,6 +491,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
     const bool decide_from_k1 = p.direct_max && !(p.occupancy_only && !ctx->force_general);
     if (decide_from_k1) {
         // K1's counters go to the host on an auxiliary stream while k_voxelize runs (see below)
+        if (!ctx->aux[0]) O2V_CHECK(hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking));
         O2V_CHECK(hipEventRecord(ctx->ev_k1, s));
         O2V_CHECK(hipStreamWaitEvent(ctx->aux[0], ctx->ev_k1, 0));
         O2V_CHECK(hipMemcpyAsync(ctx->h_ctr, ctx->d_ctr, kPassCounterWords * 4u, hipMemcpyDeviceToHost, ctx->aux[0]));
@@ -572,7 +573,7 @@ int run_pass(o2v_hip_ctx *ctx, const Params &p, bool use_uv, uint32_t n_rounds)
         const bool fork = debug_sync_level() != 1;
         hipStream_t sw = s, sm = s, sl = s;
         if (fork) {
-            for (int j = 1; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
                 if (!ctx->aux[j]) O2V_CHECK(hipStreamCreateWithFlags(&ctx->aux[j], hipStreamNonBlocking));
             sw = ctx->aux[0];
             sm = ctx->aux[1];
@@ -800,6 +801,7 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
         delete ctx;
         return O2V_HIP_ERR_HIP;
     }
+    lap("the stream");
     for (auto &e : ctx->ev)
         if (create_timing_event(&e) != hipSuccess) {
             delete ctx;
@@ -811,17 +813,23 @@ int o2v_hip_create(int device, o2v_hip_ctx **out_ctx)
     // (aux[1] and aux[2] - the cooperative resolve tiers - are created by the first pass that forks; a stream costs 0.3 ms
     // in a warm process and several in a new one, and a mesh on the direct route never needs them)
     for (int j = 0; j < 3 && ok; ++j) ok = hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking) == hipSuccess;
+    lap("events");
+    // (the auxiliary streams are made by the first pass that needs one - 7 - 8 ms each in a new process, and the occupancy-only
+    // route, every STL, never does)
     if (!ok) {
         delete ctx;
         return O2V_HIP_ERR_HIP;
     }
-    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_ctr), sizeof(Counters)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&ctx->h_ctr), sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_ctr), sizeof(Counters)) != hipSuccess) {
         delete ctx;
         return O2V_HIP_ERR_OUT_OF_MEMORY;
     }
-    lap("streams, events, counters");
+    lap("first hipMalloc");
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_ctr), sizeof(Counters), hipHostMallocDefault) != hipSuccess) {
+        delete ctx;
+        return O2V_HIP_ERR_OUT_OF_MEMORY;
+    }
+    lap("first hipHostMalloc");
     ctx->d_block_count = &ctx->d_ctr->n_listed_blocks;
     // k_resolve_big sorts in 96 KiB of dynamic LDS (above the default 64 KiB limit)
     (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resolve_big), hipFuncAttributeMaxDynamicSharedMemorySize,

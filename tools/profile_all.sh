@@ -18,6 +18,9 @@ for W in $WL; do
   if [ $W = config2 ]; then CMD="python bench.py --no-cpu-baseline --no-capi --no-routes"; S1="--steps 20 --warmup 3"; S2="--steps 3 --warmup 1"
   else CMD="python tools/run_workload.py $W"; S1="--steps 10 --warmup 2"; S2="--steps 3 --warmup 1"; fi
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${W}_stats -o s -- $CMD $S1 > $OUT/${W}_stats.log 2>&1
+  grep "^{" $OUT/${W}_stats.log | tail -1 > $OUT/${W}_line.json
+  # (bench.py's stdout line is the compact object: the device statistics collect_profiles.py wants are in its details file)
+  [ $W = config2 ] && [ -s bench_details.json ] && cp bench_details.json $OUT/${W}_line.json
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${W}_$c -o p -- $CMD $S2 > $OUT/${W}_$c.log 2>&1
   done
@@ -26,7 +29,6 @@ for W in $WL; do
   if [ $W = config2 ] || [ $W = config3 ] || [ $W = config2_blend ]; then
     timeout -k 5 300 rocprofv3 --kernel-trace --pmc $SQ3 --output-format csv -d $OUT/${W}_sq3 -o p -- $CMD $S2 > $OUT/${W}_sq3.log 2>&1
   fi
-  grep "^{" $OUT/${W}_stats.log | tail -1 > $OUT/${W}_line.json
 done
 python -c "from obj2voxel_amd import hip; print(hip.build_id())" > $OUT/build_id.txt
 # issue costs of the instructions the clip loop is made of (make -C tools/ubench here, before the gpurun call)

@@ -585,6 +585,8 @@ def report(args, n, run, dv, comm):
         # that are one leaf of one tile (here: all) have no Leaf / Tile records: both kernels read their 36 bytes.
         Lb = st.get("bypassed_leaves", 0)
         alg["expand"] = 36 * T + 96 * (L - Lb) + 8 * (tiles - Lb)
+        if run.get("kernels_ms") and "k_expand_roots" not in run["kernels_ms"] and "k_count_roots" not in run["kernels_ms"]:
+            alg["expand"] = 0   # no root stage at all (every triangle less than five voxels across: k_voxelize_occ makes and counts the leaves)
         alg["voxelize"] = 36 * T + 96 * (L - Lb) + 8 * (tiles - Lb) + 16 * st["jobs"] + 16 * (st["jobs"] - st.get("skipped_jobs", 0)) + 2 * H
         stage_kernels["resolve"] = ["k_emit_occ"]
         alg["resolve"] = 2 * CPB * D + 16 * Vr

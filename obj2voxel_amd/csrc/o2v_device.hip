@@ -1634,6 +1634,7 @@ int plan_passes(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t tri_beg
     p.n_tris = ctx->n_tris;
     p.S = G * ss;
     p.G = G;
+    for (int k = 0; k < 3; ++k) p.cs_hi[k] = p.S;   // (the planning passes see the whole grid: no crop, no tile)
     p.bounds_known = params->bounds_known;
     for (int i = 0; i < 6; ++i) p.bounds[i] = params->bounds[i];
     for (int i = 0; i < 9; ++i) p.unit[i] = params->unit_transform[i];

@@ -151,6 +151,7 @@ struct o2v_hip_ctx {
     uint32_t *d_slabs = nullptr;        // cap_slabs x kInlineHits x 64 hit records (sorted_stride dwords each)
     uint32_t cap_slabs = 0, slabs_stride = 0;
     uint64_t want_slabs_next = 0;       // the brick list of the last pass (+ 1/8): what the slabs are grown to at the next call
+    uint64_t slabs_wanted_at_grant = 0; // what was asked for when the slabs were last allocated (they may have got less: the memory was short)
     uint32_t cap_pick_extra = 0;
     PickRec *d_pick_extra = nullptr;  // textured MAX: {cell, key, argb} of the cells resolved by replay (6 words, cap_vox of them)
     unsigned long long *d_maxgrid = nullptr;  // direct MAX path: one 64-bit cell per output voxel (same bricked layout)
@@ -1334,6 +1335,7 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
         if (ctx->d_slabs) O2V_CHECK(hipFree(ctx->d_slabs));
         ctx->d_slabs = nullptr;
         ctx->slabs_stride = slab_stride;
+        ctx->slabs_wanted_at_grant = 0;
     }
     uint64_t want_slabs = 0;
     if (!p.occupancy_only) {
@@ -1462,7 +1464,10 @@ int o2v_hip_voxelize(o2v_hip_ctx *ctx, const o2v_hip_params *params, uint64_t *o
             if ((rc = grow_required(ctx->d_scratch_idx, cap_s1, want_scratch))) return rc;
             ctx->cap_scratch = cap_s0;
         }
-        if (want_slabs > ctx->cap_slabs) {
+        // (a grant below what was asked for - the memory was short - is kept until more is asked for than then: asking again
+        // with every call would free and allocate the slabs every time)
+        if (want_slabs > ctx->cap_slabs && !(ctx->cap_slabs && want_slabs <= ctx->slabs_wanted_at_grant)) {
+            ctx->slabs_wanted_at_grant = want_slabs;
             if (ctx->d_slabs) O2V_CHECK(hipFree(ctx->d_slabs));
             ctx->d_slabs = nullptr;
             ctx->cap_slabs = 0;

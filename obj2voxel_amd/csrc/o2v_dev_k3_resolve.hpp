@@ -281,21 +281,68 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const Occ *__restrict__ occ,
         __syncthreads();
     }
     const uint32_t n = c->n_vox < p.cap_vox ? c->n_vox : p.cap_vox;
+    if (part == 0u) {
+        // The inline cells with up to four hits - most cells of most meshes - in a software pipeline.  A cell is a chain of
+        // dependent round trips (its entry of the list -> its records in the brick's slab -> its triangles' materials -> a texel),
+        // and this launch, with two workgroups per CU so that the tiers beside it have room, was the stage's longest (the bench
+        // mesh with BLEND: 334 of its 385 us, 37 cells per lane one after the other).  Now the entry of the cell after next and
+        // the records of the next cell are requested before the current cell's arithmetic: one or two round trips a cell are
+        // left exposed (materials, texel) instead of three or four.  Same loads, same arithmetic, same results.
+        const SortedView slabs{slabs_dyn.base, STRIDE};
+        const uint32_t step = gridDim.x * kBlock;
+        auto wanted = [](const Occ &o) { return (o.count & kOccInline) != 0u && (o.count & ~kOccInline) <= kFourList; };
+        auto fetch = [&](const Occ &o, SortedRec (&r)[kFourList]) {
+            const uint32_t cnt = o.count & ~kOccInline;
+            const size_t first = ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits;
+#pragma unroll
+            for (uint32_t k = 0; k < kFourList; ++k) {
+                r[k] = SortedRec{0u, 0u, 0.f, 0.f, 0.f, 0u};
+                if (k < cnt) r[k] = slabs.load(first + k);
+            }
+        };
+        uint32_t i0 = blockIdx.x * kBlock + threadIdx.x, i1 = i0 + step;
+        Occ o0{}, o1{};
+        bool q0 = false;
+        SortedRec r0[kFourList], r1[kFourList];
+#pragma unroll
+        for (uint32_t k = 0; k < kFourList; ++k) r0[k] = r1[k] = SortedRec{0u, 0u, 0.f, 0.f, 0.f, 0u};
+        if (i0 < n) {
+            o0 = occ[i0];
+            q0 = wanted(o0);
+            if (q0) fetch(o0, r0);
+        }
+        if (i1 < n) o1 = occ[i1];
+        while (i0 < n) {
+            const bool q1 = i1 < n && wanted(o1);
+            if (q1) fetch(o1, r1);                      // the next cell's records ...
+            const uint32_t i2 = i1 + step;
+            Occ o2{};
+            if (i2 < n) o2 = occ[i2];                   // ... and the entry of the one after it
+            if (q0) {
+                GroupFold f;
+                const uint32_t argb = resolve_cell_in_registers<STRIDE, kFourList>([&](uint32_t k) { return r0[k]; }, o0.count & ~kOccInline, m, s_tex, p, f);
+                emit_cell(o0, argb, f.cell_acc.w, f.cell_key, out, i0, c, p);
+            }
+            o0 = o1;
+            q0 = q1;
+#pragma unroll
+            for (uint32_t k = 0; k < kFourList; ++k) r0[k] = r1[k];
+            o1 = o2;
+            i0 = i1;
+            i1 = i2;
+        }
+        return;
+    }
+    // part 1: the short cells of bricks without a slab (their hits are in the sorted array; none as a rule)
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const Occ o = occ[i];
         const uint32_t count = o.count & ~kOccInline;
         if (count > kShortList) continue;  // filed for another tier by k_scan_bricks
-        // an inline cell's hits are in its brick's slab (Occ::offset names it), the others' in the sorted array
-        const bool inl = (o.count & kOccInline) != 0u;
-        if (inl != (part == 0u)) continue;
-        if (inl && count > kFourList) continue;  // filed for k_resolve_inline_list by k_scan_bricks
-        const SortedView from{inl ? slabs_dyn.base : sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
-        const size_t first = inl ? ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits : (size_t) o.offset;
+        if ((o.count & kOccInline) != 0u) continue;  // an inline cell: part 0, or k_resolve_inline_list
+        const SortedView from{sorted_dyn.base, STRIDE};  // compile-time stride: the preloads stay branch-free
+        const size_t first = (size_t) o.offset;
         GroupFold f;
-        // (part is uniform: the inline cells left here have at most four hits - a 5-exchange network instead of 19 and one colour
-        // step instead of two)
-        const uint32_t argb = part == 0u ? resolve_cell_in_registers<STRIDE, kFourList>([&](uint32_t k) { return from.load(first + k); }, count, m, s_tex, p, f)
-                                         : resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return from.load(first + k); }, count, m, s_tex, p, f);
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return from.load(first + k); }, count, m, s_tex, p, f);
         emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
     }
 }
@@ -315,14 +362,30 @@ __global__ __launch_bounds__(kBlock) void k_resolve_inline_list(const uint32_t *
         __syncthreads();
     }
     const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
-    for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < total; item += gridDim.x * kBlock) {
-        const uint32_t i = list[item];
-        const Occ o = occ[i];
-        const size_t first = ((size_t) o.offset * kBrickCells + (o.cell_lo & (kBrickCells - 1u))) * kInlineHits;
+    // (the list entry of the cell after next and the next cell's entry of the cell list are requested ahead of this cell's
+    // records: three dependent round trips a cell - records, materials, texel - instead of five; see k_resolve)
+    const uint32_t step = gridDim.x * kBlock;
+    uint32_t item = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t i0 = 0, i1 = 0;
+    Occ o0{};
+    if (item < total) {
+        i0 = list[item];
+        o0 = occ[i0];
+    }
+    if (item + step < total) i1 = list[item + step];
+    for (; item < total; item += step) {
+        Occ o1{};
+        uint32_t i2 = 0;
+        if (item + step < total) o1 = occ[i1];
+        if (item + 2u * step < total) i2 = list[item + 2u * step];
+        const size_t first = ((size_t) o0.offset * kBrickCells + (o0.cell_lo & (kBrickCells - 1u))) * kInlineHits;
         GroupFold f;
-        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return slabs.load(first + k); }, o.count & ~kOccInline, m,
+        const uint32_t argb = resolve_cell_in_registers<STRIDE, kShortList>([&](uint32_t k) { return slabs.load(first + k); }, o0.count & ~kOccInline, m,
                                                                             s_tex, p, f);
-        emit_cell(o, argb, f.cell_acc.w, f.cell_key, out, i, c, p);
+        emit_cell(o0, argb, f.cell_acc.w, f.cell_key, out, i0, c, p);
+        o0 = o1;
+        i0 = i1;
+        i1 = i2;
     }
 }
 
@@ -341,6 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_list16(const uint32_t *__res
         __syncthreads();
     }
     const uint32_t total = *n_list < list_cap ? *n_list : list_cap;
+    // (no loads ahead here, unlike k_resolve_inline_list: five more registers put the uv variant above 128 - three wavefronts per SIMD)
     for (uint32_t item = blockIdx.x * kBlock + threadIdx.x; item < total; item += gridDim.x * kBlock) {
         const uint32_t i = list[item];
         const Occ o = occ[i];
